@@ -1,0 +1,91 @@
+"""Oracle (test infrastructure, NOT product code).
+
+ctypes binding of oracle/liboracle.so (dispatch_oracle.c, the plain-C
+restatement of yadcc/scheduler/task_dispatcher.cc:283-451).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+IDX_TIMEOUT = 0xFFFFFFFF
+IDX_ENV_NOT_FOUND = 0xFFFFFFFE
+MIN_MEMORY_DEFAULT = 10 << 30  # --servant_min_memory_for_accepting_new_task=10G (task_dispatcher.cc:35)
+
+
+class _Servants(C.Structure):
+    _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in (
+        "version", "num_processors", "current_load", "max_tasks", "priority", "total_memory",
+        "memory_available", "env_mask", "ip")]
+
+
+class _Tasks(C.Structure):
+    _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in (
+        "env_id", "min_version", "requestor_ip")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_SO)
+        for name in ("oracle_dispatch_scan", "oracle_dispatch_sorted"):
+            f = getattr(L, name)
+            f.argtypes = [C.POINTER(_Servants), C.c_uint64, C.POINTER(_Tasks), C.c_void_p,
+                          C.c_void_p, C.c_void_p]
+            f.restype = C.c_size_t
+        L.oracle_capacity_available.argtypes = [C.c_uint32] * 3 + [C.c_uint64] * 4
+        L.oracle_capacity_available.restype = C.c_uint64
+        L.oracle_try_parse_size.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+        L.oracle_try_parse_size.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _col(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def dispatch(sv, tk, method="sorted", min_memory=MIN_MEMORY_DEFAULT, want_util=True):
+    """Runs the oracle on column dicts (see yadcc_amd.synth). Returns
+    (servant_idx[N] u32, util[N] f64 or None, running_after[S] u32)."""
+    keep = []
+    S = _Servants()
+    S.n = len(sv["version"])
+    for k, dt in (("version", np.uint32), ("num_processors", np.uint32),
+                  ("current_load", np.uint32), ("max_tasks", np.uint32),
+                  ("priority", np.uint32), ("total_memory", np.uint64),
+                  ("memory_available", np.uint64), ("env_mask", np.uint64), ("ip", np.uint32)):
+        a = _col(sv[k], dt)
+        keep.append(a)
+        setattr(S, k, a.ctypes.data)
+    T = _Tasks()
+    T.n = len(tk["env_id"])
+    for k in ("env_id", "min_version", "requestor_ip"):
+        a = _col(tk[k], np.uint32)
+        keep.append(a)
+        setattr(T, k, a.ctypes.data)
+    running = np.array(sv["running_tasks"], dtype=np.uint32, copy=True)
+    out = np.empty(T.n, dtype=np.uint32)
+    util = np.empty(T.n, dtype=np.float64) if want_util else None
+    fn = lib().oracle_dispatch_scan if method == "scan" else lib().oracle_dispatch_sorted
+    fn(C.byref(S), min_memory, C.byref(T), running.ctypes.data, out.ctypes.data,
+       util.ctypes.data if want_util else None)
+    return out, util, running
+
+
+def capacity_available(nproc, load, max_tasks, total_mem, mem_avail, running,
+                       min_memory=MIN_MEMORY_DEFAULT):
+    return lib().oracle_capacity_available(nproc, load, max_tasks, total_mem, mem_avail, running,
+                                           min_memory)
+
+
+def try_parse_size(s):
+    v = C.c_uint64(0)
+    rc = lib().oracle_try_parse_size(s.encode(), C.byref(v))
+    return None if rc else v.value
