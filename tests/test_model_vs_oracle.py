@@ -1,0 +1,40 @@
+"""CPU replay of the device pipeline (tests/model, built from the SAME placement
+headers the kernels use) against the oracle: bit-exact placement, exact
+utilisation, exact post-batch running_tasks."""
+import numpy as np
+import pytest
+
+from oracle import oraclebind as O
+from tests import cases
+from tests.model import modelbind as M
+
+
+def _check(sv, tk, chunk, fp64=False):
+    want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+    got, gutil, grun, st = M.dispatch(sv, tk, chunk, fp64)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gutil, wutil)  # same IEEE division on both sides => bit-equal
+    assert np.array_equal(grun, wrun)
+    return st
+
+
+@pytest.mark.parametrize("name,kw", cases.SMALL_CASES, ids=[c[0] for c in cases.SMALL_CASES])
+@pytest.mark.parametrize("chunk", [0, 64, 1000])
+def test_model_matches_oracle(name, kw, chunk):
+    sv, tk = cases.random_case(**kw)
+    _check(sv, tk, chunk)
+    _check(sv, tk, chunk, fp64=True)
+
+
+@pytest.mark.parametrize("name,sv,tk", cases.handmade_cases(),
+                         ids=[c[0] for c in cases.handmade_cases()])
+def test_model_handmade(name, sv, tk):
+    for chunk in (0, 2, 7):
+        _check(sv, tk, chunk)
+
+
+def test_speculation_converges_quickly():
+    sv, tk = cases.random_case(seed=21, n_tasks=100_000, n_servants=2000, n_envs=4,
+                               unknown_env_frac=0.001)
+    st = _check(sv, tk, 1024)
+    assert st.n_chunks == 98 and st.rounds <= 4 and st.chunk_sims <= 2 * st.n_chunks

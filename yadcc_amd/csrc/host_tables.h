@@ -1,0 +1,101 @@
+// host_tables.h — host-side derived tables of the resident servant registry.
+//
+// Built once per registry change (upload / heartbeat), never per dispatch:
+//   * servant classes: servants with max_tasks != 0 grouped by the signature
+//     (env_mask, version) that decides eligibility for every possible request
+//     (reference yadcc/scheduler/task_dispatcher.cc:324-338);
+//   * the ip table: servants sorted by (ip_id, registry index), used to find a
+//     request's own servant (`self`, :372-379) with a binary search;
+//   * cap_bits: bit width of the largest capacity any pick can see, which fixes
+//     the integer sort-key format (dispatch_core.h: slot_key_exact).
+#ifndef YADCC_AMD_HOST_TABLES_H_
+#define YADCC_AMD_HOST_TABLES_H_
+
+#include <algorithm>
+#include <cstdint>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "dispatch_core.h"
+
+namespace ydc {
+
+struct HostTables {
+  std::vector<uint32_t> class_of;   // per servant, kNone when max_tasks == 0
+  std::vector<uint64_t> cls_env;    // per class
+  std::vector<uint32_t> cls_ver;    // per class
+  std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant)
+  std::vector<uint32_t> ip_servant;
+  bool any_shared_ip = false;       // some host runs more than one servant
+  uint32_t cap_bits = 1;            // max over servants of bits(min(max_tasks, nproc))
+  uint64_t max_slots = 0;           // sum over servants of min(max_tasks, nproc): bound on slots
+
+  struct SigHash {
+    size_t operator()(const std::pair<uint64_t, uint32_t>& k) const {
+      return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ull ^ k.second);
+    }
+  };
+
+  void build(uint32_t n, const uint64_t* env_mask, const uint32_t* version,
+             const uint32_t* max_tasks, const uint32_t* nproc, const uint32_t* ip_id) {
+    class_of.assign(n, kNone);
+    cls_env.clear();
+    cls_ver.clear();
+    std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, SigHash> ids;
+    uint32_t max_cap = 1;
+    max_slots = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+      if (max_tasks[s] == 0) continue;
+      auto key = std::make_pair(env_mask[s], version[s]);
+      auto it = ids.find(key);
+      if (it == ids.end()) {
+        it = ids.emplace(key, (uint32_t)cls_env.size()).first;
+        cls_env.push_back(env_mask[s]);
+        cls_ver.push_back(version[s]);
+      }
+      class_of[s] = it->second;
+      uint32_t top = std::min(max_tasks[s], nproc[s]);
+      max_cap = std::max(max_cap, top);
+      max_slots += top;
+    }
+    cap_bits = 1;
+    while (cap_bits < 32 && (max_cap >> cap_bits)) ++cap_bits;
+
+    std::vector<std::pair<uint32_t, uint32_t>> byip(n);
+    for (uint32_t s = 0; s < n; ++s) byip[s] = {ip_id[s], s};
+    std::sort(byip.begin(), byip.end());
+    ip_sorted.resize(n);
+    ip_servant.resize(n);
+    any_shared_ip = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      ip_sorted[i] = byip[i].first;
+      ip_servant[i] = byip[i].second;
+      if (i && byip[i].first == byip[i - 1].first) any_shared_ip = true;
+    }
+  }
+
+  uint32_t n_classes() const { return (uint32_t)cls_env.size(); }
+};
+
+// Sort-key format for a registry.
+struct KeyFormat {
+  bool exact;         // slot_key_exact (integer) vs slot_key_fp64
+  uint32_t cap_bits;  // only for exact
+  uint32_t key_bits;  // significant bits
+  uint32_t passes;    // LSD radix passes
+  uint32_t bits_per_pass;
+};
+
+inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 11) {
+  KeyFormat f;
+  f.exact = cap_bits <= kMaxExactCapBits;
+  f.cap_bits = cap_bits;
+  f.key_bits = f.exact ? 2 * cap_bits + 1 : 64;
+  f.passes = (f.key_bits + max_radix_bits - 1) / max_radix_bits;
+  f.bits_per_pass = (f.key_bits + f.passes - 1) / f.passes;
+  return f;
+}
+
+}  // namespace ydc
+#endif  // YADCC_AMD_HOST_TABLES_H_
