@@ -1,0 +1,25 @@
+# Builds everything in-tree:
+#   yadcc_amd/libydc.so        HIP kernels + C-ABI (+ host C++ dispatcher), gfx950
+#   oracle/liboracle.so, oracle/_ref/libyadcc_ref.so   (test infrastructure)
+#   tests/model/libmodel.so    (test tool)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := yadcc_amd/csrc
+HIP_SRCS := $(CSRC)/ydc_api.hip $(wildcard $(CSRC)/*.cc)
+HDRS := $(wildcard $(CSRC)/*.h) include/yadcc_dispatch.h
+
+all: lib oracle model
+
+lib: yadcc_amd/libydc.so
+yadcc_amd/libydc.so: $(HIP_SRCS) $(HDRS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+	    -Iinclude -I$(CSRC) -o $@ $(HIP_SRCS)
+
+oracle:
+	$(MAKE) -s -C oracle
+model:
+	$(MAKE) -s -C tests/model
+clean:
+	rm -f yadcc_amd/libydc.so tests/model/libmodel.so
+	$(MAKE) -C oracle clean
+.PHONY: all lib oracle model clean

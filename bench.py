@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — task->servant assignments/s of the MI355X dispatch path.
+
+One "step" = one pass of the hot path over one batch: BASELINE.json configs[1]
+(100k pending requests x 2k servants, single compiler env) dispatched against the
+resident servant table, request columns and result buffers already in HBM. Each step
+starts from the same snapshot (no COMMIT), so every step does identical work.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): see DESIGN.md §multi-GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def percentile(a, q):
+    a = np.sort(np.asarray(a))
+    return float(a[min(len(a) - 1, int(np.ceil(q * len(a))) - 1)]) if len(a) else 0.0
+
+
+def cpu_baseline(sv, tk):
+    """The reference's own TaskDispatcher (oracle/_ref, compiled verbatim) on this host,
+    1 thread (everything in the reference runs under one lock), same snapshot."""
+    from oracle import refbind as R
+    from oracle import oraclebind as O
+    if R.available():
+        d = R.RefDispatcher()
+        d.load_servants(sv)
+        idx, _, secs, lat = d.dispatch_batch(tk, want_latency=True)
+        d.close()
+        granted = int((idx < R.IDX_ENV_NOT_FOUND).sum())
+        return idx, {
+            "value": granted / secs, "unit": "assignments/s", "cores": 1, "kind": "reference",
+            "sample": "full batch: %d sequential WaitForStartingNewTask calls, %d servants, %.2f s"
+                      % (len(idx), len(sv["version"]), secs),
+            "p99_latency_us": percentile(lat, 0.99) / 1e3,
+            "host_cores_available": os.cpu_count(),
+        }
+    t0 = time.perf_counter()
+    idx, _, _ = O.dispatch(sv, tk, "scan")
+    secs = time.perf_counter() - t0
+    granted = int((idx < O.IDX_ENV_NOT_FOUND).sum())
+    return idx, {"value": granted / secs, "unit": "assignments/s", "cores": 1, "kind": "port",
+                 "sample": "full batch through oracle_dispatch_scan, %.2f s" % secs,
+                 "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from yadcc_amd import binding, pack, synth
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # Weak scaling: every rank owns one snapshot of the named config (own seed).
+    sv, tk = synth.make_config(args.config, seed=42 + rank)
+    n_tasks, n_serv = len(tk["env_id"]), len(sv["version"])
+    stream = torch.cuda.current_stream()
+    ctx = binding.Context(device=local_rank, stream=stream.cuda_stream)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    d_env = torch.from_numpy(tk["env_id"].astype(np.int64)).to(dev).to(torch.int32)
+    d_minv = torch.from_numpy(tk["min_version"].astype(np.int64)).to(dev).to(torch.int32)
+    d_ip = torch.from_numpy(tk["requestor_ip"].astype(np.int64) - (1 << 32) * (
+        tk["requestor_ip"] >= (1 << 31))).to(dev).to(torch.int32)
+    d_out = torch.empty(n_tasks, dtype=torch.int32, device=dev)
+    d_run = torch.empty(n_serv, dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s0 = time.perf_counter()
+        step()  # returns after the batch's results are final in HBM (one stream sync inside)
+        lat.append(time.perf_counter() - s0)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    granted = st["granted"]
+    if dist:
+        t = torch.tensor([elapsed, float(granted)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, granted_all = float(tmax[0]), float(t[1])
+    else:
+        granted_all = float(granted)
+
+    # Per-kernel durations, HIP events on the dispatch stream (separate profiled steps so
+    # the events do not perturb the timed region).
+    ctx.set_profiling(True)
+    prof = {}
+    n_prof = max(3, min(20, args.steps))
+    for _ in range(n_prof):
+        step()
+        for k, (cnt, ms) in ctx.kernel_profile().items():
+            a = prof.setdefault(k, [0, 0.0])
+            a[0] += cnt
+            a[1] += ms
+    stage_ms = ctx.stats()["stage_ms"]
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        host_idx = d_out.cpu().numpy().view(np.uint32)
+        out = {
+            "metric": "task-to-servant assignments/sec on synthetic pool",
+            "value": granted_all * args.steps / elapsed,
+            "unit": "assignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 keys (exact integer image of the reference's fp64 utilisation)",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d pending requests x %d servants per GPU, %d classes"
+                                   % (args.config, n_tasks, n_serv, st["n_classes"]),
+                       "parallelism": "1 GPU" if world == 1 else
+                                      "%d independent snapshots, one per GPU" % world,
+                       "inputs": "request columns + servant table resident in HBM; results in HBM"},
+            "p99_dispatch_latency_ms": 1e3 * percentile(lat, 0.99),
+            "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
+            "stats": {k: v for k, v in st.items() if k != "stage_ms"},
+            "stage_ms": stage_ms,
+            "kernels_ms_per_step": {k: v[1] / n_prof for k, v in prof.items()},
+        }
+        # Roofline of the dominant kernel.
+        if prof:
+            dom = max(prof, key=lambda k: prof[k][1])
+            launches, total_ms = prof[dom]
+            alg_bytes = 16 * n_tasks + 40 * n_serv  # per batch
+            avg_launch_s = (total_ms / launches) * 1e-3
+            # one batch needs `launches / n_prof` launches of this kernel; each launch is
+            # charged the whole batch's algorithmic bytes (the kernel processes the batch)
+            ach = alg_bytes / avg_launch_s / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
+                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg_bytes,
+                               "avg_launch_us": avg_launch_s * 1e6,
+                               "launches_per_step": launches / n_prof}
+        if world == 1 and not args.no_cpu_baseline:
+            ref_idx, base = cpu_baseline(sv, tk)
+            out["cpu_baseline"] = base
+            out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx))
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

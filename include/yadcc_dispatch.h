@@ -141,6 +141,10 @@ int ydc_dispatch_device(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t 
 int ydc_synchronize(ydc_context* ctx);
 int ydc_set_profiling(ydc_context* ctx, int on);
 int ydc_get_stats(const ydc_context* ctx, ydc_stats* out);
+/* Profiling on: per-kernel totals of the most recent dispatch, measured with HIP
+ * events on the context stream, as JSON {"kernel": [launches, total_ms], ...}.
+ * The string lives until the next dispatch. */
+const char* ydc_kernel_profile(const ydc_context* ctx);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,201 @@
+"""Parity tests proper: the HIP path (through the C-ABI, yadcc_amd/libydc.so) against the
+oracle on the same seeded snapshots. Bit-exact placement and running_tasks; the
+chosen-servant utilisation is the same IEEE double division on both sides, so it is
+compared exactly too (north_star tolerance: 1e-6)."""
+import numpy as np
+import pytest
+
+from oracle import oraclebind as O
+from tests import cases
+from yadcc_amd import binding, pack, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = binding.Context(device=0)
+    yield c
+    c.close()
+
+
+def run_gpu(ctx, sv, tk, **kw):
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    return ctx.dispatch(tk, **kw)
+
+
+def check(ctx, sv, tk, method="sorted"):
+    want, wutil, wrun = O.dispatch(sv, tk, method)
+    got, gutil, grun = run_gpu(ctx, sv, tk)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at task %d: gpu %d oracle %d (%d total) stats=%s" % (
+        bad[0], got[bad[0]], want[bad[0]], bad.size, ctx.stats())
+    assert np.array_equal(grun, wrun)
+    assert np.allclose(gutil, wutil, rtol=0, atol=1e-6) and np.array_equal(gutil, wutil)
+    st = ctx.stats()
+    assert st["granted"] == int((want < O.IDX_ENV_NOT_FOUND).sum())
+    assert st["timeouts"] == int((want == O.IDX_TIMEOUT).sum())
+    assert st["env_not_found"] == int((want == O.IDX_ENV_NOT_FOUND).sum())
+    return st
+
+
+@pytest.mark.parametrize("name,kw", cases.SMALL_CASES, ids=[c[0] for c in cases.SMALL_CASES])
+def test_small_cases(ctx, name, kw):
+    sv, tk = cases.random_case(**kw)
+    check(ctx, sv, tk, "scan")  # literal restatement of the reference
+
+
+@pytest.mark.parametrize("name,sv,tk", cases.handmade_cases(),
+                         ids=[c[0] for c in cases.handmade_cases()])
+def test_handmade_cases(ctx, name, sv, tk):
+    check(ctx, sv, tk, "scan")
+
+
+def test_golden_load_balance(ctx):
+    """task_dispatcher_test.cc:216-298 through the GPU path, one request per batch with the
+    chosen servant re-heartbeated at load + 1, like the reference test."""
+    from tests.test_oracle_golden import LB, LB_EXPECT, _lb_columns
+    loads = [x[3] for x in LB]
+    running = [0] * len(LB)
+    one = {"env_id": np.zeros(1, np.uint32), "min_version": np.full(1, 8, np.uint32),
+           "requestor_ip": np.array([0x7F000003], np.uint32)}
+    sv0 = {k: v[:1] for k, v in _lb_columns(loads, running).items()}
+    idx, _, _ = run_gpu(ctx, sv0, one)
+    assert idx[0] == binding.IDX_TIMEOUT
+    got = []
+    for _ in LB_EXPECT:
+        idx, _, run = run_gpu(ctx, _lb_columns(loads, running), one)
+        got.append(int(idx[0]))
+        running = run.tolist()
+        loads[got[-1]] += 1
+    assert got == LB_EXPECT
+
+
+def test_golden_fixture_file(ctx):
+    """Committed golden vectors (tests/golden/*.npz) generated from the verbatim reference."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files, "no golden fixtures committed"
+    for f in files:
+        z = np.load(f)
+        sv = {k[3:]: z[k] for k in z.files if k.startswith("sv_")}
+        tk = {k[3:]: z[k] for k in z.files if k.startswith("tk_")}
+        got, _, grun = run_gpu(ctx, sv, tk)
+        assert np.array_equal(got, z["ref_servant_idx"]), f
+        assert np.array_equal(grun, z["ref_running_after"]), f
+
+
+def test_cfg2_full_size(ctx):
+    """BASELINE.json configs[1]: 100k tasks x 2k servants, single compiler env."""
+    sv, tk = synth.make_config("cfg2")
+    st = check(ctx, sv, tk)
+    assert st["n_tasks"] == 100_000 and st["n_servants"] == 2000
+
+
+def test_cfg2_oversubscribed(ctx):
+    sv, tk = synth.make_config("cfg2", oversubscribed=True)
+    st = check(ctx, sv, tk)
+    assert st["timeouts"] > 10_000
+
+
+def test_cfg3_full_size(ctx):
+    """BASELINE.json configs[2]: 1M tasks x 8k servants, 4 overlapping digests + env filtering."""
+    sv, tk = synth.make_config("cfg3")
+    st = check(ctx, sv, tk)
+    assert st["n_classes"] >= 20 and st["env_not_found"] > 0
+
+
+def test_cfg3_disjoint_envs(ctx):
+    sv, tk = synth.make_config("cfg3", disjoint_envs=True, n_tasks=300_000)
+    check(ctx, sv, tk)
+
+
+def test_properties_at_full_size(ctx):
+    """Size-independent properties on cfg3: conservation, capacity, eligibility, and the
+    monotonicity per (env, min_version) type of the utilisation keys."""
+    sv, tk = synth.make_config("cfg3")
+    got, util, run = run_gpu(ctx, sv, tk)
+    granted = got < binding.IDX_ENV_NOT_FOUND
+    # conservation: running_after - running_before == histogram of the placement
+    hist = np.bincount(got[granted], minlength=len(sv["version"]))
+    assert np.array_equal(run - sv["running_tasks"], hist)
+    # never above min(max_tasks, nproc); never on low-memory / overloaded / max_tasks == 0
+    top = np.minimum(sv["max_tasks"], sv["num_processors"])
+    assert (run <= np.maximum(top, sv["running_tasks"])).all()
+    flags = pack.servant_flags(sv)
+    dead = ((flags & 2) != 0) | (sv["current_load"] >= sv["num_processors"]) | (sv["max_tasks"] == 0)
+    assert hist[dead].sum() == 0
+    # eligibility of every grant
+    s = got[granted]
+    env = tk["env_id"][granted].astype(np.uint64)
+    assert ((sv["env_mask"][s] >> env) & np.uint64(1)).all()
+    assert (sv["version"][s] >= tk["min_version"][granted]).all()
+    # ENV_NOT_FOUND exactly for the unknown digest
+    assert np.array_equal(got == binding.IDX_ENV_NOT_FOUND, tk["env_id"] >= 64)
+
+
+def test_commit_then_second_batch(ctx):
+    """COMMIT keeps the grants in the resident running_tasks (task_dispatcher.cc:123): two
+    committed half batches == one full batch."""
+    sv, tk = cases.random_case(seed=31, n_tasks=20_000, n_servants=500, n_envs=3, self_frac=0.2)
+    want, _, wrun = O.dispatch(sv, tk, "sorted")
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    half = {k: v[:10_000] for k, v in tk.items()}
+    rest = {k: v[10_000:] for k, v in tk.items()}
+    a, _, _ = ctx.dispatch(half, commit=True)
+    b, _, run = ctx.dispatch(rest, commit=True)
+    assert np.array_equal(np.concatenate([a, b]), want)
+    assert np.array_equal(run, wrun) and np.array_equal(ctx.get_running(), wrun)
+
+
+def test_heartbeat_update_and_release(ctx):
+    """ydc_update_servants == KeepServantAlive of a known servant (personality replaced,
+    running_tasks kept, task_dispatcher.cc:195-201); ydc_release_slots == FreeTask's
+    --running_tasks (:181)."""
+    sv, tk = cases.random_case(seed=32, n_tasks=4000, n_servants=120, n_envs=2)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    a, _, run1 = ctx.dispatch(tk, commit=True)
+    # free every second grant, re-heartbeat 30 servants with a new load
+    granted = a[a < binding.IDX_ENV_NOT_FOUND]
+    freed = granted[::2]
+    ctx.release_slots(freed)
+    rng = np.random.default_rng(5)
+    who = rng.choice(len(sv["version"]), 30, replace=False)
+    sv2 = {k: v.copy() for k, v in sv.items()}
+    sv2["current_load"][who] = (rng.random(30) * sv2["num_processors"][who]).astype(np.uint32)
+    cols = pack.to_abi_columns(sv2)
+    rows = [{k: cols[k][s] for k in ("version", "num_processors", "current_load", "max_tasks",
+                                     "flags", "ip_id", "env_mask")} for s in who]
+    ctx.update_servants(who, rows)
+    sv2["running_tasks"] = (run1 - np.bincount(freed, minlength=len(run1))).astype(np.uint32)
+    assert np.array_equal(ctx.get_running(), sv2["running_tasks"])
+    _, tk2 = cases.random_case(seed=33, n_tasks=3000, n_servants=120, n_envs=2)
+    want, _, wrun = O.dispatch(sv2, tk2, "sorted")
+    got, _, grun = ctx.dispatch(tk2)
+    assert np.array_equal(got, want) and np.array_equal(grun, wrun)
+
+
+@pytest.mark.parametrize("chunk", [64, 256, 4096])
+def test_chunk_size_does_not_change_results(chunk, monkeypatch):
+    monkeypatch.setenv("YDC_CHUNK_SIZE", str(chunk))
+    c = binding.Context(device=0)
+    try:
+        sv, tk = cases.random_case(seed=34, n_tasks=60_000, n_servants=900, n_envs=4,
+                                   unknown_env_frac=0.001, self_frac=0.2)
+        st = check(c, sv, tk)
+        assert st["n_chunks"] == -(-60_000 // chunk)
+    finally:
+        c.close()
+
+
+def test_many_classes_paths(ctx):
+    """> 64 classes (two per lane) and > 256 classes (thread-per-chunk kernel)."""
+    sv, tk = cases.random_case(seed=35, n_tasks=20_000, n_servants=1500, n_envs=7,
+                               unknown_env_frac=0.002)
+    st = check(ctx, sv, tk)
+    assert 64 < st["n_classes"] <= 256
+    sv, tk = cases.random_case(seed=36, n_tasks=20_000, n_servants=3000, n_envs=10)
+    sv["version"] = (20 + np.arange(3000) % 3).astype(np.uint32)
+    st = check(ctx, sv, tk)
+    assert st["n_classes"] > 256

@@ -1,0 +1,210 @@
+"""ctypes binding of yadcc_amd/libydc.so (include/yadcc_dispatch.h).
+
+The library is the product; this file only marshals numpy / torch buffers. If the
+shared object is missing or no GPU is present every entry point raises — there
+is no CPU fallback on purpose.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libydc.so")
+
+IDX_TIMEOUT = 0xFFFFFFFF
+IDX_ENV_NOT_FOUND = 0xFFFFFFFE
+DISPATCH_COMMIT = 1
+STAGES = ("servant_scan", "slot_gen", "sort", "class_lists", "task_classify", "match", "finalize",
+          "total")
+
+# Every symbol include/yadcc_dispatch.h declares (tests check they are all exported).
+ABI_SYMBOLS = (
+    "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
+    "ydc_upload_servants", "ydc_update_servants", "ydc_release_slots", "ydc_set_running",
+    "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
+    "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile",
+)
+
+
+class ServantSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("version", "num_processors", "current_load",
+                                           "max_tasks", "running_tasks", "flags", "env_mask",
+                                           "ip_id")]
+
+
+class ServantRow(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("num_processors", C.c_uint32),
+                ("current_load", C.c_uint32), ("max_tasks", C.c_uint32), ("flags", C.c_uint32),
+                ("ip_id", C.c_uint32), ("env_mask", C.c_uint64)]
+
+
+class TaskSoA(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("env_id", "min_version", "requestor_ip")]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in (
+        "n_tasks", "n_servants", "n_classes", "n_slots", "key_bits", "radix_passes", "n_chunks",
+        "rounds", "chunk_sims", "granted", "timeouts", "env_not_found")] + [
+            ("stage_ms", C.c_float * 16)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_ms"}
+        d["stage_ms"] = {name: float(self.stage_ms[i]) for i, name in enumerate(STAGES)}
+        return d
+
+
+_lib = None
+
+
+class YdcError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libydc.so or raises (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YdcError("%s is missing: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                           "this package has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ydc_strerror.restype = C.c_char_p
+        L.ydc_strerror.argtypes = [C.c_int]
+        L.ydc_last_error.restype = C.c_char_p
+        L.ydc_last_error.argtypes = [C.c_void_p]
+        L.ydc_abi_version.restype = C.c_uint32
+        L.ydc_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                 C.POINTER(C.c_void_p)]
+        L.ydc_destroy.argtypes = [C.c_void_p]
+        L.ydc_upload_servants.argtypes = [C.c_void_p, C.POINTER(ServantSoA), C.c_uint32]
+        L.ydc_update_servants.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ServantRow),
+                                          C.c_uint32]
+        L.ydc_release_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ydc_set_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ydc_get_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ydc_dispatch.argtypes = [C.c_void_p, C.POINTER(TaskSoA), C.c_uint32, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ydc_dispatch_device.argtypes = L.ydc_dispatch.argtypes
+        L.ydc_synchronize.argtypes = [C.c_void_p]
+        L.ydc_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.ydc_kernel_profile.argtypes = [C.c_void_p]
+        L.ydc_kernel_profile.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch tensor
+
+
+class Context:
+    """One ydc_context: a resident servant registry on one GPU + batch dispatch."""
+
+    def __init__(self, device=0, max_servants=0, max_tasks=0, max_slots=0, stream=None):
+        h = C.c_void_p()
+        rc = lib().ydc_create(device, max_servants, max_tasks, max_slots, stream, C.byref(h))
+        if rc:
+            raise YdcError("ydc_create: %s" % lib().ydc_strerror(rc).decode())
+        self._h = h
+        self.n_servants = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ydc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise YdcError("%s: %s (%s)" % (what, lib().ydc_strerror(rc).decode(),
+                                            lib().ydc_last_error(self._h).decode()))
+
+    def upload_servants(self, cols):
+        """cols: dict of numpy columns named like ydc_servant_soa (see pack.to_abi_columns)."""
+        keep = {}
+        soa = ServantSoA()
+        for k, dt in (("version", np.uint32), ("num_processors", np.uint32),
+                      ("current_load", np.uint32), ("max_tasks", np.uint32),
+                      ("running_tasks", np.uint32), ("flags", np.uint32),
+                      ("env_mask", np.uint64), ("ip_id", np.uint32)):
+            keep[k] = np.ascontiguousarray(cols[k], dtype=dt)
+            setattr(soa, k, keep[k].ctypes.data)
+        n = len(keep["version"])
+        self._check(lib().ydc_upload_servants(self._h, C.byref(soa), n), "ydc_upload_servants")
+        self.n_servants = n
+
+    def update_servants(self, idx, rows):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        arr = (ServantRow * len(rows))()
+        for i, r in enumerate(rows):
+            for k in ("version", "num_processors", "current_load", "max_tasks", "flags", "ip_id",
+                      "env_mask"):
+                setattr(arr[i], k, int(r[k]))
+        self._check(lib().ydc_update_servants(self._h, idx.ctypes.data, arr, len(rows)),
+                    "ydc_update_servants")
+        if len(idx):
+            self.n_servants = max(self.n_servants, int(idx.max()) + 1)
+
+    def release_slots(self, servant_idx):
+        a = np.ascontiguousarray(servant_idx, dtype=np.uint32)
+        self._check(lib().ydc_release_slots(self._h, a.ctypes.data, len(a)), "ydc_release_slots")
+
+    def set_running(self, running):
+        a = np.ascontiguousarray(running, dtype=np.uint32)
+        self._check(lib().ydc_set_running(self._h, a.ctypes.data, len(a)), "ydc_set_running")
+
+    def get_running(self):
+        out = np.empty(self.n_servants, np.uint32)
+        self._check(lib().ydc_get_running(self._h, out.ctypes.data, len(out)), "ydc_get_running")
+        return out
+
+    def dispatch(self, tasks, commit=False, want_util=True, want_running=True):
+        """Host numpy columns in, numpy out: (servant_idx, utilization|None, running_after|None)."""
+        keep = [np.ascontiguousarray(tasks[k], dtype=np.uint32)
+                for k in ("env_id", "min_version", "requestor_ip")]
+        n = len(keep[0])
+        soa = TaskSoA(*[a.ctypes.data for a in keep])
+        out = np.empty(n, np.uint32)
+        util = np.empty(n, np.float64) if want_util else None
+        run = np.empty(self.n_servants, np.uint32) if want_running else None
+        self._check(lib().ydc_dispatch(self._h, C.byref(soa), n, DISPATCH_COMMIT if commit else 0,
+                                       _ptr(out), _ptr(util), _ptr(run)), "ydc_dispatch")
+        return out, util, run
+
+    def dispatch_device(self, d_env, d_minv, d_ip, d_out_idx=None, d_out_util=None,
+                        d_out_running=None, commit=False):
+        """Device buffers (torch tensors): task columns and outputs already in HBM."""
+        soa = TaskSoA(_ptr(d_env), _ptr(d_minv), _ptr(d_ip))
+        n = int(d_env.numel())
+        self._check(lib().ydc_dispatch_device(self._h, C.byref(soa), n,
+                                              DISPATCH_COMMIT if commit else 0, _ptr(d_out_idx),
+                                              _ptr(d_out_util), _ptr(d_out_running)),
+                    "ydc_dispatch_device")
+
+    def synchronize(self):
+        self._check(lib().ydc_synchronize(self._h), "ydc_synchronize")
+
+    def set_profiling(self, on):
+        self._check(lib().ydc_set_profiling(self._h, int(on)), "ydc_set_profiling")
+
+    def kernel_profile(self):
+        """{"kernel": [launches, total_ms]} of the last dispatch (profiling must be on)."""
+        import json
+        return json.loads(lib().ydc_kernel_profile(self._h).decode() or "{}")
+
+    def stats(self):
+        st = Stats()
+        self._check(lib().ydc_get_stats(self._h, C.byref(st)), "ydc_get_stats")
+        return st.as_dict()

@@ -1,0 +1,663 @@
+// kernels.h — HIP kernels of the MI355X task-dispatch path (gfx950, wave64).
+//
+// Pipeline of one batch (all on one stream, sizes that depend on device data
+// are read from DeviceParams, so the host never waits for them):
+//
+//   k_servant_scan   per-servant free-slot counts -> slot_base[], class sizes
+//   k_slot_gen       one (key, generation index) pair per free slot
+//   k_radix_*        stable LSD radix sort of the slots by key  (HBM-bound)
+//   k_radix_* (cls)  stable partition of the sorted ranks by servant class
+//   k_task_classify  per task: eligible-class mask, own-servant slot range
+//   k_chunk_prefix / k_guess_init   speculative start state of every task chunk
+//   k_sim_wave + k_update (rounds)  chunk-parallel replay of the greedy picks
+//   k_finalize       slot -> servant index, utilisation, running_tasks
+//
+// The arithmetic (capacity, keys, class-state machine) lives in dispatch_core.h
+// and is shared with the CPU model in tests/model.
+#ifndef YADCC_AMD_KERNELS_H_
+#define YADCC_AMD_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dispatch_core.h"
+
+namespace ydc {
+
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 slots per workgroup
+constexpr int kSortWaves = kSortThreads / 64;
+
+// Device-resident scalars produced and consumed by the kernels.
+struct DeviceParams {
+  uint32_t n_slots;       // M: free slots of this batch
+  uint32_t overflow;      // M exceeded the workspace
+  uint32_t need_shared;   // some task's host runs several servants
+  uint32_t n_changed[2];  // guesses changed by k_update in rounds of even / odd index
+  uint32_t chunk_sims;    // chunk simulations executed (all rounds)
+  uint32_t granted, timeouts, env_not_found;
+};
+
+struct ServantTable {
+  const uint32_t* version;
+  const uint32_t* nproc;
+  const uint32_t* load;
+  const uint32_t* max_tasks;
+  const uint32_t* running;
+  const uint32_t* flags;
+  const uint32_t* class_of;
+  uint32_t n;
+};
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Minimum over the 64 lanes (every lane gets it). Six v_min_u32_dpp.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = min(v, dpp_u32<0x111>(0xFFFFFFFFu, v));       // row_shr:1
+  v = min(v, dpp_u32<0x112>(0xFFFFFFFFu, v));       // row_shr:2
+  v = min(v, dpp_u32<0x114>(0xFFFFFFFFu, v));       // row_shr:4
+  v = min(v, dpp_u32<0x118>(0xFFFFFFFFu, v));       // row_shr:8
+  v = min(v, dpp_u32<0x142, 0xa>(0xFFFFFFFFu, v));  // row_bcast:15
+  v = min(v, dpp_u32<0x143, 0xc>(0xFFFFFFFFu, v));  // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Inclusive scan over the wave (ds_bpermute based; used off the hot loops).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d);
+    if (lane >= (uint32_t)d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread over a workgroup of `blockDim.x`
+// threads (multiple of 64, <= 1024). Returns the exclusive prefix; *total gets
+// the workgroup sum. `lds` needs 17 words.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds,
+                                                         uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < nw ? lds[lane] : 0;
+    uint32_t winc = wave_inclusive_scan(w);
+    if (lane < nw) lds[lane] = winc - w;
+    if (lane == nw - 1) lds[16] = winc;
+  }
+  __syncthreads();
+  uint32_t r = lds[wave] + inc - v;
+  *total = lds[16];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// k_servant_scan: ONE workgroup. slot_base[s] = number of free slots of the
+// servants before s; cls_begin[c] = number of slots of the classes before c.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
+                                                       uint32_t max_slots, uint32_t* slot_base,
+                                                       uint32_t* cls_begin, DeviceParams* prm) {
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t carry;
+  extern __shared__ uint32_t cls_cnt[];  // n_classes + 1
+  for (uint32_t c = threadIdx.x; c <= n_classes; c += blockDim.x) cls_cnt[c] = 0;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t s0 = 0; s0 < sv.n; s0 += blockDim.x) {
+    uint32_t s = s0 + threadIdx.x;
+    uint32_t k = 0, cls = kNone;
+    if (s < sv.n) {
+      cls = sv.class_of[s];
+      if (cls != kNone)
+        k = servant_slot_count(sv.nproc[s], sv.load[s], sv.max_tasks[s], sv.running[s],
+                               sv.flags[s]);
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(k, lds, &total);
+    uint32_t base = carry + ex;
+    if (s < sv.n) {
+      slot_base[s] = base;
+      if (k) atomicAdd(&cls_cnt[cls], k);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint32_t m = carry;
+    slot_base[sv.n] = m;
+    prm->overflow = m > max_slots ? 1u : 0u;
+    prm->n_slots = m > max_slots ? 0u : m;
+    prm->need_shared = 0;
+    prm->n_changed[0] = prm->n_changed[1] = 0;
+    prm->chunk_sims = 0;
+    prm->granted = prm->timeouts = prm->env_not_found = 0;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < n_classes; ++c) {
+      cls_begin[c] = acc;
+      acc += cls_cnt[c];
+    }
+    cls_begin[n_classes] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_slot_gen: thread per slot, generation order (servant-major, running ascending).
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_t* slot_base,
+                                                  const DeviceParams* prm, uint32_t exact,
+                                                  uint32_t cap_bits, KeyT* keys, uint32_t* vals,
+                                                  uint16_t* cls_by_g) {
+  const uint32_t M = prm->n_slots;
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= M) return;
+  uint32_t s = owner_of_slot(slot_base, sv.n, g);
+  uint32_t r = sv.running[s] + (g - slot_base[s]);
+  uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
+  uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
+  uint32_t tier = slot_tier(nproc, flags, r);
+  uint64_t key = exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap);
+  keys[g] = (KeyT)key;
+  vals[g] = g;
+  if (cls_by_g) cls_by_g[g] = (uint16_t)sv.class_of[s];
+}
+
+// ---------------------------------------------------------------------------
+// Stable LSD radix sort, 8-bit digits, three kernels per pass.
+// Digit of element i: bits [shift, shift+8) of keys[i], or (class pass) of
+// cls_by_g[vals[i]] with the element's key being its index (== global rank).
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+struct SortIn {
+  const KeyT* keys;         // NULL in the class pass: key == index
+  const uint32_t* vals;
+  const uint16_t* cls_by_g; // non-NULL in the class pass
+  uint32_t shift;
+};
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t i, KeyT key,
+                                               uint32_t val) {
+  if (in.cls_by_g) return ((uint32_t)in.cls_by_g[val] >> in.shift) & (kRadix - 1);
+  return (uint32_t)(key >> in.shift) & (kRadix - 1);
+}
+
+// hist[d * n_tiles + tile] = number of elements of the tile with digit d.
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in,
+                                                             const DeviceParams* prm,
+                                                             uint32_t n_tiles, uint32_t* hist) {
+  __shared__ uint32_t h[kRadix];
+  const uint32_t M = prm->n_slots;
+  const uint32_t tile = blockIdx.x;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = tile * kSortTile;
+  if (base < M) {
+#pragma unroll
+    for (int j = 0; j < kSortItems; ++j) {
+      uint32_t i = base + j * kSortThreads + threadIdx.x;
+      if (i < M) {
+        KeyT key = in.keys ? in.keys[i] : (KeyT)i;
+        uint32_t d = sort_digit(in, i, key, in.vals[i]);
+        atomicAdd(&h[d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  hist[threadIdx.x * n_tiles + tile] = h[threadIdx.x];
+}
+
+// One workgroup per digit: exclusive scan of its row of tile counts, row total.
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t n_tiles, uint32_t* hist,
+                                                    uint32_t* row_total) {
+  __shared__ uint32_t lds[17];
+  uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
+  const uint32_t per = (n_tiles + blockDim.x - 1) / blockDim.x;
+  const uint32_t b = threadIdx.x * per;
+  const uint32_t e = min(n_tiles, b + per);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += row[i];
+  uint32_t total;
+  uint32_t acc = block_exclusive_scan(sum, lds, &total);
+  for (uint32_t i = b; i < e; ++i) {
+    uint32_t v = row[i];
+    row[i] = acc;
+    acc += v;
+  }
+  if (threadIdx.x == 0) row_total[blockIdx.x] = total;
+}
+
+// Scatter. Within a tile, wave w owns elements [w*512, (w+1)*512) and walks them
+// 64 at a time, so (tile, wave, round, lane) order == index order and the rank of
+// an element among equal digits is: digit start + earlier tiles (scanned hist) +
+// earlier waves + earlier rounds of this wave + lower lanes with the same digit
+// (wave ballot match) — no atomics, deterministic, stable.
+template <typename KeyT, typename OutKeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
+    SortIn<KeyT> in, const DeviceParams* prm, uint32_t n_tiles, const uint32_t* hist,
+    const uint32_t* row_total, OutKeyT* out_keys, uint32_t* out_vals) {
+  __shared__ uint32_t cnt[kSortWaves][kRadix];
+  __shared__ uint32_t dstart[kRadix];
+  __shared__ uint32_t lds[17];
+  const uint32_t M = prm->n_slots;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t base = tile * kSortTile;
+  if (base >= M) return;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(row_total[threadIdx.x], lds, &total);
+    dstart[threadIdx.x] = ex + hist[threadIdx.x * n_tiles + tile];
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) cnt[w][threadIdx.x] = 0;
+  }
+  __syncthreads();
+  KeyT key[kSortItems];
+  uint32_t val[kSortItems], dig[kSortItems], rank[kSortItems];
+  const uint64_t lt_mask = (1ull << lane) - 1;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
+    const bool valid = i < M;
+    key[j] = 0;
+    val[j] = 0;
+    uint32_t d = 0;
+    if (valid) {
+      key[j] = in.keys ? in.keys[i] : (KeyT)i;
+      val[j] = in.vals[i];
+      d = sort_digit(in, i, key[j], val[j]);
+    }
+    dig[j] = d;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+      const uint64_t m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    uint32_t before = 0;
+    if (valid) before = cnt[wave][d];
+    rank[j] = before + (uint32_t)__popcll(peers & lt_mask);
+    // The lowest lane of each peer group publishes the group's size. All lanes
+    // of this wave have read cnt[wave][d] in the instruction above.
+    if (valid && (peers & lt_mask) == 0) cnt[wave][d] = before + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      uint32_t t = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x] = off;
+      off += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
+    if (i < M) {
+      const uint32_t pos = dstart[dig[j]] + cnt[wave][dig[j]] + rank[j];
+      out_keys[pos] = (OutKeyT)key[j];
+      out_vals[pos] = val[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_task_classify: thread per task.
+// ---------------------------------------------------------------------------
+struct TaskColumns {
+  const uint32_t* env_id;
+  const uint32_t* min_version;
+  const uint32_t* requestor_ip;
+};
+
+__global__ __launch_bounds__(256) void k_task_classify(
+    TaskColumns tk, uint32_t n_tasks, const uint64_t* cls_env, const uint32_t* cls_ver,
+    uint32_t n_classes, uint32_t words, const uint32_t* ip_sorted, const uint32_t* ip_servant,
+    uint32_t n_servants, const uint32_t* slot_base, uint32_t chunk_size, uint64_t* mask,
+    uint32_t* self_lo, uint32_t* self_hi, uint32_t* chunk_consuming, DeviceParams* prm) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  uint64_t any = 0;
+  {
+    uint32_t env = tk.env_id[t], minv = tk.min_version[t];
+    for (uint32_t w = 0; w < words; ++w) {
+      uint64_t m = 0;
+      if (env < 64) {
+        uint32_t c0 = w * 64, c1 = min(c0 + 64, n_classes);
+        for (uint32_t c = c0; c < c1; ++c) {
+          if (((cls_env[c] >> env) & 1u) && cls_ver[c] >= minv) m |= 1ull << (c - c0);
+        }
+      }
+      mask[(size_t)t * words + w] = m;
+      any |= m;
+    }
+  }
+  uint32_t lo = kNone, hi = kNone;
+  uint32_t rip = tk.requestor_ip[t];
+  uint32_t i = lower_bound_u32(ip_sorted, n_servants, rip);
+  if (i < n_servants && ip_sorted[i] == rip) {
+    if (i + 1 < n_servants && ip_sorted[i + 1] == rip) {
+      lo = i;
+      hi = kSelfShared;
+      if (any) prm->need_shared = 1;  // benign race: everybody writes 1
+    } else {
+      uint32_t s = ip_servant[i];
+      uint32_t b = slot_base[s], e = slot_base[s + 1];
+      if (e > b) {
+        lo = b;
+        hi = e;
+      }
+    }
+  }
+  self_lo[t] = lo;
+  self_hi[t] = hi;
+  if (any) atomicAdd(&chunk_consuming[t / chunk_size], 1u);
+}
+
+// ONE workgroup: before[k] = number of consuming tasks in the chunks before k.
+__global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_consuming,
+                                                       uint32_t n_chunks, uint32_t* before) {
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < n_chunks; k0 += blockDim.x) {
+    uint32_t k = k0 + threadIdx.x;
+    uint32_t v = k < n_chunks ? chunk_consuming[k] : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(v, lds, &total);
+    if (k < n_chunks) before[k] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+}
+
+// Thread per (chunk, class): level guess, everything dirty.
+__global__ __launch_bounds__(256) void k_guess_init(ClassLists L, const uint32_t* before,
+                                                    uint32_t n_chunks, ClassState* guess,
+                                                    uint8_t* dirty) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t C = L.n_classes;
+  if (i >= n_chunks * C) return;
+  uint32_t k = i / C, c = i - k * C;
+  guess[i] = level_guess(L, c, before[k]);
+  if (c == 0) dirty[k] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// k_sim_wave: one wave per task chunk, one lane per servant class (W classes per
+// lane when there are more than 64). Replays the chunk's requests in order:
+// every lane offers its class's smallest admissible slot, a 6-instruction DPP
+// min picks the winner, the winning lane advances its class state.
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_sim_wave(ClassLists L, TaskTable T, uint32_t n_tasks,
+                                                  uint32_t chunk_size, uint32_t n_chunks,
+                                                  const ClassState* guess, ClassState* endst,
+                                                  uint8_t* dirty, uint32_t* slot_of,
+                                                  uint32_t round, DeviceParams* prm) {
+  // This round's change counter is zeroed here; k_update (next kernel on the
+  // stream) adds to it.
+  if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
+  if (prm->need_shared) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t k =
+      (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (k >= n_chunks) return;
+  if (!dirty[k]) return;
+  const uint32_t C = L.n_classes;
+  ClassRun r[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    uint32_t c = lane + 64 * j;
+    if (c < C) {
+      class_run_init(L, c, guess[(size_t)k * C + c], r[j]);
+    } else {
+      r[j].cursor = r[j].lo = r[j].end = 0;
+      r[j].hown_lo = r[j].hown_hi = kNone;
+      r[j].head_p = r[j].head_g = kNone;
+    }
+  }
+  const uint32_t t0 = k * chunk_size;
+  const uint32_t t1 = min(n_tasks, t0 + chunk_size);
+  for (uint32_t tb = t0; tb < t1; tb += 64) {
+    // Lane l stages task tb + l; the loop below broadcasts with v_readlane.
+    uint32_t mlo[W], mhi[W], slo = kNone, shi = kNone;
+    const uint32_t tl = tb + lane;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      uint64_t m = tl < t1 ? T.mask[(size_t)tl * W + j] : 0;
+      mlo[j] = (uint32_t)m;
+      mhi[j] = (uint32_t)(m >> 32);
+    }
+    if (tl < t1) {
+      slo = T.self_lo[tl];
+      shi = T.self_hi[tl];
+    }
+    const uint32_t cnt = min(64u, t1 - tb);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t t = tb + i;
+      uint64_t mw[W];
+      uint64_t any = 0;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
+        any |= mw[j];
+      }
+      if (any == 0) {
+        if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+        continue;
+      }
+      const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
+      const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
+      uint32_t bp = kNone, bi = 0, bg = 0;
+      int bj = 0;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if ((mw[j] >> lane) & 1u) {
+          uint32_t ci, cp, cg;
+          if (class_candidate(L, r[j], self_lo, self_hi, ci, cp, cg) && cp < bp) {
+            bp = cp;
+            bi = ci;
+            bg = cg;
+            bj = j;
+          }
+        }
+      }
+      const uint32_t mn = wave_min_u32(bp);
+      uint64_t winners;
+      if (mn != kNone) {
+        winners = __ballot(bp == mn);
+      } else {
+        // Nothing but (maybe) the requestor's own servant is left.
+        bool ok = false;
+        if (self_lo != kNone) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            if (!ok && ((mw[j] >> lane) & 1u)) {
+              uint32_t ci, cg;
+              if (class_self_candidate(L, r[j], self_lo, self_hi, ci, cg)) {
+                ok = true;
+                bi = ci;
+                bg = cg;
+                bj = j;
+              }
+            }
+          }
+        }
+        winners = __ballot(ok);
+        if (winners == 0) {
+          if (lane == 0) slot_of[t] = kIdxTimeout;
+          continue;
+        }
+      }
+      const uint32_t win = (uint32_t)__builtin_ctzll(winners);
+      if (lane == win) {
+        slot_of[t] = bg;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (j == bj) class_consume(L, r[j], bi, self_lo, self_hi);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    uint32_t c = lane + 64 * j;
+    if (c < C) endst[(size_t)k * C + c] = class_run_state(r[j]);
+  }
+  if (lane == 0) {
+    dirty[k] = 0;
+    atomicAdd(&prm->chunk_sims, 1u);
+  }
+}
+
+// Thread per chunk, any number of classes, optional run-time `self` resolution
+// (then n_chunks must be 1). Slow path: hosts that run several servants, or
+// more than kMaxWaveClasses classes.
+__global__ __launch_bounds__(64) void k_sim_generic(ClassLists L, TaskTable T, uint32_t n_tasks,
+                                                    uint32_t chunk_size, uint32_t n_chunks,
+                                                    const ClassState* guess, ClassState* endst,
+                                                    uint8_t* dirty, uint32_t* slot_of,
+                                                    ClassRun* runs, SharedIpTable shared,
+                                                    uint32_t only_if_shared, uint32_t round,
+                                                    DeviceParams* prm) {
+  if (!only_if_shared && blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
+  if (only_if_shared && !prm->need_shared) return;
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_chunks) return;
+  if (!dirty[k]) return;
+  const uint32_t C = L.n_classes;
+  const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
+  sim_chunk(L, T, t0, t1, guess + (size_t)k * C, endst + (size_t)k * C, slot_of,
+            runs + (size_t)k * C, shared.left ? &shared : nullptr);
+  dirty[k] = 0;
+  atomicAdd(&prm->chunk_sims, 1u);
+}
+
+// left[s] = free slots of servant s (for the run-time `self` rule).
+__global__ __launch_bounds__(256) void k_init_left(const uint32_t* slot_base, uint32_t n,
+                                                   uint32_t* left) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) left[s] = slot_base[s + 1] - slot_base[s];
+}
+
+// ---------------------------------------------------------------------------
+// k_update: one workgroup per class. New start guess of chunk k+1 = initial
+// cursor + sum of the cursor advances the chunks 0..k made in their latest
+// simulation (clamped to the class), holes of chunk k's end state carried over
+// when the cursors agree. Chunks whose guess changed are marked dirty. A round
+// in which nothing changes proves guess[k+1] == end[k] for every k, i.e. the
+// chunk results are exactly the sequential ones.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_update(ClassLists L, uint32_t n_chunks,
+                                                 const ClassState* gold, const ClassState* endst,
+                                                 ClassState* gnew, uint8_t* dirty,
+                                                 uint32_t round, DeviceParams* prm) {
+  __shared__ uint32_t lds[17];
+  if (prm->need_shared) return;  // the whole batch went through the sequential path
+  const uint32_t c = blockIdx.x, C = L.n_classes;
+  const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
+  const uint32_t n = n_chunks - 1;  // transitions k -> k+1
+  const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
+  const uint32_t k0 = min(n, threadIdx.x * per), k1 = min(n, k0 + per);
+  uint32_t sum = 0;  // cursor advances are non-negative and bounded by the class size
+  for (uint32_t k = k0; k < k1; ++k)
+    sum += endst[(size_t)k * C + c].cursor - gold[(size_t)k * C + c].cursor;
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(sum, lds, &total);
+  const ClassState first = gold[c];
+  if (threadIdx.x == 0) gnew[c] = first;
+  uint64_t acc = (uint64_t)first.cursor + ex;
+  uint32_t changed = 0;
+  for (uint32_t k = k0; k < k1; ++k) {
+    const ClassState en = endst[(size_t)k * C + c];
+    acc += en.cursor - gold[(size_t)k * C + c].cursor;
+    ClassState ng;
+    ng.cursor = (uint32_t)(acc < b ? b : (acc > e ? e : acc));
+    if (en.lo < en.cursor && ng.cursor == en.cursor) {
+      ng.lo = en.lo;
+      ng.hown_lo = en.hown_lo;
+      ng.hown_hi = en.hown_hi;
+    } else {
+      ng.lo = ng.cursor;
+      ng.hown_lo = ng.hown_hi = kNone;
+    }
+    const ClassState old = gold[(size_t)(k + 1) * C + c];
+    if (!class_state_equal(old, ng)) {
+      dirty[k + 1] = 1;
+      ++changed;
+    }
+    gnew[(size_t)(k + 1) * C + c] = ng;
+  }
+  if (changed) atomicAdd(&prm->n_changed[round & 1], changed);
+}
+
+// ---------------------------------------------------------------------------
+// k_finalize: thread per task.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_t* slot_base,
+                                                  const uint32_t* slot_of, uint32_t n_tasks,
+                                                  uint32_t* out_idx, double* out_util,
+                                                  uint32_t* running_out, DeviceParams* prm) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t kind = 3;  // 0 granted, 1 timeout, 2 env-not-found, 3 inactive lane
+  if (t < n_tasks) {
+    uint32_t g = slot_of[t];
+    if (g >= kIdxEnvNotFound) {
+      kind = g == kIdxTimeout ? 1 : 2;
+      if (out_idx) out_idx[t] = g;
+      if (out_util) out_util[t] = -1.0;
+    } else {
+      kind = 0;
+      uint32_t s = owner_of_slot(slot_base, sv.n, g);
+      if (out_idx) out_idx[t] = s;
+      if (out_util) {
+        uint32_t r = sv.running[s] + (g - slot_base[s]);
+        out_util[t] = slot_utilization(r, slot_capacity(sv.nproc[s], sv.load[s], sv.max_tasks[s], r));
+      }
+      atomicAdd(&running_out[s], 1u);
+    }
+  }
+  uint64_t g0 = __ballot(kind == 0), g1 = __ballot(kind == 1), g2 = __ballot(kind == 2);
+  if ((threadIdx.x & 63) == 0) {
+    if (g0) atomicAdd(&prm->granted, (uint32_t)__popcll(g0));
+    if (g1) atomicAdd(&prm->timeouts, (uint32_t)__popcll(g1));
+    if (g2) atomicAdd(&prm->env_not_found, (uint32_t)__popcll(g2));
+  }
+}
+
+// Registry maintenance.
+__global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_idx, uint32_t n,
+                                                       uint32_t n_servants, uint32_t* running) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && servant_idx[i] < n_servants) atomicSub(&running[servant_idx[i]], 1u);
+}
+
+}  // namespace ydc
+#endif  // YADCC_AMD_KERNELS_H_
