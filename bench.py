@@ -6,7 +6,9 @@ One "step" = one pass of the hot path over one batch: BASELINE.json configs[1]
 resident servant table, request columns and result buffers already in HBM. Each step
 starts from the same snapshot (no COMMIT), so every step does identical work.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): see DESIGN.md §multi-GPU.
+GPU work goes through yadcc_amd/libydc.so only (its own HIP runtime, /opt/rocm). For
+N > 1 (launched by torch.distributed.run, one rank per GPU) torch.distributed is used
+for the rendezvous, the barriers and the max-over-ranks of the wall time.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -26,11 +28,13 @@ def percentile(a, q):
     return float(a[min(len(a) - 1, int(np.ceil(q * len(a))) - 1)]) if len(a) else 0.0
 
 
-def cpu_baseline(sv, tk):
+def cpu_baseline(sv, tk, max_tasks=None):
     """The reference's own TaskDispatcher (oracle/_ref, compiled verbatim) on this host,
     1 thread (everything in the reference runs under one lock), same snapshot."""
-    from oracle import refbind as R
     from oracle import oraclebind as O
+    from oracle import refbind as R
+    if max_tasks and len(tk["env_id"]) > max_tasks:
+        tk = {k: v[:max_tasks] for k, v in tk.items()}
     if R.available():
         d = R.RefDispatcher()
         d.load_servants(sv)
@@ -39,8 +43,8 @@ def cpu_baseline(sv, tk):
         granted = int((idx < R.IDX_ENV_NOT_FOUND).sum())
         return idx, {
             "value": granted / secs, "unit": "assignments/s", "cores": 1, "kind": "reference",
-            "sample": "full batch: %d sequential WaitForStartingNewTask calls, %d servants, %.2f s"
-                      % (len(idx), len(sv["version"]), secs),
+            "sample": "first %d requests of the batch: sequential WaitForStartingNewTask calls, "
+                      "%d servants, %.2f s" % (len(idx), len(sv["version"]), secs),
             "p99_latency_us": percentile(lat, 0.99) / 1e3,
             "host_cores_available": os.cpu_count(),
         }
@@ -49,7 +53,8 @@ def cpu_baseline(sv, tk):
     secs = time.perf_counter() - t0
     granted = int((idx < O.IDX_ENV_NOT_FOUND).sum())
     return idx, {"value": granted / secs, "unit": "assignments/s", "cores": 1, "kind": "port",
-                 "sample": "full batch through oracle_dispatch_scan, %.2f s" % secs,
+                 "sample": "first %d requests through oracle_dispatch_scan, %.2f s" % (
+                     len(idx), secs),
                  "host_cores_available": os.cpu_count()}
 
 
@@ -62,64 +67,61 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    from yadcc_amd import binding, pack, synth
-
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from yadcc_amd import binding, pack, synth
+
+    def barrier():
+        if dist:
+            dist.barrier()
 
     # Weak scaling: every rank owns one snapshot of the named config (own seed).
     sv, tk = synth.make_config(args.config, seed=42 + rank)
     n_tasks, n_serv = len(tk["env_id"]), len(sv["version"])
-    stream = torch.cuda.current_stream()
-    ctx = binding.Context(device=local_rank, stream=stream.cuda_stream)
+    ctx = binding.Context(device=local_rank)
     ctx.upload_servants(pack.to_abi_columns(sv))
-    d_env = torch.from_numpy(tk["env_id"].astype(np.int64)).to(dev).to(torch.int32)
-    d_minv = torch.from_numpy(tk["min_version"].astype(np.int64)).to(dev).to(torch.int32)
-    d_ip = torch.from_numpy(tk["requestor_ip"].astype(np.int64) - (1 << 32) * (
-        tk["requestor_ip"] >= (1 << 31))).to(dev).to(torch.int32)
-    d_out = torch.empty(n_tasks, dtype=torch.int32, device=dev)
-    d_run = torch.empty(n_serv, dtype=torch.int32, device=dev)
+    DA = binding.DeviceArray
+    d_env = DA.from_numpy(tk["env_id"], local_rank)
+    d_minv = DA.from_numpy(tk["min_version"], local_rank)
+    d_ip = DA.from_numpy(tk["requestor_ip"], local_rank)
+    d_out = DA(n_tasks, np.uint32, local_rank)
+    d_run = DA(n_serv, np.uint32, local_rank)
 
     def step():
+        # Returns after the batch's results are final in HBM (stream sync inside).
         ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    ctx.synchronize()
+    barrier()
     lat = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s0 = time.perf_counter()
-        step()  # returns after the batch's results are final in HBM (one stream sync inside)
+        step()
         lat.append(time.perf_counter() - s0)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    ctx.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
-    granted = st["granted"]
+    granted_all = float(st["granted"])
     if dist:
-        t = torch.tensor([elapsed, float(granted)], device=dev, dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, granted_all = float(tmax[0]), float(t[1])
-    else:
-        granted_all = float(granted)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = torch.tensor([granted_all], dtype=torch.float64)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        elapsed, granted_all = float(t[0]), float(g[0])
 
-    # Per-kernel durations, HIP events on the dispatch stream (separate profiled steps so
-    # the events do not perturb the timed region).
+    # Per-kernel durations: HIP events on the dispatch stream, separate profiled steps so
+    # the events do not perturb the timed region.
     ctx.set_profiling(True)
     prof = {}
     n_prof = max(3, min(20, args.steps))
@@ -133,7 +135,7 @@ def main():
     ctx.set_profiling(False)
 
     if rank == 0:
-        host_idx = d_out.cpu().numpy().view(np.uint32)
+        host_idx = d_out.numpy()
         out = {
             "metric": "task-to-servant assignments/sec on synthetic pool",
             "value": granted_all * args.steps / elapsed,
@@ -141,7 +143,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 keys (exact integer image of the reference's fp64 utilisation)",
+            "dtype": "u32" if st["key_bits"] <= 32 else "u64",
             "data": "synthetic",
             "config": {"workload": "%s: %d pending requests x %d servants per GPU, %d classes"
                                    % (args.config, n_tasks, n_serv, st["n_classes"]),
@@ -152,16 +154,13 @@ def main():
             "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
             "stats": {k: v for k, v in st.items() if k != "stage_ms"},
             "stage_ms": stage_ms,
-            "kernels_ms_per_step": {k: v[1] / n_prof for k, v in prof.items()},
+            "kernels_us_per_step": {k: 1e3 * v[1] / n_prof for k, v in prof.items()},
         }
-        # Roofline of the dominant kernel.
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
             launches, total_ms = prof[dom]
-            alg_bytes = 16 * n_tasks + 40 * n_serv  # per batch
+            alg_bytes = 16 * n_tasks + 40 * n_serv  # bytes(batch) = 16 N + 40 S
             avg_launch_s = (total_ms / launches) * 1e-3
-            # one batch needs `launches / n_prof` launches of this kernel; each launch is
-            # charged the whole batch's algorithmic bytes (the kernel processes the batch)
             ach = alg_bytes / avg_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
                                "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
@@ -169,12 +168,13 @@ def main():
                                "avg_launch_us": avg_launch_s * 1e6,
                                "launches_per_step": launches / n_prof}
         if world == 1 and not args.no_cpu_baseline:
-            ref_idx, base = cpu_baseline(sv, tk)
+            ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
             out["cpu_baseline"] = base
-            out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx))
+            out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
         print(json.dumps(out))
     ctx.close()
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -102,8 +102,17 @@ enum {
                                   `++pick->running_tasks` (task_dispatcher.cc:123) */
 
 const char* ydc_strerror(int code);
-const char* ydc_last_error(const ydc_context* ctx);
+const char* ydc_last_error(const ydc_context* ctx); /* ctx == NULL: last error outside a context */
 uint32_t ydc_abi_version(void);
+
+/* Number of usable devices (0 if the HIP runtime cannot see one). */
+int ydc_device_count(void);
+/* Plain device buffers for callers that keep request columns / results in HBM
+ * (bench, streaming): thin wrappers of hipMalloc/hipFree/hipMemcpy. */
+int ydc_device_malloc(int device, size_t bytes, void** out);
+int ydc_device_free(void* p);
+int ydc_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int ydc_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
 
 /* stream: a hipStream_t to launch on, or NULL to create a private one. */
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,

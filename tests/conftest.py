@@ -21,8 +21,10 @@ def _build_test_tools():
 
 
 def has_gpu():
+    """Asked of the product library's own HIP runtime (torch bundles a different
+    libamdhip64; the GPU processes of this repo do not mix the two)."""
     try:
-        import torch
-        return torch.cuda.is_available()
+        from yadcc_amd import binding
+        return binding.device_count() > 0
     except Exception:
         return False

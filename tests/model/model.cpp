@@ -134,8 +134,7 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
         n += !task_mask_empty(ti, t);
       before[k + 1] = before[k] + n;
     }
-    std::vector<ClassState> guess((size_t)K * C), endst((size_t)K * C), init(C);
-    for (uint32_t c = 0; c < C; ++c) init[c] = level_guess(L, c, 0);
+    std::vector<ClassState> guess((size_t)K * C), endst((size_t)K * C);
     for (uint32_t k = 0; k < K; ++k)
       for (uint32_t c = 0; c < C; ++c) guess[(size_t)k * C + c] = level_guess(L, c, before[k]);
     std::vector<uint8_t> dirty(K, 1);
@@ -149,30 +148,15 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
                   need_shared ? &sh : nullptr);
         dirty[k] = 0;
       }
-      // update: cursor guess = init + prefix sum of per-chunk deltas; holes of
-      // the previous chunk's end carried over when consistent.
+      // update (same rule as k_update): the start guess of chunk k+1 becomes the
+      // end state chunk k reached in its latest simulation.
       bool any = false;
-      std::vector<int64_t> acc(C);
-      for (uint32_t c = 0; c < C; ++c) acc[c] = init[c].cursor;
       for (uint32_t k = 0; k + 1 < K; ++k) {
         for (uint32_t c = 0; c < C; ++c) {
-          const ClassState& st = guess[(size_t)k * C + c];
           const ClassState& en = endst[(size_t)k * C + c];
-          acc[c] += (int64_t)en.cursor - (int64_t)st.cursor;
-          int64_t cur = std::min<int64_t>(std::max<int64_t>(acc[c], cls_begin[c]), cls_begin[c + 1]);
-          ClassState ng;
-          ng.cursor = (uint32_t)cur;
-          if (en.lo < en.cursor && ng.cursor == en.cursor) {
-            ng.lo = en.lo;
-            ng.hown_lo = en.hown_lo;
-            ng.hown_hi = en.hown_hi;
-          } else {
-            ng.lo = ng.cursor;
-            ng.hown_lo = ng.hown_hi = kNone;
-          }
           ClassState& g = guess[(size_t)(k + 1) * C + c];
-          if (!class_state_equal(g, ng)) {
-            g = ng;
+          if (!class_state_equal(g, en)) {
+            g = en;
             dirty[k + 1] = 1;
             any = true;
           }

@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
     "ydc_upload_servants", "ydc_update_servants", "ydc_release_slots", "ydc_set_running",
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
-    "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile",
+    "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
+    "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
 )
 
 
@@ -92,6 +93,11 @@ def lib():
         L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.ydc_kernel_profile.argtypes = [C.c_void_p]
         L.ydc_kernel_profile.restype = C.c_char_p
+        L.ydc_device_count.restype = C.c_int
+        L.ydc_device_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ydc_device_free.argtypes = [C.c_void_p]
+        L.ydc_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ydc_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -101,7 +107,60 @@ def _ptr(a):
         return None
     if isinstance(a, np.ndarray):
         return a.ctypes.data
-    return a.data_ptr()  # torch tensor
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if isinstance(a, int):
+        return a
+    return a.data_ptr()  # anything torch-like
+
+
+def device_count():
+    """GPUs visible to the library's HIP runtime (0 when the library is missing)."""
+    try:
+        return int(lib().ydc_device_count())
+    except (YdcError, OSError):
+        return 0
+
+
+class DeviceArray:
+    """A typed buffer in HBM owned by the caller (hipMalloc through the C-ABI)."""
+
+    def __init__(self, n, dtype, device=0):
+        self.n, self.dtype, self.device = int(n), np.dtype(dtype), device
+        p = C.c_void_p()
+        rc = lib().ydc_device_malloc(device, self.n * self.dtype.itemsize, C.byref(p))
+        if rc:
+            raise YdcError("ydc_device_malloc: %s (%s)" % (
+                lib().ydc_strerror(rc).decode(), lib().ydc_last_error(None).decode()))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a, device=0):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype, device)
+        if a.size and lib().ydc_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes):
+            raise YdcError("ydc_memcpy_h2d failed")
+        return d
+
+    def numpy(self):
+        out = np.empty(self.n, self.dtype)
+        if self.n and lib().ydc_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes):
+            raise YdcError("ydc_memcpy_d2h failed")
+        return out
+
+    def numel(self):
+        return self.n
+
+    def free(self):
+        if self.ptr:
+            lib().ydc_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -111,7 +170,8 @@ class Context:
         h = C.c_void_p()
         rc = lib().ydc_create(device, max_servants, max_tasks, max_slots, stream, C.byref(h))
         if rc:
-            raise YdcError("ydc_create: %s" % lib().ydc_strerror(rc).decode())
+            raise YdcError("ydc_create: %s (%s)" % (lib().ydc_strerror(rc).decode(),
+                                                    lib().ydc_last_error(None).decode()))
         self._h = h
         self.n_servants = 0
 

@@ -283,9 +283,10 @@ YDC_HD bool class_self_candidate(const ClassLists& L, const ClassRun& r, uint32_
 }
 
 // Marks entry `ci` (obtained from one of the two functions above for the same
-// self range) as consumed.
-YDC_HD void class_consume(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_t self_lo,
-                          uint32_t self_hi) {
+// self range) as consumed. Returns true when the cursor moved, in which case the
+// caller must reload the head (class_load_head, or its own cached copy).
+YDC_HD bool class_consume_state(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_t self_lo,
+                                uint32_t self_hi) {
   if (ci < r.cursor) {
     // Took the smallest hole: the next hole is the next slot of the same
     // servant below the cursor.
@@ -296,7 +297,7 @@ YDC_HD void class_consume(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_
       ++j;
     }
     r.lo = j;  // == cursor: no holes left
-    return;
+    return false;
   }
   if (r.lo == r.cursor) {
     if (ci > r.cursor) {
@@ -308,7 +309,12 @@ YDC_HD void class_consume(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_
     }
   }
   r.cursor = ci + 1;
-  class_load_head(L, r);
+  return true;
+}
+
+YDC_HD void class_consume(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_t self_lo,
+                          uint32_t self_hi) {
+  if (class_consume_state(L, r, ci, self_lo, self_hi)) class_load_head(L, r);
 }
 
 // Resolves `self` for a task whose host runs several servants.

@@ -374,7 +374,11 @@ __global__ __launch_bounds__(256) void k_task_classify(
   }
   self_lo[t] = lo;
   self_hi[t] = hi;
-  if (any) atomicAdd(&chunk_consuming[t / chunk_size], 1u);
+  // chunk_size is a multiple of 64 and waves start at multiples of 64, so all
+  // lanes of a wave fall into the same chunk: one atomic per wave.
+  const uint64_t consuming = __ballot(any != 0);
+  if (consuming && (threadIdx.x & 63) == __builtin_ctzll(__ballot(true)))
+    atomicAdd(&chunk_consuming[t / chunk_size], (uint32_t)__popcll(consuming));
 }
 
 // ONE workgroup: before[k] = number of consuming tasks in the chunks before k.
@@ -409,48 +413,101 @@ __global__ __launch_bounds__(256) void k_guess_init(ClassLists L, const uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// k_sim_wave: one wave per task chunk, one lane per servant class (W classes per
-// lane when there are more than 64). Replays the chunk's requests in order:
-// every lane offers its class's smallest admissible slot, a 6-instruction DPP
-// min picks the winner, the winning lane advances its class state.
+// k_sim_wave: one wave (= one workgroup) per task chunk, one lane per servant
+// class (W classes per lane when there are more than 64). Replays the chunk's
+// requests in order: every lane offers its class's smallest admissible slot, a
+// 6-instruction DPP min picks the winner, the winning lane advances its class.
+//
+// A request's pick depends on the previous one, so the loop is latency-bound:
+// the class lists are therefore staged through LDS. Every class owns a ring of
+// R list entries (rank, generation index) ahead of its cursor; the winner reads
+// its next head from the ring (LDS latency instead of HBM/L2 latency), and when
+// a ring runs low all 64 lanes refill it with one coalesced load.
 // ---------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(256) void k_sim_wave(ClassLists L, TaskTable T, uint32_t n_tasks,
-                                                  uint32_t chunk_size, uint32_t n_chunks,
-                                                  const ClassState* guess, ClassState* endst,
-                                                  uint8_t* dirty, uint32_t* slot_of,
-                                                  uint32_t round, DeviceParams* prm) {
+template <int W, int R>
+struct SimRing {
+  static constexpr int CP = 64 * W;  // classes, padded
+  uint32_t* p;                       // [R][CP] global rank
+  uint32_t* g;                       // [R][CP] generation index
+  __device__ __forceinline__ uint32_t at(uint32_t i, uint32_t cl) const {
+    return (i & (R - 1)) * CP + cl;
+  }
+};
+
+template <int W, int R>
+__global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint32_t n_tasks,
+                                                 uint32_t chunk_size, uint32_t n_chunks,
+                                                 const ClassState* guess, ClassState* endst,
+                                                 uint8_t* dirty, uint32_t* slot_of,
+                                                 uint32_t round, DeviceParams* prm) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
   // This round's change counter is zeroed here; k_update (next kernel on the
   // stream) adds to it.
   if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
   if (prm->need_shared) return;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t k =
-      (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const uint32_t lane = threadIdx.x;
+  const uint32_t k = blockIdx.x;
   if (k >= n_chunks) return;
   if (!dirty[k]) return;
   const uint32_t C = L.n_classes;
+  SimRing<W, R> ring{lds_ring, lds_ring + R * 64 * W};
   ClassRun r[W];
+  uint32_t filled[W];  // ring of class j holds list entries [cursor, filled)
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    uint32_t c = lane + 64 * j;
+    const uint32_t c = lane + 64 * j;
     if (c < C) {
-      class_run_init(L, c, guess[(size_t)k * C + c], r[j]);
+      const ClassState st = guess[(size_t)k * C + c];
+      const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
+      uint32_t cur = st.cursor, lo = st.lo;
+      cur = cur < b ? b : (cur > e ? e : cur);
+      lo = lo < b ? b : (lo > cur ? cur : lo);
+      r[j].cursor = cur;
+      r[j].lo = lo;
+      r[j].hown_lo = st.hown_lo;
+      r[j].hown_hi = st.hown_hi;
+      r[j].end = e;
     } else {
       r[j].cursor = r[j].lo = r[j].end = 0;
       r[j].hown_lo = r[j].hown_hi = kNone;
+    }
+    // Initial fill, every lane its own ring: 16 independent loads in flight per lane.
+    const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
+    for (uint32_t base = r[j].cursor; base < hi; base += 16) {
+      uint32_t tp[16], tg[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const uint32_t i = base + u;
+        tp[u] = i < hi ? list_rank(L, i) : 0;
+        tg[u] = i < hi ? L.list_g[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const uint32_t i = base + u;
+        if (i < hi) {
+          ring.p[ring.at(i, c)] = tp[u];
+          ring.g[ring.at(i, c)] = tg[u];
+        }
+      }
+    }
+    filled[j] = hi;
+    if (r[j].cursor < r[j].end) {
+      r[j].head_p = ring.p[ring.at(r[j].cursor, c)];
+      r[j].head_g = ring.g[ring.at(r[j].cursor, c)];
+    } else {
       r[j].head_p = r[j].head_g = kNone;
     }
   }
   const uint32_t t0 = k * chunk_size;
   const uint32_t t1 = min(n_tasks, t0 + chunk_size);
   for (uint32_t tb = t0; tb < t1; tb += 64) {
-    // Lane l stages task tb + l; the loop below broadcasts with v_readlane.
+    // Lane l stages task tb + l; the loop below broadcasts with v_readlane and
+    // collects the 64 results in `res` (one coalesced store per 64 requests).
     uint32_t mlo[W], mhi[W], slo = kNone, shi = kNone;
     const uint32_t tl = tb + lane;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      uint64_t m = tl < t1 ? T.mask[(size_t)tl * W + j] : 0;
+      uint64_t m = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
       mlo[j] = (uint32_t)m;
       mhi[j] = (uint32_t)(m >> 32);
     }
@@ -458,9 +515,9 @@ __global__ __launch_bounds__(256) void k_sim_wave(ClassLists L, TaskTable T, uin
       slo = T.self_lo[tl];
       shi = T.self_hi[tl];
     }
+    uint32_t res = kIdxTimeout;
     const uint32_t cnt = min(64u, t1 - tb);
     for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t t = tb + i;
       uint64_t mw[W];
       uint64_t any = 0;
 #pragma unroll
@@ -470,7 +527,7 @@ __global__ __launch_bounds__(256) void k_sim_wave(ClassLists L, TaskTable T, uin
         any |= mw[j];
       }
       if (any == 0) {
-        if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+        res = lane == i ? kIdxEnvNotFound : res;
         continue;
       }
       const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
@@ -512,19 +569,66 @@ __global__ __launch_bounds__(256) void k_sim_wave(ClassLists L, TaskTable T, uin
         }
         winners = __ballot(ok);
         if (winners == 0) {
-          if (lane == 0) slot_of[t] = kIdxTimeout;
+          res = lane == i ? kIdxTimeout : res;
           continue;
         }
       }
       const uint32_t win = (uint32_t)__builtin_ctzll(winners);
+      {
+        const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)bg, (int)win);
+        res = lane == i ? taken : res;
+      }
+      // The winner advances its class; if the cursor moved it needs a new head,
+      // and possibly a ring refill first.
+      bool refill = false;
+      uint32_t f_from = 0, f_to = 0, f_cl = 0;
       if (lane == win) {
-        slot_of[t] = bg;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          if (j == bj) class_consume(L, r[j], bi, self_lo, self_hi);
+          if (j == bj) {
+            if (class_consume_state(L, r[j], bi, self_lo, self_hi)) {
+              if (filled[j] < r[j].cursor) filled[j] = r[j].cursor;  // jumped past the ring
+              if (r[j].cursor < r[j].end) {
+                const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
+                if (filled[j] - r[j].cursor <= (uint32_t)(R / 4) && filled[j] < hi) {
+                  refill = true;
+                  f_from = filled[j];
+                  f_to = hi;
+                  f_cl = lane + 64 * j;
+                  filled[j] = hi;
+                }
+              } else {
+                r[j].head_p = r[j].head_g = kNone;
+              }
+            }
+          }
+        }
+      }
+      if (__ballot(refill)) {
+        // Wave-uniform: all lanes fetch the winner's next entries, coalesced.
+        const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)f_from, (int)win);
+        const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)f_to, (int)win);
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)f_cl, (int)win);
+        for (uint32_t e0 = from; e0 < to; e0 += 64) {
+          const uint32_t e = e0 + lane;
+          if (e < to) {
+            ring.p[ring.at(e, cl)] = list_rank(L, e);
+            ring.g[ring.at(e, cl)] = L.list_g[e];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == win) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (j == bj && r[j].cursor < r[j].end) {
+            r[j].head_p = ring.p[ring.at(r[j].cursor, lane + 64 * j)];
+            r[j].head_g = ring.g[ring.at(r[j].cursor, lane + 64 * j)];
+          }
         }
       }
     }
+    if (tl < t1) slot_of[tl] = res;
   }
 #pragma unroll
   for (int j = 0; j < W; ++j) {
@@ -568,54 +672,33 @@ __global__ __launch_bounds__(256) void k_init_left(const uint32_t* slot_base, ui
 }
 
 // ---------------------------------------------------------------------------
-// k_update: one workgroup per class. New start guess of chunk k+1 = initial
-// cursor + sum of the cursor advances the chunks 0..k made in their latest
-// simulation (clamped to the class), holes of chunk k's end state carried over
-// when the cursors agree. Chunks whose guess changed are marked dirty. A round
-// in which nothing changes proves guess[k+1] == end[k] for every k, i.e. the
-// chunk results are exactly the sequential ones.
+// k_update: thread per (chunk, class). The start guess of chunk k+1 becomes the
+// end state chunk k reached in its latest simulation; chunks whose guess changed
+// are marked dirty. Two replays of a chunk from different start states fall
+// into step after a few dozen requests (every request takes the smallest
+// admissible slot, which pulls lagging classes level), so end states are right
+// long before start states are and a few rounds suffice. A round in which no
+// guess changes proves guess[k+1] == end[k] for every k, i.e. the chunk results
+// are exactly the sequential ones (chunk 0 always starts from the true state).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_update(ClassLists L, uint32_t n_chunks,
-                                                 const ClassState* gold, const ClassState* endst,
-                                                 ClassState* gnew, uint8_t* dirty,
-                                                 uint32_t round, DeviceParams* prm) {
-  __shared__ uint32_t lds[17];
+__global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_chunks,
+                                                const ClassState* endst, ClassState* guess,
+                                                uint8_t* dirty, uint32_t round,
+                                                DeviceParams* prm) {
   if (prm->need_shared) return;  // the whole batch went through the sequential path
-  const uint32_t c = blockIdx.x, C = L.n_classes;
-  const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
-  const uint32_t n = n_chunks - 1;  // transitions k -> k+1
-  const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
-  const uint32_t k0 = min(n, threadIdx.x * per), k1 = min(n, k0 + per);
-  uint32_t sum = 0;  // cursor advances are non-negative and bounded by the class size
-  for (uint32_t k = k0; k < k1; ++k)
-    sum += endst[(size_t)k * C + c].cursor - gold[(size_t)k * C + c].cursor;
-  uint32_t total;
-  uint32_t ex = block_exclusive_scan(sum, lds, &total);
-  const ClassState first = gold[c];
-  if (threadIdx.x == 0) gnew[c] = first;
-  uint64_t acc = (uint64_t)first.cursor + ex;
-  uint32_t changed = 0;
-  for (uint32_t k = k0; k < k1; ++k) {
-    const ClassState en = endst[(size_t)k * C + c];
-    acc += en.cursor - gold[(size_t)k * C + c].cursor;
-    ClassState ng;
-    ng.cursor = (uint32_t)(acc < b ? b : (acc > e ? e : acc));
-    if (en.lo < en.cursor && ng.cursor == en.cursor) {
-      ng.lo = en.lo;
-      ng.hown_lo = en.hown_lo;
-      ng.hown_hi = en.hown_hi;
-    } else {
-      ng.lo = ng.cursor;
-      ng.hown_lo = ng.hown_hi = kNone;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool changed = false;
+  if (n_chunks && i < (n_chunks - 1) * n_classes) {
+    const ClassState en = endst[i];  // (k, c) -> guess of (k + 1, c)
+    ClassState* g = guess + i + n_classes;
+    if (!class_state_equal(*g, en)) {
+      *g = en;
+      dirty[i / n_classes + 1] = 1;
+      changed = true;
     }
-    const ClassState old = gold[(size_t)(k + 1) * C + c];
-    if (!class_state_equal(old, ng)) {
-      dirty[k + 1] = 1;
-      ++changed;
-    }
-    gnew[(size_t)(k + 1) * C + c] = ng;
   }
-  if (changed) atomicAdd(&prm->n_changed[round & 1], changed);
+  const uint64_t b = __ballot(changed);
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(&prm->n_changed[round & 1], (uint32_t)__popcll(b));
 }
 
 // ---------------------------------------------------------------------------

@@ -99,6 +99,8 @@ struct ydc_context {
 
 namespace {
 
+std::string g_create_error;  // errors raised before a context exists
+
 int fail(ydc_context* ctx, int code, const char* fmt, ...) {
   if (ctx) {
     char buf[512];
@@ -233,7 +235,41 @@ const char* ydc_strerror(int code) {
   }
 }
 
-const char* ydc_last_error(const ydc_context* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* ydc_last_error(const ydc_context* ctx) {
+  return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+int ydc_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return 0;
+  }
+  return n;
+}
+
+int ydc_device_malloc(int device, size_t bytes, void** out) {
+  if (!out) return YDC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (hipSetDevice(device) != hipSuccess) return YDC_ERR_NO_DEVICE;
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return YDC_ERR_HIP;
+  }
+  return YDC_OK;
+}
+
+int ydc_device_free(void* p) { return hipFree(p) == hipSuccess ? YDC_OK : YDC_ERR_HIP; }
+
+int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
+}
+
+int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
+}
 uint32_t ydc_abi_version(void) { return 1; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
@@ -241,8 +277,12 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (!out) return YDC_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev)
+  hipError_t de = hipGetDeviceCount(&n_dev);
+  if (de != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(de) + ", " +
+                     std::to_string(n_dev) + " device(s), asked for " + std::to_string(device);
     return YDC_ERR_NO_DEVICE;
+  }
   if (hipSetDevice(device) != hipSuccess) return YDC_ERR_NO_DEVICE;
   auto* c = new ydc_context();
   c->device = device;
@@ -479,7 +519,6 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   HIP_TRY(c, c->d_before.reserve((size_t)K + 1));
   HIP_TRY(c, c->d_dirty.reserve((size_t)K + 1));
   HIP_TRY(c, c->d_guess[0].reserve((size_t)K * C + 1));
-  HIP_TRY(c, c->d_guess[1].reserve((size_t)K * C + 1));
   HIP_TRY(c, c->d_endst.reserve((size_t)K * C + 1));
   if (use_generic) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
   else if (any_shared) HIP_TRY(c, c->d_runs.reserve((size_t)C + 1));
@@ -566,7 +605,6 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   mark(c, 5);
   // ---- matching
   uint32_t rounds = 0;
-  int gcur = 0;
   SharedIpTable no_shared{};
   if (N && C == 0) {
     // No eligible servant at all: every request fails with EnvironmentNotFound
@@ -587,25 +625,23 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
     }
     for (;;) {
       for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
-        const ClassState* gold = c->d_guess[gcur].p;
-        ClassState* gnew = c->d_guess[gcur ^ 1].p;
+        ClassState* gold = c->d_guess[0].p;
         if (use_generic) {
           YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(K, 64)), dim3(64), 0, st, L, T, N, cs, K,
                              gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
                              no_shared, 0u, rounds, prm);
         } else if (W == 1) {
-          YDC_LAUNCH(c, "k_sim_wave", k_sim_wave<1>, dim3(ceil_div(K, 4)), dim3(256), 0, st, L, T, N, cs, K,
-                             gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<1, 64>), dim3(K), dim3(64), 64 * 1 * 64 * 8, st, L,
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
         } else if (W == 2) {
-          YDC_LAUNCH(c, "k_sim_wave", k_sim_wave<2>, dim3(ceil_div(K, 4)), dim3(256), 0, st, L, T, N, cs, K,
-                             gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<2, 32>), dim3(K), dim3(64), 32 * 2 * 64 * 8, st, L,
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
         } else {
-          YDC_LAUNCH(c, "k_sim_wave", k_sim_wave<4>, dim3(ceil_div(K, 4)), dim3(256), 0, st, L, T, N, cs, K,
-                             gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<4, 16>), dim3(K), dim3(64), 16 * 4 * 64 * 8, st, L,
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
         }
-        YDC_LAUNCH(c, "k_update", k_update, dim3(C), dim3(1024), 0, st, L, K, gold, c->d_endst.p, gnew,
-                           c->d_dirty.p, rounds, prm);
-        gcur ^= 1;
+        YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(K * C, 256))), dim3(256), 0,
+                   st, C, K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
         ++rounds;
       }
       HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
