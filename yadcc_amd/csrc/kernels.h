@@ -439,8 +439,10 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
                                                  uint32_t chunk_size, uint32_t n_chunks,
                                                  const ClassState* guess, ClassState* endst,
                                                  uint8_t* dirty, uint32_t* slot_of,
-                                                 uint32_t round, DeviceParams* prm) {
+                                                 uint32_t round, DeviceParams* prm,
+                                                 uint64_t* dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
+  const uint64_t dbg_t0 = dbg ? wall_clock64() : 0;
   // This round's change counter is zeroed here; k_update (next kernel on the
   // stream) adds to it.
   if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
       r[j].head_p = r[j].head_g = kNone;
     }
   }
+  const uint64_t dbg_t1 = dbg ? wall_clock64() : 0;
   const uint32_t t0 = k * chunk_size;
   const uint32_t t1 = min(n_tasks, t0 + chunk_size);
   for (uint32_t tb = t0; tb < t1; tb += 64) {
@@ -517,80 +520,63 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
     }
     uint32_t res = kIdxTimeout;
     const uint32_t cnt = min(64u, t1 - tb);
-    for (uint32_t i = 0; i < cnt; ++i) {
-      uint64_t mw[W];
-      uint64_t any = 0;
+    uint32_t i = 0;
+    while (i < cnt) {
+      // ================= fast loop =================
+      // Stays here while, for every request, no eligible class has holes or
+      // shows a slot of the requestor's own servant at its head, some slot is
+      // left, and the winner's ring is not running low. ~60 instructions per
+      // request; anything else drops to the general step below.
+      bool refill = false;
+      uint32_t f_from = 0, f_to = 0, f_cl = 0, f_win = 0;
+      for (; i < cnt; ++i) {
+        uint64_t any = 0;
+        uint64_t mw[W];
 #pragma unroll
-      for (int j = 0; j < W; ++j) {
-        mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
-        any |= mw[j];
-      }
-      if (any == 0) {
-        res = lane == i ? kIdxEnvNotFound : res;
-        continue;
-      }
-      const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
-      const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
-      uint32_t bp = kNone, bi = 0, bg = 0;
-      int bj = 0;
+        for (int j = 0; j < W; ++j) {
+          mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
+                  (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
+          any |= mw[j];
+        }
+        if (any == 0) {
+          res = lane == i ? kIdxEnvNotFound : res;
+          continue;
+        }
+        const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
+        const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
+        uint32_t bp = kNone, bg = 0;
+        int bj = 0;
+        bool odd = false;
 #pragma unroll
-      for (int j = 0; j < W; ++j) {
-        if ((mw[j] >> lane) & 1u) {
-          uint32_t ci, cp, cg;
-          if (class_candidate(L, r[j], self_lo, self_hi, ci, cp, cg) && cp < bp) {
-            bp = cp;
-            bi = ci;
-            bg = cg;
+        for (int j = 0; j < W; ++j) {
+          const bool compat = (mw[j] >> lane) & 1u;
+          const bool plain = r[j].lo == r[j].cursor &&
+                             !(r[j].head_g >= self_lo && r[j].head_g < self_hi);
+          odd |= compat && !plain;
+          if (compat && plain && r[j].head_p < bp) {
+            bp = r[j].head_p;
+            bg = r[j].head_g;
             bj = j;
           }
         }
-      }
-      const uint32_t mn = wave_min_u32(bp);
-      uint64_t winners;
-      if (mn != kNone) {
-        winners = __ballot(bp == mn);
-      } else {
-        // Nothing but (maybe) the requestor's own servant is left.
-        bool ok = false;
-        if (self_lo != kNone) {
-#pragma unroll
-          for (int j = 0; j < W; ++j) {
-            if (!ok && ((mw[j] >> lane) & 1u)) {
-              uint32_t ci, cg;
-              if (class_self_candidate(L, r[j], self_lo, self_hi, ci, cg)) {
-                ok = true;
-                bi = ci;
-                bg = cg;
-                bj = j;
-              }
-            }
-          }
-        }
-        winners = __ballot(ok);
-        if (winners == 0) {
-          res = lane == i ? kIdxTimeout : res;
-          continue;
-        }
-      }
-      const uint32_t win = (uint32_t)__builtin_ctzll(winners);
-      {
+        if (__ballot(odd)) break;
+        const uint32_t mn = wave_min_u32(bp);
+        if (mn == kNone) break;
+        const uint32_t win = (uint32_t)__builtin_ctzll(__ballot(bp == mn));
         const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)bg, (int)win);
         res = lane == i ? taken : res;
-      }
-      // The winner advances its class; if the cursor moved it needs a new head,
-      // and possibly a ring refill first.
-      bool refill = false;
-      uint32_t f_from = 0, f_to = 0, f_cl = 0;
-      if (lane == win) {
+        if (lane == win) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          if (j == bj) {
-            if (class_consume_state(L, r[j], bi, self_lo, self_hi)) {
-              if (filled[j] < r[j].cursor) filled[j] = r[j].cursor;  // jumped past the ring
-              if (r[j].cursor < r[j].end) {
-                const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
-                if (filled[j] - r[j].cursor <= (uint32_t)(R / 4) && filled[j] < hi) {
+          for (int j = 0; j < W; ++j) {
+            if (j == bj) {
+              const uint32_t cur = r[j].cursor + 1;
+              r[j].cursor = cur;
+              r[j].lo = cur;
+              if (cur < r[j].end) {
+                r[j].head_p = ring.p[ring.at(cur, lane + 64 * j)];
+                r[j].head_g = ring.g[ring.at(cur, lane + 64 * j)];
+                const uint32_t hi = min(r[j].end, cur + (uint32_t)R);
+                if (filled[j] - cur <= (uint32_t)(R / 4) && filled[j] < hi) {
                   refill = true;
                   f_from = filled[j];
                   f_to = hi;
@@ -603,12 +589,17 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
             }
           }
         }
+        if (__ballot(refill)) {
+          f_win = win;
+          ++i;
+          break;
+        }
       }
       if (__ballot(refill)) {
         // Wave-uniform: all lanes fetch the winner's next entries, coalesced.
-        const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)f_from, (int)win);
-        const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)f_to, (int)win);
-        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)f_cl, (int)win);
+        const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)f_from, (int)f_win);
+        const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)f_to, (int)f_win);
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)f_cl, (int)f_win);
         for (uint32_t e0 = from; e0 < to; e0 += 64) {
           const uint32_t e = e0 + lane;
           if (e < to) {
@@ -617,15 +608,90 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
           }
         }
         __builtin_amdgcn_wave_barrier();
+        continue;
       }
-      if (lane == win) {
+      if (i >= cnt) break;
+      // ================= general step (request i) =================
+      // Holes, own-servant heads, exhausted pool. Class state is advanced with
+      // the shared state machine; the ring is rebuilt for the class that moved.
+      {
+        uint64_t mw[W];
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          if (j == bj && r[j].cursor < r[j].end) {
-            r[j].head_p = ring.p[ring.at(r[j].cursor, lane + 64 * j)];
-            r[j].head_g = ring.g[ring.at(r[j].cursor, lane + 64 * j)];
+          mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
+                  (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
+        }
+        const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
+        const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
+        uint32_t bp = kNone, bi = 0, bg = 0;
+        int bj = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if ((mw[j] >> lane) & 1u) {
+            uint32_t ci, cp, cg;
+            if (class_candidate(L, r[j], self_lo, self_hi, ci, cp, cg) && cp < bp) {
+              bp = cp;
+              bi = ci;
+              bg = cg;
+              bj = j;
+            }
           }
         }
+        const uint32_t mn = wave_min_u32(bp);
+        uint64_t winners;
+        if (mn != kNone) {
+          winners = __ballot(bp == mn);
+        } else {
+          // Nothing but (maybe) the requestor's own servant is left.
+          bool ok = false;
+          if (self_lo != kNone) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (!ok && ((mw[j] >> lane) & 1u)) {
+                uint32_t ci, cg;
+                if (class_self_candidate(L, r[j], self_lo, self_hi, ci, cg)) {
+                  ok = true;
+                  bi = ci;
+                  bg = cg;
+                  bj = j;
+                }
+              }
+            }
+          }
+          winners = __ballot(ok);
+        }
+        if (winners == 0) {
+          res = lane == i ? kIdxTimeout : res;
+        } else {
+          const uint32_t win = (uint32_t)__builtin_ctzll(winners);
+          const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)bg, (int)win);
+          res = lane == i ? taken : res;
+          if (lane == win) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (j == bj && class_consume_state(L, r[j], bi, self_lo, self_hi)) {
+                // Cursor moved (possibly far): restart this class's ring at it.
+                const uint32_t cl = lane + 64 * j;
+                const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
+                for (uint32_t e = max(r[j].cursor, min(filled[j], hi)); e < hi; ++e) {
+                  ring.p[ring.at(e, cl)] = list_rank(L, e);
+                  ring.g[ring.at(e, cl)] = L.list_g[e];
+                }
+                if (filled[j] < r[j].cursor) {
+                  // jumped past the old window: everything in [cursor, hi) was reloaded above
+                }
+                filled[j] = max(filled[j], hi);
+                if (r[j].cursor < r[j].end) {
+                  r[j].head_p = ring.p[ring.at(r[j].cursor, cl)];
+                  r[j].head_g = ring.g[ring.at(r[j].cursor, cl)];
+                } else {
+                  r[j].head_p = r[j].head_g = kNone;
+                }
+              }
+            }
+          }
+        }
+        ++i;
       }
     }
     if (tl < t1) slot_of[tl] = res;
@@ -638,6 +704,11 @@ __global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint
   if (lane == 0) {
     dirty[k] = 0;
     atomicAdd(&prm->chunk_sims, 1u);
+    if (dbg) {  // 100 MHz ticks: [launch-relative start, init, loop]
+      dbg[3 * k + 0] = dbg_t0;
+      dbg[3 * k + 1] = dbg_t1 - dbg_t0;
+      dbg[3 * k + 2] = wall_clock64() - dbg_t1;
+    }
   }
 }
 

@@ -73,6 +73,8 @@ struct ydc_context {
   DevBuf<ClassState> d_guess[2], d_endst;
   DevBuf<ClassRun> d_runs;
   DevBuf<uint8_t> d_dirty;
+  DevBuf<uint64_t> d_dbg;
+  bool debug_sim = false;
   DevBuf<DeviceParams> d_prm;
   DeviceParams* h_prm = nullptr;  // pinned
 
@@ -81,7 +83,7 @@ struct ydc_context {
   DevBuf<double> d_out_util;
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
-  uint32_t opt_target_chunks = 1024;
+  uint32_t opt_target_chunks = 2048;
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -310,6 +312,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
       return YDC_ERR_HIP;
     }
   }
+  if (const char* s = getenv("YDC_DEBUG_SIM")) c->debug_sim = atoi(s) != 0;
   if (const char* s = getenv("YDC_CHUNK_SIZE")) c->opt_chunk_size = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_TARGET_CHUNKS")) c->opt_target_chunks = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
@@ -336,6 +339,7 @@ int ydc_destroy(ydc_context* c) {
   c->d_endst.release();
   c->d_runs.release();
   c->d_dirty.release();
+  c->d_dbg.release();
   c->d_prm.release();
   c->d_out_util.release();
   if (c->h_prm) (void)hipHostFree(c->h_prm);
@@ -623,6 +627,12 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
                          c->d_guess[0].p, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p,
                          c->d_runs.p, sh, 1u, 0u, prm);
     }
+    uint64_t* dbg = nullptr;
+    if (c->debug_sim) {
+      HIP_TRY(c, c->d_dbg.reserve((size_t)3 * K + 3));
+      HIP_TRY(c, hipMemsetAsync(c->d_dbg.p, 0, ((size_t)3 * K + 3) * 8, st));
+      dbg = c->d_dbg.p;
+    }
     for (;;) {
       for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
         ClassState* gold = c->d_guess[0].p;
@@ -632,13 +642,13 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
                              no_shared, 0u, rounds, prm);
         } else if (W == 1) {
           YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<1, 64>), dim3(K), dim3(64), 64 * 1 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
         } else if (W == 2) {
           YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<2, 32>), dim3(K), dim3(64), 32 * 2 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
         } else {
           YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<4, 16>), dim3(K), dim3(64), 16 * 4 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm);
+                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
         }
         YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(K * C, 256))), dim3(256), 0,
                    st, C, K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
@@ -651,6 +661,29 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
       if (c->h_prm->n_changed[(rounds - 1) & 1] == 0) break;
       if (rounds > K + 4) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", rounds);
     }
+  }
+  if (c->debug_sim && K && N && C) {
+    // Developer aid (YDC_DEBUG_SIM=1): per-chunk timing of the LAST simulation of each chunk.
+    std::vector<uint64_t> h((size_t)3 * K);
+    HIP_TRY(c, hipMemcpy(h.data(), c->d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t t_min = ~0ull, t_max = 0, init_sum = 0, init_max = 0, loop_sum = 0, loop_max = 0;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+      if (!h[3 * k]) continue;
+      ++n;
+      t_min = std::min(t_min, h[3 * k]);
+      t_max = std::max(t_max, h[3 * k] + h[3 * k + 1] + h[3 * k + 2]);
+      init_sum += h[3 * k + 1];
+      init_max = std::max(init_max, h[3 * k + 1]);
+      loop_sum += h[3 * k + 2];
+      loop_max = std::max(loop_max, h[3 * k + 2]);
+    }
+    if (n)
+      fprintf(stderr,
+              "[ydc sim] chunks=%u cs=%u rounds=%u: span %.1f us | init avg %.2f max %.2f us | "
+              "loop avg %.2f max %.2f us (%.1f ns/request avg)\n",
+              n, cs, rounds, (t_max - t_min) / 100.0, init_sum / 100.0 / n, init_max / 100.0,
+              loop_sum / 100.0 / n, loop_max / 100.0, loop_sum * 10.0 / n / cs);
   }
   mark(c, 6);
   // ---- finalise
