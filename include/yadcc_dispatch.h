@@ -155,6 +155,91 @@ int ydc_get_stats(const ydc_context* ctx, ydc_stats* out);
  * The string lives until the next dispatch. */
 const char* ydc_kernel_profile(const ydc_context* ctx);
 
+
+/* ===========================================================================
+ * ydc_td_* — C wrapper of the host class GpuTaskDispatcher
+ * (yadcc_amd/csrc/gpu_task_dispatcher.h), i.e. of the reference's
+ * TaskDispatcher public surface, task_dispatcher.h:139-181. One function per
+ * method, strings as NUL-terminated char*, durations in nanoseconds.
+ * Thread-safe like the reference class (one internal lock; concurrent
+ * WaitForStartingNewTask callers are combined into one device batch).
+ * =========================================================================== */
+typedef struct ydc_td ydc_td;
+
+/* return codes of the wait functions (>= 0); negative: YDC_ERR_* */
+#define YDC_TD_GRANTED 0
+#define YDC_TD_ENV_NOT_FOUND 1 /* WaitStatus::EnvironmentNotFound -> STATUS_ENVIRONMENT_NOT_AVAILABLE */
+#define YDC_TD_TIMEOUT 2       /* WaitStatus::Timeout            -> STATUS_NO_QUOTA_AVAILABLE   */
+
+/* ServantPersonality, task_dispatcher.h:80-116. */
+typedef struct ydc_td_servant {
+  int32_t version;
+  const char* observed_location;
+  const char* reported_location;
+  const char* const* env_digests; /* EnvironmentDesc::compiler_digest of each environment */
+  size_t n_envs;
+  uint64_t num_processors, current_load, total_memory_in_bytes, memory_available_in_bytes,
+      max_tasks;
+  int32_t priority;                  /* ServantPriority, api/scheduler.proto:39-48 */
+  int32_t not_accepting_task_reason; /* api/scheduler.proto:51-62 */
+} ydc_td_servant;
+
+/* RunningTask, api/scheduler.proto:233-238. */
+typedef struct ydc_td_running_task {
+  uint64_t servant_task_id, task_grant_id;
+  const char* servant_location;
+  const char* task_digest;
+} ydc_td_running_task;
+
+/* device: HIP ordinal, or -1 for a dispatcher without a device (registry and lease
+ * bookkeeping only; every wait fails with YDC_ERR_NO_DEVICE — there is no CPU placement).
+ * min_memory: --servant_min_memory_for_accepting_new_task, NULL = "10G" (task_dispatcher.cc:35-38).
+ * start_timer: own 1 s expiration thread (task_dispatcher.cc:81-82).
+ * fake_clock: time only moves through ydc_td_set_clock_ns (tests). */
+int ydc_td_create(int device, const char* min_memory, int start_timer, int fake_clock,
+                  ydc_td** out);
+int ydc_td_destroy(ydc_td* td);
+int ydc_td_device_status(const ydc_td* td); /* YDC_OK or why placement is unavailable */
+int ydc_td_set_clock_ns(ydc_td* td, int64_t now_ns);
+
+/* KeepServantAlive, task_dispatcher.h:167-168. */
+int ydc_td_keep_servant_alive(ydc_td* td, const ydc_td_servant* servant, int64_t expires_in_ns);
+/* WaitForStartingNewTask, task_dispatcher.h:139-141. timeout_in_ns is relative to now
+ * (0: do not block). out_location receives TaskAllocation::servant_location. */
+int ydc_td_wait_for_starting_new_task(ydc_td* td, const char* requestor_ip, uint32_t min_version,
+                                      const char* compiler_digest, int64_t expires_in_ns,
+                                      int64_t timeout_in_ns, int prefetching,
+                                      uint64_t* out_task_id, char* out_location,
+                                      size_t location_cap);
+/* n back-to-back WaitForStartingNewTask(timeout = now) calls as ONE device batch
+ * (the loop of scheduler_service_impl.cc:234-264). out_status[i]: YDC_TD_*;
+ * out_locations: n strings of location_stride bytes each (nullable). */
+int ydc_td_wait_for_starting_new_tasks(ydc_td* td, size_t n, const char* const* requestor_ips,
+                                       const uint32_t* min_versions,
+                                       const char* const* compiler_digests, int64_t expires_in_ns,
+                                       const uint8_t* prefetching, int32_t* out_status,
+                                       uint64_t* out_task_ids, char* out_locations,
+                                       size_t location_stride);
+/* KeepTaskAlive, task_dispatcher.h:146-147: 1 renewed, 0 unknown or zombie. */
+int ydc_td_keep_task_alive(ydc_td* td, uint64_t task_id, int64_t new_expires_in_ns);
+/* FreeTask, task_dispatcher.h:154. */
+int ydc_td_free_task(ydc_td* td, uint64_t task_id);
+/* NotifyServantRunningTasks, task_dispatcher.h:175-176: returns the number of grant ids
+ * unknown to the dispatcher; the first min(count, unknown_cap) are written to out_unknown. */
+int64_t ydc_td_notify_servant_running_tasks(ydc_td* td, const char* servant_location,
+                                            const ydc_td_running_task* tasks, size_t n,
+                                            uint64_t* out_unknown, size_t unknown_cap);
+/* GetRunningTasks, task_dispatcher.h:180: returns the total count; the first
+ * min(count, cap) entries are written (string columns nullable, fixed stride). */
+int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
+                                 uint64_t* out_grant_ids, char* out_locations,
+                                 size_t location_stride, char* out_digests, size_t digest_stride,
+                                 size_t cap);
+/* OnExpirationTimer, task_dispatcher.cc:498-536 (for hosts that drive the 1 s tick themselves). */
+int ydc_td_on_expiration_timer(ydc_td* td);
+/* DumpInternals, task_dispatcher.cc:538-614, as JSON. Valid until the next call on td. */
+const char* ydc_td_dump_internals(ydc_td* td);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,699 @@
+// gpu_task_dispatcher.cc — see gpu_task_dispatcher.h. Placement goes through the
+// C-ABI only (ydc_upload_servants / ydc_update_servants / ydc_release_slots /
+// ydc_dispatch); this file never computes a pick itself.
+#include "gpu_task_dispatcher.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+
+#include "../../include/yadcc_dispatch.h"
+
+using namespace std::literals;
+
+namespace ydc {
+
+namespace {
+
+// TryParseSize (reference yadcc/common/parse_size.cc:25-45): digits with an
+// optional G/M/K/B suffix.
+bool ParseSize(const std::string& s, std::size_t* out) {
+  if (s.empty()) return false;
+  std::uint64_t scale = 1;
+  std::string body = s;
+  switch (s.back()) {
+    case 'G': scale = 1ull << 30; body.pop_back(); break;
+    case 'M': scale = 1ull << 20; body.pop_back(); break;
+    case 'K': scale = 1ull << 10; body.pop_back(); break;
+    case 'B': body.pop_back(); break;
+    default: break;
+  }
+  if (body.empty()) return false;
+  std::uint64_t v = 0;
+  for (char c : body) {
+    if (c < '0' || c > '9') return false;
+    v = v * 10 + (std::uint64_t)(c - '0');
+  }
+  *out = (std::size_t)(v * scale);
+  return true;
+}
+
+// Host part of a location for the requestor-is-the-servant test
+// (IsNetworkAddressEqual, task_dispatcher.cc:66-69: `location` starts with
+// `requestor_ip` followed by ':'). Exact for "a.b.c.d:port" endpoints (what
+// scheduler_service_impl.cc:102-103 produces for IPv4); bracketed IPv6
+// locations never equal a requestor address in the reference either.
+std::string HostOf(const std::string& location) {
+  auto p = location.find(':');
+  return p == std::string::npos ? std::string() : location.substr(0, p);
+}
+
+std::uint32_t Clamp32(std::size_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (std::uint32_t)v; }
+
+void JsonEscape(const std::string& s, std::string* out) {
+  out->push_back('"');
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': *out += "\\\""; break;
+      case '\\': *out += "\\\\"; break;
+      case '\n': *out += "\\n"; break;
+      case '\r': *out += "\\r"; break;
+      case '\t': *out += "\\t"; break;
+      default:
+        if (c < 0x20) {
+          char buf[8];
+          std::snprintf(buf, sizeof(buf), "\\u%04x", c);
+          *out += buf;
+        } else {
+          out->push_back((char)c);
+        }
+    }
+  }
+  out->push_back('"');
+}
+
+const char* PriorityName(int p) {  // ServantPriority_Name, api/scheduler.proto:39-48
+  switch (p) {
+    case kServantPriorityDedicated: return "SERVANT_PRIORITY_DEDICATED";
+    case kServantPriorityUser: return "SERVANT_PRIORITY_USER";
+    default: return "SERVANT_PRIORITY_UNKNOWN";
+  }
+}
+
+const char* ReasonName(int r) {  // NotAcceptingTaskReason_Name, api/scheduler.proto:51-62
+  switch (r) {
+    case 1: return "NOT_ACCEPTING_TASK_REASON_USER_INSTRUCTED";
+    case 2: return "NOT_ACCEPTING_TASK_REASON_POOR_MACHINE";
+    case 3: return "NOT_ACCEPTING_TASK_REASON_CGROUPS_PRESENT";
+    case 4: return "NOT_ACCEPTING_TASK_REASON_BEHIND_NAT";
+    case 5: return "NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED";
+    default: return "NOT_ACCEPTING_TASK_REASON_UNKNOWN";
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// RunningTaskBookkeeper
+// ---------------------------------------------------------------------------
+void RunningTaskBookkeeper::SetServantRunningTasks(const std::string& servant_location,
+                                                   std::vector<RunningTask> tasks) {
+  std::scoped_lock _(lock_);
+  running_tasks_[servant_location] = std::move(tasks);
+  flattened_valid_ = false;
+}
+
+void RunningTaskBookkeeper::DropServant(const std::string& servant_location) {
+  std::scoped_lock _(lock_);
+  if (running_tasks_.erase(servant_location)) flattened_valid_ = false;
+}
+
+std::vector<RunningTask> RunningTaskBookkeeper::GetRunningTasks() const {
+  std::scoped_lock _(lock_);
+  if (!flattened_valid_) {
+    // Order across servants is unspecified in the reference (hash-map order,
+    // running_task_bookkeeper.cc:39-41); order within a servant is kept.
+    flattened_.clear();
+    for (auto&& [k, v] : running_tasks_) flattened_.insert(flattened_.end(), v.begin(), v.end());
+    flattened_valid_ = true;
+  }
+  return flattened_;
+}
+
+// ---------------------------------------------------------------------------
+// GpuTaskDispatcher
+// ---------------------------------------------------------------------------
+GpuTaskDispatcher::GpuTaskDispatcher(const Options& options) : options_(options) {
+  if (!ParseSize(options_.servant_min_memory_for_accepting_new_task, &min_memory_for_new_task_)) {
+    // The reference FLARE_CHECKs the flag (task_dispatcher.cc:83-86).
+    std::fprintf(stderr, "GpuTaskDispatcher: cannot parse memory size [%s]\n",
+                 options_.servant_min_memory_for_accepting_new_task.c_str());
+    std::abort();
+  }
+  if (options_.device >= 0) {
+    device_status_ = ydc_create(options_.device, 0, 0, 0, nullptr, &ctx_);
+    if (device_status_ != YDC_OK) {
+      device_error_ = std::string(ydc_strerror(device_status_)) + ": " + ydc_last_error(nullptr);
+      ctx_ = nullptr;
+    }
+  } else {
+    device_status_ = YDC_ERR_NO_DEVICE;
+    device_error_ = "created without a device";
+  }
+  if (options_.start_expiration_timer) timer_ = std::thread([this] { TimerLoop(); });
+}
+
+GpuTaskDispatcher::~GpuTaskDispatcher() {
+  {
+    std::scoped_lock _(timer_lock_);
+    stopping_ = true;
+  }
+  timer_cv_.notify_all();
+  if (timer_.joinable()) timer_.join();
+  if (ctx_) ydc_destroy(ctx_);
+}
+
+void GpuTaskDispatcher::TimerLoop() {
+  std::unique_lock lk(timer_lock_);
+  while (!stopping_) {
+    if (timer_cv_.wait_for(lk, 1s, [this] { return stopping_; })) break;
+    lk.unlock();
+    OnExpirationTimer();
+    lk.lock();
+  }
+}
+
+std::size_t GpuTaskDispatcher::CapacityAvailable(const Servant& s) const {
+  // GetCapacityAvailable, task_dispatcher.cc:283-313 (for DumpInternals only;
+  // the dispatch path evaluates the same formula on the device).
+  const auto& p = s.personality;
+  if (p.total_memory_in_bytes != 0 && p.memory_available_in_bytes < min_memory_for_new_task_)
+    return s.running_tasks;
+  std::int64_t foreign = std::max<std::int64_t>((std::int64_t)p.current_load - (std::int64_t)s.running_tasks, 0);
+  std::int64_t cap = std::max<std::int64_t>((std::int64_t)p.num_processors - foreign, 0);
+  return std::min<std::size_t>(p.max_tasks, (std::size_t)cap);
+}
+
+std::uint32_t GpuTaskDispatcher::InternIp(const std::string& ip, bool create) {
+  auto it = ip_ids_.find(ip);
+  if (it != ip_ids_.end()) return it->second;
+  if (!create) return 0;  // 0: no servant lives there
+  std::uint32_t id = (std::uint32_t)ip_ids_.size() + 1;
+  ip_ids_.emplace(ip, id);
+  return id;
+}
+
+std::uint32_t GpuTaskDispatcher::LookupEnv(const std::string& digest) const {
+  auto it = env_ids_.find(digest);
+  return it == env_ids_.end() ? 0xFFFFu : it->second.first;
+}
+
+std::uint64_t GpuTaskDispatcher::AcquireEnvMask(const std::vector<std::string>& digests) {
+  std::uint64_t mask = 0;
+  for (auto&& d : digests) {
+    auto it = env_ids_.find(d);
+    if (it == env_ids_.end()) {
+      std::uint32_t bit;
+      if (!free_env_bits_.empty()) {
+        bit = free_env_bits_.back();
+        free_env_bits_.pop_back();
+      } else if (env_ids_.size() < YDC_MAX_ENVS) {
+        bit = (std::uint32_t)env_ids_.size();
+      } else {
+        ++env_overflow_;  // more than 64 distinct live digests: not representable
+        continue;
+      }
+      it = env_ids_.emplace(d, std::make_pair(bit, 0u)).first;
+    }
+    // A servant listing a digest twice still holds one reference per listing;
+    // ReleaseEnvMask walks the same list.
+    ++it->second.second;
+    mask |= 1ull << it->second.first;
+  }
+  return mask;
+}
+
+void GpuTaskDispatcher::ReleaseEnvMask(const std::vector<std::string>& digests) {
+  for (auto&& d : digests) {
+    auto it = env_ids_.find(d);
+    if (it == env_ids_.end()) continue;
+    if (--it->second.second == 0) {
+      free_env_bits_.push_back(it->second.first);
+      env_ids_.erase(it);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Servant maintenance
+// ---------------------------------------------------------------------------
+void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
+                                         std::chrono::nanoseconds expires_in) {
+  std::scoped_lock _(allocation_lock_);
+  auto now = Now();
+  auto it = index_of_location_.find(servant.observed_location);
+  std::uint32_t idx;
+  if (it != index_of_location_.end()) {
+    // Renewal: the personality is replaced wholesale, running_tasks,
+    // ever_assigned_tasks, discovered_at and the registry position stay
+    // (task_dispatcher.cc:195-201).
+    idx = it->second;
+    Servant* e = servants_[idx].get();
+    std::uint64_t mask = AcquireEnvMask(servant.environments);
+    ReleaseEnvMask(e->personality.environments);
+    e->personality = servant;
+    e->env_mask = mask;
+    e->expires_at = now + expires_in;
+  } else {
+    idx = (std::uint32_t)servants_.size();
+    auto added = std::make_unique<Servant>();
+    added->uid = next_servant_uid_++;
+    added->personality = servant;
+    added->discovered_at = now;
+    added->expires_at = now + expires_in;
+    added->running_tasks = 0;  // :210
+    added->env_mask = AcquireEnvMask(servant.environments);
+    added->ip_id = InternIp(HostOf(servant.observed_location), true);
+    index_of_location_.emplace(servant.observed_location, idx);
+    index_of_uid_.emplace(added->uid, idx);
+    servants_.push_back(std::move(added));
+    row_is_dirty_.push_back(0);
+  }
+  if (!row_is_dirty_[idx]) {
+    row_is_dirty_[idx] = 1;
+    dirty_rows_.push_back(idx);
+  }
+  // The reference does not signal the condition variable here
+  // (task_dispatcher.cc:190-220); waiters see the new capacity on their next
+  // attempt, which the epoch makes possible.
+  ++registry_epoch_;
+}
+
+std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(
+    const std::string& servant_location, std::vector<RunningTask> tasks) {
+  std::vector<std::uint64_t> task_grant_ids;
+  task_grant_ids.reserve(tasks.size());
+  for (auto&& t : tasks) task_grant_ids.push_back(t.task_grant_id);
+
+  std::scoped_lock _(allocation_lock_);
+  auto it = index_of_location_.find(servant_location);
+  if (it == index_of_location_.end()) return task_grant_ids;  // :241-243
+  Servant* servant = servants_[it->second].get();
+
+  UnsafeSweepZombiesOf(servant, {task_grant_ids.begin(), task_grant_ids.end()});
+
+  // Tasks reported by the servant but not (or no longer) granted on it are
+  // returned, in report order (:256-273). `grants` is the per-servant index the
+  // reference rebuilds with a scan over every task.
+  std::vector<std::uint64_t> unknown_tasks;
+  std::vector<RunningTask> kept;
+  kept.reserve(tasks.size());
+  for (auto&& t : tasks) {
+    bool permitted = false;
+    if (servant->grants.count(t.task_grant_id)) {
+      auto ti = tasks_.find(t.task_grant_id);
+      permitted = ti != tasks_.end() && !ti->second.zombie;
+    }
+    if (permitted) {
+      kept.push_back(std::move(t));
+    } else {
+      unknown_tasks.push_back(t.task_grant_id);
+    }
+  }
+  running_task_bookkeeper_.SetServantRunningTasks(servant_location, std::move(kept));
+  return unknown_tasks;
+}
+
+std::vector<RunningTask> GpuTaskDispatcher::GetRunningTasks() const {
+  return running_task_bookkeeper_.GetRunningTasks();
+}
+
+// ---------------------------------------------------------------------------
+// Leases
+// ---------------------------------------------------------------------------
+bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanoseconds new_expires_in) {
+  std::scoped_lock _(allocation_lock_);
+  auto it = tasks_.find(task_id);
+  if (it == tasks_.end()) return false;  // :146-153
+  if (it->second.zombie) return false;   // :154-162
+  it->second.expires_at = Now() + new_expires_in;
+  return true;
+}
+
+void GpuTaskDispatcher::FreeTask(std::uint64_t task_id) {
+  std::scoped_lock _(allocation_lock_);
+  UnsafeFreeTasks({task_id});
+}
+
+void GpuTaskDispatcher::UnsafeFreeTasks(const std::vector<std::uint64_t>& task_ids) {
+  for (auto id : task_ids) {
+    auto it = tasks_.find(id);
+    if (it == tasks_.end()) return;  // quirk kept: bails out, no wake-up (:176-180)
+    auto si = index_of_uid_.find(it->second.servant_uid);
+    if (si != index_of_uid_.end()) {
+      Servant* s = servants_[si->second].get();
+      --s->running_tasks;  // :181
+      s->grants.erase(id);
+      if (!need_full_upload_) pending_release_.push_back(si->second);
+    }
+    tasks_.erase(it);
+  }
+  ++registry_epoch_;
+  allocation_cv_.notify_all();  // :187
+}
+
+void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant,
+                                             const std::unordered_set<std::uint64_t>& running) {
+  std::vector<std::uint64_t> sweeping;  // :453-476
+  for (auto id : servant->grants) {
+    auto ti = tasks_.find(id);
+    if (ti != tasks_.end() && ti->second.zombie && running.count(id) == 0) sweeping.push_back(id);
+  }
+  UnsafeFreeTasks(sweeping);
+}
+
+void GpuTaskDispatcher::OnExpirationTimer() {
+  auto now = Now();
+  std::scoped_lock _(allocation_lock_);
+
+  // Expired servants leave the registry; the order of the others is kept
+  // because it decides ties (:503-516).
+  std::vector<std::uint64_t> orphans;
+  bool removed = false;
+  std::size_t w = 0;
+  for (std::size_t i = 0; i != servants_.size(); ++i) {
+    if (servants_[i]->expires_at < now) {
+      Servant* s = servants_[i].get();
+      running_task_bookkeeper_.DropServant(s->personality.observed_location);
+      ReleaseEnvMask(s->personality.environments);
+      orphans.insert(orphans.end(), s->grants.begin(), s->grants.end());
+      index_of_location_.erase(s->personality.observed_location);
+      index_of_uid_.erase(s->uid);
+      removed = true;
+    } else {
+      if (w != i) servants_[w] = std::move(servants_[i]);
+      ++w;
+    }
+  }
+  if (removed) {
+    servants_.resize(w);
+    for (std::uint32_t i = 0; i != servants_.size(); ++i) {
+      index_of_location_[servants_[i]->personality.observed_location] = i;
+      index_of_uid_[servants_[i]->uid] = i;
+    }
+    need_full_upload_ = true;
+    dirty_rows_.clear();
+    pending_release_.clear();
+    row_is_dirty_.assign(servants_.size(), 0);
+    ++registry_epoch_;
+  }
+  // UnsafeSweepOrphans (:478-496): tasks of vanished servants are forgotten at
+  // once. Their ids are exactly the grant sets of the servants removed above.
+  if (!orphans.empty()) UnsafeFreeTasks(orphans);
+
+  // Expired leases become zombies; they keep their slot until the servant's
+  // next heartbeat no longer lists them (:523-535, task_dispatcher.h:207-214).
+  for (auto&& [id, t] : tasks_) {
+    if (t.expires_at < now) t.zombie = true;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Placement
+// ---------------------------------------------------------------------------
+int GpuTaskDispatcher::UnsafeSyncDevice() {
+  if (!ctx_) return device_status_ ? device_status_ : YDC_ERR_NO_DEVICE;
+  auto flags_of = [this](const Servant& s) {
+    const auto& p = s.personality;
+    std::uint32_t f = 0;
+    if (p.priority == kServantPriorityDedicated) f |= YDC_SERVANT_DEDICATED;          // :405
+    if (p.total_memory_in_bytes != 0 && p.memory_available_in_bytes < min_memory_for_new_task_)
+      f |= YDC_SERVANT_LOW_MEMORY;                                                     // :286-287
+    return f;
+  };
+  if (need_full_upload_) {
+    const std::size_t n = servants_.size();
+    std::vector<std::uint32_t> version(n), nproc(n), load(n), max_tasks(n), running(n), flags(n), ip(n);
+    std::vector<std::uint64_t> env(n);
+    for (std::size_t i = 0; i != n; ++i) {
+      const Servant& s = *servants_[i];
+      version[i] = (std::uint32_t)s.personality.version;  // compared as unsigned, :333
+      nproc[i] = Clamp32(s.personality.num_processors);
+      load[i] = Clamp32(s.personality.current_load);
+      max_tasks[i] = Clamp32(s.personality.max_tasks);
+      running[i] = Clamp32(s.running_tasks);
+      flags[i] = flags_of(s);
+      env[i] = s.env_mask;
+      ip[i] = s.ip_id;
+    }
+    ydc_servant_soa soa{version.data(), nproc.data(), load.data(), max_tasks.data(),
+                        running.data(), flags.data(),  env.data(),  ip.data()};
+    int rc = ydc_upload_servants(ctx_, &soa, (std::uint32_t)n);
+    if (rc != YDC_OK) return rc;
+    need_full_upload_ = false;
+    dirty_rows_.clear();
+    pending_release_.clear();
+    row_is_dirty_.assign(n, 0);
+    return YDC_OK;
+  }
+  if (!dirty_rows_.empty()) {
+    std::sort(dirty_rows_.begin(), dirty_rows_.end());  // appended rows in index order
+    std::vector<ydc_servant_row> rows(dirty_rows_.size());
+    for (std::size_t k = 0; k != dirty_rows_.size(); ++k) {
+      const Servant& s = *servants_[dirty_rows_[k]];
+      rows[k].version = (std::uint32_t)s.personality.version;
+      rows[k].num_processors = Clamp32(s.personality.num_processors);
+      rows[k].current_load = Clamp32(s.personality.current_load);
+      rows[k].max_tasks = Clamp32(s.personality.max_tasks);
+      rows[k].flags = flags_of(s);
+      rows[k].ip_id = s.ip_id;
+      rows[k].env_mask = s.env_mask;
+    }
+    int rc = ydc_update_servants(ctx_, dirty_rows_.data(), rows.data(), (std::uint32_t)rows.size());
+    if (rc != YDC_OK) return rc;
+    for (auto i : dirty_rows_) row_is_dirty_[i] = 0;
+    dirty_rows_.clear();
+  }
+  if (!pending_release_.empty()) {
+    int rc = ydc_release_slots(ctx_, pending_release_.data(), (std::uint32_t)pending_release_.size());
+    if (rc != YDC_OK) return rc;
+    pending_release_.clear();
+  }
+  return YDC_OK;
+}
+
+void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
+  if (batch.empty()) return;
+  int rc = UnsafeSyncDevice();
+  const std::uint32_t n = (std::uint32_t)batch.size();
+  std::vector<std::uint32_t> env(n), minv(n), rip(n), out(n, YDC_IDX_TIMEOUT);
+  if (rc == YDC_OK) {
+    for (std::uint32_t i = 0; i != n; ++i) {
+      const TaskPersonality& p = *batch[i]->personality;
+      env[i] = LookupEnv(p.compiler_digest);
+      minv[i] = p.min_version;
+      rip[i] = InternIp(p.requestor_ip, false);
+    }
+    ydc_task_soa soa{env.data(), minv.data(), rip.data()};
+    rc = ydc_dispatch(ctx_, &soa, n, YDC_DISPATCH_COMMIT, out.data(), nullptr, nullptr);
+  }
+  if (rc != YDC_OK) {
+    // Fail loudly: every request of the batch gets the device error. The
+    // resident running_tasks may be stale now; rebuild it from the host's.
+    need_full_upload_ = true;
+    for (auto* r : batch) {
+      r->done = true;
+      r->result = WaitResult{};
+      r->result.device_error = rc;
+      r->result.status = WaitStatus::Timeout;
+    }
+    return;
+  }
+  auto now = Now();
+  for (std::uint32_t i = 0; i != n; ++i) {
+    Pending* r = batch[i];
+    if (out[i] == YDC_IDX_ENV_NOT_FOUND) {
+      r->done = true;  // :105-108
+      r->result.ok = false;
+      r->result.status = WaitStatus::EnvironmentNotFound;
+    } else if (out[i] == YDC_IDX_TIMEOUT) {
+      r->tried_epoch = registry_epoch_;  // stays pending until its deadline (:116-118)
+    } else {
+      Servant* pick = servants_[out[i]].get();
+      ++pick->running_tasks;  // :123-124 (the device did the same on its column: COMMIT)
+      ++pick->ever_assigned_tasks;
+      const std::uint64_t task_id = next_task_id_++;  // :127
+      Task& t = tasks_[task_id];
+      t.task_id = task_id;
+      t.personality = *r->personality;
+      t.servant_uid = pick->uid;
+      t.started_at = now;
+      t.expires_at = now + r->expires_in;
+      t.is_prefetch = r->prefetching;
+      pick->grants.insert(task_id);
+      r->done = true;
+      r->result.ok = true;
+      r->result.allocation.task_id = task_id;
+      r->result.allocation.servant_location = pick->personality.observed_location;
+    }
+  }
+}
+
+void GpuTaskDispatcher::UnsafeDrainQueue() {
+  {
+    std::scoped_lock _(queue_lock_);
+    waiting_.insert(waiting_.end(), queue_.begin(), queue_.end());
+    queue_.clear();
+  }
+  // One device batch, arrival order; requests that already failed against this
+  // very registry state are not retried.
+  std::vector<Pending*> batch;
+  for (auto* r : waiting_)
+    if (!r->done && r->tried_epoch != registry_epoch_) batch.push_back(r);
+  UnsafeDispatch(batch);
+  waiting_.erase(std::remove_if(waiting_.begin(), waiting_.end(), [](Pending* r) { return r->done; }),
+                 waiting_.end());
+}
+
+WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& personality,
+                                                     std::chrono::nanoseconds expires_in,
+                                                     Clock::time_point timeout, bool prefetching) {
+  Pending req;
+  req.personality = &personality;
+  req.expires_in = expires_in;
+  req.deadline = timeout;
+  req.prefetching = prefetching;
+  {
+    // Concurrent callers queue up here; whoever holds allocation_lock_ next
+    // places all of them as one batch.
+    std::scoped_lock _(queue_lock_);
+    queue_.push_back(&req);
+  }
+  std::unique_lock lk(allocation_lock_);
+  for (;;) {
+    UnsafeDrainQueue();
+    if (req.done) return req.result;
+    bool timed_out;
+    if (options_.clock) {
+      // Injected (test) clock: poll it, do not sleep on the real one.
+      timed_out = Now() >= req.deadline;
+      if (!timed_out) allocation_cv_.wait_for(lk, 1ms);
+    } else {
+      timed_out = allocation_cv_.wait_until(lk, req.deadline) == std::cv_status::timeout;
+    }
+    if (req.done) return req.result;  // a concurrent drain served us meanwhile
+    if (timed_out) {
+      waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), &req), waiting_.end());
+      WaitResult r;
+      r.status = WaitStatus::Timeout;  // :116-118
+      return r;
+    }
+  }
+}
+
+std::vector<WaitResult> GpuTaskDispatcher::WaitForStartingNewTasks(
+    const std::vector<TaskPersonality>& personalities, std::chrono::nanoseconds expires_in,
+    const std::vector<bool>& prefetching) {
+  std::vector<Pending> reqs(personalities.size());
+  std::unique_lock lk(allocation_lock_);
+  auto now = Now();
+  std::vector<Pending*> batch;
+  batch.reserve(reqs.size());
+  for (std::size_t i = 0; i != reqs.size(); ++i) {
+    reqs[i].personality = &personalities[i];
+    reqs[i].expires_in = expires_in;
+    reqs[i].deadline = now;
+    reqs[i].prefetching = i < prefetching.size() && prefetching[i];
+    batch.push_back(&reqs[i]);
+  }
+  UnsafeDrainQueue();  // earlier arrivals first
+  UnsafeDispatch(batch);
+  std::vector<WaitResult> out(reqs.size());
+  for (std::size_t i = 0; i != reqs.size(); ++i) {
+    if (reqs[i].done) {
+      out[i] = reqs[i].result;
+    } else {
+      out[i].status = WaitStatus::Timeout;  // timeout == now
+    }
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------
+// DumpInternals (task_dispatcher.cc:538-614): same keys.
+// ---------------------------------------------------------------------------
+std::string GpuTaskDispatcher::DumpInternals() {
+  std::scoped_lock _(allocation_lock_);
+  auto format_time = [this](Clock::time_point tp) {
+    // steady -> system clock, like flare::internal::SystemClockView.
+    auto sys = std::chrono::system_clock::now() +
+               std::chrono::duration_cast<std::chrono::system_clock::duration>(tp - Now());
+    std::time_t t = std::chrono::system_clock::to_time_t(sys);
+    struct tm buf;
+    char out[64] = "";
+    if (localtime_r(&t, &buf)) std::strftime(out, sizeof(out), "%Y-%m-%d %H:%M:%S", &buf);
+    return std::string(out);
+  };
+  std::string j = "{";
+  std::uint64_t cluster_capacity = 0, capacity_unavailable = 0, total_running = 0;
+  j += "\"servants\":[";
+  for (std::size_t i = 0; i != servants_.size(); ++i) {
+    const Servant& e = *servants_[i];
+    const auto& p = e.personality;
+    if (i) j += ",";
+    j += "{\"version\":" + std::to_string(p.version);
+    if (p.observed_location != p.reported_location) {
+      j += ",\"observed_location\":";
+      JsonEscape(p.observed_location, &j);
+      j += ",\"reported_location\":";
+      JsonEscape(p.reported_location, &j);
+    } else {
+      j += ",\"location\":";
+      JsonEscape(p.observed_location, &j);
+    }
+    j += ",\"discovered_at\":";
+    JsonEscape(format_time(e.discovered_at), &j);
+    j += ",\"expires_at\":";
+    JsonEscape(format_time(e.expires_at), &j);
+    j += ",\"environments\":[";
+    for (std::size_t k = 0; k != p.environments.size(); ++k) {
+      if (k) j += ",";
+      JsonEscape(p.environments[k], &j);
+    }
+    j += "],\"priority\":";
+    JsonEscape(PriorityName(p.priority), &j);
+    if (p.max_tasks) {
+      j += ",\"max_tasks\":" + std::to_string(p.max_tasks);
+    } else {
+      j += ",\"not_accepting_task_reason\":";
+      JsonEscape(ReasonName(p.not_accepting_task_reason), &j);
+    }
+    const std::size_t cap = CapacityAvailable(e);
+    j += ",\"num_processors\":" + std::to_string(p.num_processors);
+    j += ",\"current_load\":" + std::to_string(p.current_load);
+    j += ",\"capacity_available\":" + std::to_string((std::int64_t)cap);
+    j += ",\"total_memory_mb\":" + std::to_string(p.total_memory_in_bytes / 1024 / 1024);
+    j += ",\"memory_available_mb\":" + std::to_string(p.memory_available_in_bytes / 1024 / 1024);
+    j += ",\"running_tasks\":" + std::to_string(e.running_tasks);
+    j += ",\"ever_assigned_tasks\":" + std::to_string(e.ever_assigned_tasks) + "}";
+    total_running += e.running_tasks;
+    cluster_capacity += p.max_tasks;
+    capacity_unavailable += p.max_tasks - cap;
+  }
+  j += "],\"tasks\":{";
+  bool first = true;
+  for (auto&& [k, v] : tasks_) {
+    if (!first) j += ",";
+    first = false;
+    j += "\"" + std::to_string(k) + "\":{\"task_id\":" + std::to_string(v.task_id);
+    j += ",\"requestor_ip\":";
+    JsonEscape(v.personality.requestor_ip, &j);
+    j += ",\"compiler_digest\":";
+    JsonEscape(v.personality.compiler_digest, &j);
+    j += ",\"started_at\":";
+    JsonEscape(format_time(v.started_at), &j);
+    j += ",\"expires_at\":";
+    JsonEscape(format_time(v.expires_at), &j);
+    j += std::string(",\"prefetched_task\":") + (v.is_prefetch ? "true" : "false");
+    auto si = index_of_uid_.find(v.servant_uid);
+    j += ",\"servant_location\":";
+    JsonEscape(si == index_of_uid_.end() ? std::string() : servants_[si->second]->personality.observed_location, &j);
+    j += std::string(",\"zombie\":") + (v.zombie ? "true" : "false") + "}";
+  }
+  j += "}";
+  j += ",\"servants_up\":" + std::to_string(servants_.size());
+  j += ",\"running_tasks\":" + std::to_string(total_running);
+  j += ",\"capacity\":" + std::to_string(cluster_capacity);
+  std::int64_t avail = (std::int64_t)(cluster_capacity - total_running - capacity_unavailable);
+  j += ",\"capacity_available\":" + std::to_string(std::max<std::int64_t>(avail, 0));
+  j += ",\"capacity_unavailable\":" + std::to_string(capacity_unavailable);
+  j += ",\"gpu\":{\"device\":" + std::to_string(options_.device) +
+       ",\"device_status\":" + std::to_string(device_status_) +
+       ",\"environments_interned\":" + std::to_string(env_ids_.size()) +
+       ",\"environments_overflowed\":" + std::to_string(env_overflow_) + "}";
+  j += "}";
+  return j;
+}
+
+}  // namespace ydc

@@ -1,0 +1,198 @@
+"""ctypes view of the host class GpuTaskDispatcher (ydc_td_*, include/yadcc_dispatch.h):
+the reference's TaskDispatcher surface (yadcc/scheduler/task_dispatcher.h:139-181),
+method for method. Placement always runs on the GPU through libydc.so; a dispatcher
+created with device=-1 only keeps the registry / lease state and fails every wait with
+YDC_ERR_NO_DEVICE (no CPU placement exists in this package).
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import binding
+
+GRANTED, ENV_NOT_FOUND, TIMEOUT = 0, 1, 2
+PRIORITY_DEDICATED, PRIORITY_USER = 1, 2
+
+TD_SYMBOLS = (
+    "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
+    "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
+    "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
+    "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
+    "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
+)
+
+
+class _Servant(C.Structure):
+    _fields_ = [("version", C.c_int32), ("observed_location", C.c_char_p),
+                ("reported_location", C.c_char_p), ("env_digests", C.POINTER(C.c_char_p)),
+                ("n_envs", C.c_size_t), ("num_processors", C.c_uint64),
+                ("current_load", C.c_uint64), ("total_memory_in_bytes", C.c_uint64),
+                ("memory_available_in_bytes", C.c_uint64), ("max_tasks", C.c_uint64),
+                ("priority", C.c_int32), ("not_accepting_task_reason", C.c_int32)]
+
+
+class _RunningTask(C.Structure):
+    _fields_ = [("servant_task_id", C.c_uint64), ("task_grant_id", C.c_uint64),
+                ("servant_location", C.c_char_p), ("task_digest", C.c_char_p)]
+
+
+_typed = False
+
+
+def _lib():
+    global _typed
+    L = binding.lib()
+    if not _typed:
+        u64p = C.POINTER(C.c_uint64)
+        L.ydc_td_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ydc_td_destroy.argtypes = [C.c_void_p]
+        L.ydc_td_device_status.argtypes = [C.c_void_p]
+        L.ydc_td_set_clock_ns.argtypes = [C.c_void_p, C.c_int64]
+        L.ydc_td_keep_servant_alive.argtypes = [C.c_void_p, C.POINTER(_Servant), C.c_int64]
+        L.ydc_td_wait_for_starting_new_task.argtypes = [
+            C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int64, C.c_int64, C.c_int, u64p,
+            C.c_char_p, C.c_size_t]
+        L.ydc_td_wait_for_starting_new_tasks.argtypes = [
+            C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(C.c_char_p),
+            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.ydc_td_keep_task_alive.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+        L.ydc_td_free_task.argtypes = [C.c_void_p, C.c_uint64]
+        L.ydc_td_notify_servant_running_tasks.argtypes = [
+            C.c_void_p, C.c_char_p, C.POINTER(_RunningTask), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ydc_td_notify_servant_running_tasks.restype = C.c_int64
+        L.ydc_td_get_running_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p,
+                                               C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t]
+        L.ydc_td_get_running_tasks.restype = C.c_int64
+        L.ydc_td_on_expiration_timer.argtypes = [C.c_void_p]
+        L.ydc_td_dump_internals.argtypes = [C.c_void_p]
+        L.ydc_td_dump_internals.restype = C.c_char_p
+        _typed = True
+    return L
+
+
+MS = 1_000_000  # ns
+
+
+class GpuTaskDispatcher:
+    """Same method names / argument meaning as oracle.refbind.RefDispatcher, which wraps the
+    reference class itself — the parity tests drive both with the same calls."""
+
+    LOC = 128
+
+    def __init__(self, device=0, min_memory=None, start_timer=False, fake_clock=True):
+        h = C.c_void_p()
+        rc = _lib().ydc_td_create(device, min_memory.encode() if min_memory else None,
+                                  int(start_timer), int(fake_clock), C.byref(h))
+        if rc:
+            raise binding.YdcError("ydc_td_create: %s" % _lib().ydc_strerror(rc).decode())
+        self._h = h
+        self._now_ns = 0
+
+    def close(self):
+        if self._h:
+            _lib().ydc_td_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_status(self):
+        return _lib().ydc_td_device_status(self._h)
+
+    def clock_advance_ms(self, ms):
+        self._now_ns += int(ms) * MS
+        _lib().ydc_td_set_clock_ns(self._h, self._now_ns)
+
+    def keep_servant_alive(self, location, envs, max_tasks, num_processors, current_load,
+                           priority=PRIORITY_USER, version=8, total_memory=0,
+                           memory_available=50 << 30, expires_in_ms=10000, reported=None,
+                           reason=0):
+        arr = (C.c_char_p * max(len(envs), 1))(*[e.encode() for e in envs])
+        s = _Servant(version, location.encode(), (reported or location).encode(), arr, len(envs),
+                     num_processors, current_load, total_memory, memory_available, max_tasks,
+                     priority, reason)
+        rc = _lib().ydc_td_keep_servant_alive(self._h, C.byref(s), expires_in_ms * MS)
+        assert rc == 0
+
+    def wait_for_starting_new_task(self, requestor_ip, digest, min_version=8,
+                                   expires_in_ms=1000, timeout_in_ms=0, prefetching=False):
+        tid = C.c_uint64(0)
+        buf = C.create_string_buffer(self.LOC)
+        st = _lib().ydc_td_wait_for_starting_new_task(
+            self._h, requestor_ip.encode(), min_version, digest.encode(), expires_in_ms * MS,
+            timeout_in_ms * MS, int(prefetching), C.byref(tid), buf, self.LOC)
+        if st < 0:
+            raise binding.YdcError("wait_for_starting_new_task: %s" %
+                                   _lib().ydc_strerror(st).decode())
+        if st != GRANTED:
+            return st, None, None
+        return GRANTED, tid.value, buf.value.decode()
+
+    def wait_for_starting_new_tasks(self, requestor_ips, digests, min_versions,
+                                    expires_in_ms=1000, prefetching=None):
+        """One device batch == len(digests) back-to-back calls with timeout == now.
+        Returns (status[n], task_id[n], location[n])."""
+        n = len(digests)
+        ips = (C.c_char_p * max(n, 1))(*[x.encode() for x in requestor_ips])
+        dg = (C.c_char_p * max(n, 1))(*[x.encode() for x in digests])
+        mv = np.ascontiguousarray(min_versions, dtype=np.uint32)
+        pf = None if prefetching is None else np.ascontiguousarray(prefetching, dtype=np.uint8)
+        st = np.empty(n, dtype=np.int32)
+        ids = np.empty(n, dtype=np.uint64)
+        locs = C.create_string_buffer(max(n, 1) * self.LOC)
+        rc = _lib().ydc_td_wait_for_starting_new_tasks(
+            self._h, n, ips, mv.ctypes.data, dg, expires_in_ms * MS,
+            pf.ctypes.data if pf is not None else None, st.ctypes.data, ids.ctypes.data, locs,
+            self.LOC)
+        if rc < 0:
+            raise binding.YdcError("wait_for_starting_new_tasks: %s" %
+                                   _lib().ydc_strerror(rc).decode())
+        raw = locs.raw
+        out_locs = [raw[i * self.LOC:(i + 1) * self.LOC].split(b"\0", 1)[0].decode()
+                    for i in range(n)]
+        return st, ids, out_locs
+
+    def keep_task_alive(self, task_id, ms):
+        return bool(_lib().ydc_td_keep_task_alive(self._h, task_id, ms * MS))
+
+    def free_task(self, task_id):
+        _lib().ydc_td_free_task(self._h, task_id)
+
+    def notify_servant_running_tasks(self, location, grant_ids, servant_task_ids=None,
+                                     digests=None):
+        n = len(grant_ids)
+        arr = (_RunningTask * max(n, 1))()
+        for i, g in enumerate(grant_ids):
+            arr[i].servant_task_id = int(servant_task_ids[i]) if servant_task_ids is not None else i
+            arr[i].task_grant_id = int(g)
+            arr[i].servant_location = location.encode()
+            arr[i].task_digest = digests[i].encode() if digests else None
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        cnt = _lib().ydc_td_notify_servant_running_tasks(self._h, location.encode(), arr, n,
+                                                         out.ctypes.data, len(out))
+        assert cnt >= 0
+        return [int(x) for x in out[:cnt]]
+
+    def get_running_tasks(self, cap=1 << 16, with_strings=False):
+        st = np.zeros(cap, dtype=np.uint64)
+        gr = np.zeros(cap, dtype=np.uint64)
+        locs = C.create_string_buffer(cap * self.LOC) if with_strings else None
+        n = _lib().ydc_td_get_running_tasks(self._h, st.ctypes.data, gr.ctypes.data, locs,
+                                            self.LOC if with_strings else 0, None, 0, cap)
+        pairs = list(zip(st[:n].tolist(), gr[:n].tolist()))
+        if not with_strings:
+            return pairs
+        raw = locs.raw
+        return [(a, b, raw[i * self.LOC:(i + 1) * self.LOC].split(b"\0", 1)[0].decode())
+                for i, (a, b) in enumerate(pairs)]
+
+    def on_expiration_timer(self):
+        _lib().ydc_td_on_expiration_timer(self._h)
+
+    def dump_internals(self):
+        return json.loads(_lib().ydc_td_dump_internals(self._h).decode())
