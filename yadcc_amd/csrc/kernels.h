@@ -9,7 +9,7 @@
 //   k_radix_* (cls)  stable partition of the sorted ranks by servant class
 //   k_task_classify  per task: eligible-class mask, own-servant slot range
 //   k_chunk_prefix / k_guess_init   speculative start state of every task chunk
-//   k_sim_wave + k_update (rounds)  chunk-parallel replay of the greedy picks
+//   k_match_round (rounds)          chunk-parallel replay of the greedy picks (match_kernel.h)
 //   k_finalize       slot -> servant index, utilisation, running_tasks
 //
 // The arithmetic (capacity, keys, class-state machine) lives in dispatch_core.h
@@ -36,7 +36,7 @@ struct DeviceParams {
   uint32_t n_slots;       // M: free slots of this batch
   uint32_t overflow;      // M exceeded the workspace
   uint32_t need_shared;   // some task's host runs several servants
-  uint32_t n_changed[2];  // guesses changed by k_update in rounds of even / odd index
+  uint32_t n_changed[64]; // end states changed in round r, at index r & 63 (match_kernel.h)
   uint32_t chunk_sims;    // chunk simulations executed (all rounds)
   uint32_t granted, timeouts, env_not_found;
 };
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->need_shared = 0;
-    prm->n_changed[0] = prm->n_changed[1] = 0;
+    for (int r = 0; r < 64; ++r) prm->n_changed[r] = 0;
     prm->chunk_sims = 0;
     prm->granted = prm->timeouts = prm->env_not_found = 0;
     uint32_t acc = 0;
@@ -412,306 +412,6 @@ __global__ __launch_bounds__(256) void k_guess_init(ClassLists L, const uint32_t
   if (c == 0) dirty[k] = 1;
 }
 
-// ---------------------------------------------------------------------------
-// k_sim_wave: one wave (= one workgroup) per task chunk, one lane per servant
-// class (W classes per lane when there are more than 64). Replays the chunk's
-// requests in order: every lane offers its class's smallest admissible slot, a
-// 6-instruction DPP min picks the winner, the winning lane advances its class.
-//
-// A request's pick depends on the previous one, so the loop is latency-bound:
-// the class lists are therefore staged through LDS. Every class owns a ring of
-// R list entries (rank, generation index) ahead of its cursor; the winner reads
-// its next head from the ring (LDS latency instead of HBM/L2 latency), and when
-// a ring runs low all 64 lanes refill it with one coalesced load.
-// ---------------------------------------------------------------------------
-template <int W, int R>
-struct SimRing {
-  static constexpr int CP = 64 * W;  // classes, padded
-  uint32_t* p;                       // [R][CP] global rank
-  uint32_t* g;                       // [R][CP] generation index
-  __device__ __forceinline__ uint32_t at(uint32_t i, uint32_t cl) const {
-    return (i & (R - 1)) * CP + cl;
-  }
-};
-
-template <int W, int R>
-__global__ __launch_bounds__(64) void k_sim_wave(ClassLists L, TaskTable T, uint32_t n_tasks,
-                                                 uint32_t chunk_size, uint32_t n_chunks,
-                                                 const ClassState* guess, ClassState* endst,
-                                                 uint8_t* dirty, uint32_t* slot_of,
-                                                 uint32_t round, DeviceParams* prm,
-                                                 uint64_t* dbg) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
-  const uint64_t dbg_t0 = dbg ? wall_clock64() : 0;
-  // This round's change counter is zeroed here; k_update (next kernel on the
-  // stream) adds to it.
-  if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
-  if (prm->need_shared) return;
-  const uint32_t lane = threadIdx.x;
-  const uint32_t k = blockIdx.x;
-  if (k >= n_chunks) return;
-  if (!dirty[k]) return;
-  const uint32_t C = L.n_classes;
-  SimRing<W, R> ring{lds_ring, lds_ring + R * 64 * W};
-  ClassRun r[W];
-  uint32_t filled[W];  // ring of class j holds list entries [cursor, filled)
-#pragma unroll
-  for (int j = 0; j < W; ++j) {
-    const uint32_t c = lane + 64 * j;
-    if (c < C) {
-      const ClassState st = guess[(size_t)k * C + c];
-      const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
-      uint32_t cur = st.cursor, lo = st.lo;
-      cur = cur < b ? b : (cur > e ? e : cur);
-      lo = lo < b ? b : (lo > cur ? cur : lo);
-      r[j].cursor = cur;
-      r[j].lo = lo;
-      r[j].hown_lo = st.hown_lo;
-      r[j].hown_hi = st.hown_hi;
-      r[j].end = e;
-    } else {
-      r[j].cursor = r[j].lo = r[j].end = 0;
-      r[j].hown_lo = r[j].hown_hi = kNone;
-    }
-    // Initial fill, every lane its own ring: 16 independent loads in flight per lane.
-    const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
-    for (uint32_t base = r[j].cursor; base < hi; base += 16) {
-      uint32_t tp[16], tg[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const uint32_t i = base + u;
-        tp[u] = i < hi ? list_rank(L, i) : 0;
-        tg[u] = i < hi ? L.list_g[i] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const uint32_t i = base + u;
-        if (i < hi) {
-          ring.p[ring.at(i, c)] = tp[u];
-          ring.g[ring.at(i, c)] = tg[u];
-        }
-      }
-    }
-    filled[j] = hi;
-    if (r[j].cursor < r[j].end) {
-      r[j].head_p = ring.p[ring.at(r[j].cursor, c)];
-      r[j].head_g = ring.g[ring.at(r[j].cursor, c)];
-    } else {
-      r[j].head_p = r[j].head_g = kNone;
-    }
-  }
-  const uint64_t dbg_t1 = dbg ? wall_clock64() : 0;
-  const uint32_t t0 = k * chunk_size;
-  const uint32_t t1 = min(n_tasks, t0 + chunk_size);
-  for (uint32_t tb = t0; tb < t1; tb += 64) {
-    // Lane l stages task tb + l; the loop below broadcasts with v_readlane and
-    // collects the 64 results in `res` (one coalesced store per 64 requests).
-    uint32_t mlo[W], mhi[W], slo = kNone, shi = kNone;
-    const uint32_t tl = tb + lane;
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      uint64_t m = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
-      mlo[j] = (uint32_t)m;
-      mhi[j] = (uint32_t)(m >> 32);
-    }
-    if (tl < t1) {
-      slo = T.self_lo[tl];
-      shi = T.self_hi[tl];
-    }
-    uint32_t res = kIdxTimeout;
-    const uint32_t cnt = min(64u, t1 - tb);
-    uint32_t i = 0;
-    while (i < cnt) {
-      // ================= fast loop =================
-      // Stays here while, for every request, no eligible class has holes or
-      // shows a slot of the requestor's own servant at its head, some slot is
-      // left, and the winner's ring is not running low. ~60 instructions per
-      // request; anything else drops to the general step below.
-      bool refill = false;
-      uint32_t f_from = 0, f_to = 0, f_cl = 0, f_win = 0;
-      for (; i < cnt; ++i) {
-        uint64_t any = 0;
-        uint64_t mw[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
-                  (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
-          any |= mw[j];
-        }
-        if (any == 0) {
-          res = lane == i ? kIdxEnvNotFound : res;
-          continue;
-        }
-        const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
-        const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
-        uint32_t bp = kNone, bg = 0;
-        int bj = 0;
-        bool odd = false;
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const bool compat = (mw[j] >> lane) & 1u;
-          const bool plain = r[j].lo == r[j].cursor &&
-                             !(r[j].head_g >= self_lo && r[j].head_g < self_hi);
-          odd |= compat && !plain;
-          if (compat && plain && r[j].head_p < bp) {
-            bp = r[j].head_p;
-            bg = r[j].head_g;
-            bj = j;
-          }
-        }
-        if (__ballot(odd)) break;
-        const uint32_t mn = wave_min_u32(bp);
-        if (mn == kNone) break;
-        const uint32_t win = (uint32_t)__builtin_ctzll(__ballot(bp == mn));
-        const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)bg, (int)win);
-        res = lane == i ? taken : res;
-        if (lane == win) {
-#pragma unroll
-          for (int j = 0; j < W; ++j) {
-            if (j == bj) {
-              const uint32_t cur = r[j].cursor + 1;
-              r[j].cursor = cur;
-              r[j].lo = cur;
-              if (cur < r[j].end) {
-                r[j].head_p = ring.p[ring.at(cur, lane + 64 * j)];
-                r[j].head_g = ring.g[ring.at(cur, lane + 64 * j)];
-                const uint32_t hi = min(r[j].end, cur + (uint32_t)R);
-                if (filled[j] - cur <= (uint32_t)(R / 4) && filled[j] < hi) {
-                  refill = true;
-                  f_from = filled[j];
-                  f_to = hi;
-                  f_cl = lane + 64 * j;
-                  filled[j] = hi;
-                }
-              } else {
-                r[j].head_p = r[j].head_g = kNone;
-              }
-            }
-          }
-        }
-        if (__ballot(refill)) {
-          f_win = win;
-          ++i;
-          break;
-        }
-      }
-      if (__ballot(refill)) {
-        // Wave-uniform: all lanes fetch the winner's next entries, coalesced.
-        const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)f_from, (int)f_win);
-        const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)f_to, (int)f_win);
-        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)f_cl, (int)f_win);
-        for (uint32_t e0 = from; e0 < to; e0 += 64) {
-          const uint32_t e = e0 + lane;
-          if (e < to) {
-            ring.p[ring.at(e, cl)] = list_rank(L, e);
-            ring.g[ring.at(e, cl)] = L.list_g[e];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-      if (i >= cnt) break;
-      // ================= general step (request i) =================
-      // Holes, own-servant heads, exhausted pool. Class state is advanced with
-      // the shared state machine; the ring is rebuilt for the class that moved.
-      {
-        uint64_t mw[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          mw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi[j], (int)i) << 32) |
-                  (uint32_t)__builtin_amdgcn_readlane((int)mlo[j], (int)i);
-        }
-        const uint32_t self_lo = (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)i);
-        const uint32_t self_hi = (uint32_t)__builtin_amdgcn_readlane((int)shi, (int)i);
-        uint32_t bp = kNone, bi = 0, bg = 0;
-        int bj = 0;
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          if ((mw[j] >> lane) & 1u) {
-            uint32_t ci, cp, cg;
-            if (class_candidate(L, r[j], self_lo, self_hi, ci, cp, cg) && cp < bp) {
-              bp = cp;
-              bi = ci;
-              bg = cg;
-              bj = j;
-            }
-          }
-        }
-        const uint32_t mn = wave_min_u32(bp);
-        uint64_t winners;
-        if (mn != kNone) {
-          winners = __ballot(bp == mn);
-        } else {
-          // Nothing but (maybe) the requestor's own servant is left.
-          bool ok = false;
-          if (self_lo != kNone) {
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              if (!ok && ((mw[j] >> lane) & 1u)) {
-                uint32_t ci, cg;
-                if (class_self_candidate(L, r[j], self_lo, self_hi, ci, cg)) {
-                  ok = true;
-                  bi = ci;
-                  bg = cg;
-                  bj = j;
-                }
-              }
-            }
-          }
-          winners = __ballot(ok);
-        }
-        if (winners == 0) {
-          res = lane == i ? kIdxTimeout : res;
-        } else {
-          const uint32_t win = (uint32_t)__builtin_ctzll(winners);
-          const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)bg, (int)win);
-          res = lane == i ? taken : res;
-          if (lane == win) {
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              if (j == bj && class_consume_state(L, r[j], bi, self_lo, self_hi)) {
-                // Cursor moved (possibly far): restart this class's ring at it.
-                const uint32_t cl = lane + 64 * j;
-                const uint32_t hi = min(r[j].end, r[j].cursor + (uint32_t)R);
-                for (uint32_t e = max(r[j].cursor, min(filled[j], hi)); e < hi; ++e) {
-                  ring.p[ring.at(e, cl)] = list_rank(L, e);
-                  ring.g[ring.at(e, cl)] = L.list_g[e];
-                }
-                if (filled[j] < r[j].cursor) {
-                  // jumped past the old window: everything in [cursor, hi) was reloaded above
-                }
-                filled[j] = max(filled[j], hi);
-                if (r[j].cursor < r[j].end) {
-                  r[j].head_p = ring.p[ring.at(r[j].cursor, cl)];
-                  r[j].head_g = ring.g[ring.at(r[j].cursor, cl)];
-                } else {
-                  r[j].head_p = r[j].head_g = kNone;
-                }
-              }
-            }
-          }
-        }
-        ++i;
-      }
-    }
-    if (tl < t1) slot_of[tl] = res;
-  }
-#pragma unroll
-  for (int j = 0; j < W; ++j) {
-    uint32_t c = lane + 64 * j;
-    if (c < C) endst[(size_t)k * C + c] = class_run_state(r[j]);
-  }
-  if (lane == 0) {
-    dirty[k] = 0;
-    atomicAdd(&prm->chunk_sims, 1u);
-    if (dbg) {  // 100 MHz ticks: [launch-relative start, init, loop]
-      dbg[3 * k + 0] = dbg_t0;
-      dbg[3 * k + 1] = dbg_t1 - dbg_t0;
-      dbg[3 * k + 2] = wall_clock64() - dbg_t1;
-    }
-  }
-}
-
 // Thread per chunk, any number of classes, optional run-time `self` resolution
 // (then n_chunks must be 1). Slow path: hosts that run several servants, or
 // more than kMaxWaveClasses classes.
@@ -722,7 +422,7 @@ __global__ __launch_bounds__(64) void k_sim_generic(ClassLists L, TaskTable T, u
                                                     ClassRun* runs, SharedIpTable shared,
                                                     uint32_t only_if_shared, uint32_t round,
                                                     DeviceParams* prm) {
-  if (!only_if_shared && blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 1] = 0;
+  if (!only_if_shared && blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
   if (only_if_shared && !prm->need_shared) return;
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_chunks) return;
@@ -769,7 +469,7 @@ __global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_c
     }
   }
   const uint64_t b = __ballot(changed);
-  if (b && (threadIdx.x & 63) == 0) atomicAdd(&prm->n_changed[round & 1], (uint32_t)__popcll(b));
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(&prm->n_changed[round & 63], (uint32_t)__popcll(b));
 }
 
 // ---------------------------------------------------------------------------
@@ -778,7 +478,10 @@ __global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_c
 __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_t* slot_base,
                                                   const uint32_t* slot_of, uint32_t n_tasks,
                                                   uint32_t* out_idx, double* out_util,
-                                                  uint32_t* running_out, DeviceParams* prm) {
+                                                  uint32_t* running_out, uint32_t check_slot,
+                                                  DeviceParams* prm) {
+  // Pre-launched behind the matching rounds: only runs once they have converged.
+  if (check_slot != kNone && prm->n_changed[check_slot] != 0) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t kind = 3;  // 0 granted, 1 timeout, 2 env-not-found, 3 inactive lane
   if (t < n_tasks) {
@@ -814,4 +517,7 @@ __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_i
 }
 
 }  // namespace ydc
+
+#include "match_kernel.h"
+
 #endif  // YADCC_AMD_KERNELS_H_

@@ -70,7 +70,10 @@ struct ydc_context {
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
   DevBuf<uint32_t> d_running_out;
-  DevBuf<ClassState> d_guess[2], d_endst;
+  DevBuf<ClassState> d_guess[2], d_endst, d_checkpoint;
+  DevBuf<uint32_t> d_claim;
+  uint32_t pass_stamp = 0;  // unique id of every matching pass launched (claims)
+  uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
   DevBuf<ClassRun> d_runs;
   DevBuf<uint8_t> d_dirty;
   DevBuf<uint64_t> d_dbg;
@@ -337,6 +340,8 @@ int ydc_destroy(ydc_context* c) {
   c->d_guess[0].release();
   c->d_guess[1].release();
   c->d_endst.release();
+  c->d_checkpoint.release();
+  c->d_claim.release();
   c->d_runs.release();
   c->d_dirty.release();
   c->d_dbg.release();
@@ -524,6 +529,15 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   HIP_TRY(c, c->d_dirty.reserve((size_t)K + 1));
   HIP_TRY(c, c->d_guess[0].reserve((size_t)K * C + 1));
   HIP_TRY(c, c->d_endst.reserve((size_t)K * C + 1));
+  if (!use_generic) {
+    HIP_TRY(c, c->d_checkpoint.reserve((size_t)ceil_div(std::max(N, 1u), 64) * C + 1));
+    if ((size_t)K + 1 > c->d_claim.cap || c->pass_stamp > 0xFFFF0000u) {
+      // Claims compare against ever-growing pass stamps: a fresh (or wrapped) array starts at 0.
+      HIP_TRY(c, c->d_claim.reserve((size_t)K + 1));
+      HIP_TRY(c, hipMemsetAsync(c->d_claim.p, 0, c->d_claim.cap * 4, c->stream));
+      c->pass_stamp = 0;
+    }
+  }
   if (use_generic) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
   else if (any_shared) HIP_TRY(c, c->d_runs.reserve((size_t)C + 1));
 
@@ -627,84 +641,135 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
                          c->d_guess[0].p, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p,
                          c->d_runs.p, sh, 1u, 0u, prm);
     }
-    uint64_t* dbg = nullptr;
-    if (c->debug_sim) {
-      HIP_TRY(c, c->d_dbg.reserve((size_t)3 * K + 3));
-      HIP_TRY(c, hipMemsetAsync(c->d_dbg.p, 0, ((size_t)3 * K + 3) * 8, st));
-      dbg = c->d_dbg.p;
-    }
-    for (;;) {
-      for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
-        ClassState* gold = c->d_guess[0].p;
-        if (use_generic) {
+    if (use_generic) {
+      // > kMaxWaveClasses classes: thread-per-chunk kernel, host-checked rounds.
+      for (;;) {
+        for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
+          ClassState* gold = c->d_guess[0].p;
           YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(K, 64)), dim3(64), 0, st, L, T, N, cs, K,
                              gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
                              no_shared, 0u, rounds, prm);
-        } else if (W == 1) {
-          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<1, 64>), dim3(K), dim3(64), 64 * 1 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
-        } else if (W == 2) {
-          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<2, 32>), dim3(K), dim3(64), 32 * 2 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
-        } else {
-          YDC_LAUNCH(c, "k_sim_wave", (k_sim_wave<4, 16>), dim3(K), dim3(64), 16 * 4 * 64 * 8, st, L,
-                     T, N, cs, K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, rounds, prm, dbg);
+          YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(K * C, 256))), dim3(256), 0,
+                     st, C, K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
+          ++rounds;
         }
-        YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(K * C, 256))), dim3(256), 0,
-                   st, C, K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
-        ++rounds;
+        HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (c->h_prm->overflow)
+          return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", slot_bound);
+        if (c->h_prm->n_changed[(rounds - 1) & 63] == 0) break;
+        if (rounds > K + 4) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", rounds);
       }
+    }
+  }
+  const bool wave_path = N && C && !use_generic;
+  // ---- matching rounds + finalise. The rounds are pre-launched: a round returns at
+  // once when an earlier one already proved the fixpoint, k_finalize only runs when
+  // the last launched round did, and the host looks at the counters once.
+  MatchBuffers mb{};
+  uint32_t rshift = 4, init_fill = 8;
+  if (wave_path) {
+    mb.guess0 = c->d_guess[0].p;
+    mb.endst = c->d_endst.p;
+    mb.checkpoint = c->d_checkpoint.p;
+    mb.claim = c->d_claim.p;
+    mb.slot_of = c->d_slot_of.p;
+    mb.boundary_in = nullptr;
+    // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
+    // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
+    rshift = 3;
+    while (rshift < 10 && ((size_t)C << (rshift + 1)) <= 2048) ++rshift;
+    const uint32_t R = 1u << rshift;
+    uint32_t want = 2 * cs / std::max(C, 1u);
+    while (init_fill < want && init_fill < 64) init_fill <<= 1;
+    init_fill = std::min(std::max(init_fill, 32u), R);
+  }
+  auto launch_round = [&](uint32_t r, uint32_t device_check) {
+    const size_t lds = 16384;
+    const uint32_t stamp = ++c->pass_stamp;
+    if (W == 1) {
+      YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(K), dim3(64), lds, st, L, T, N, cs, K,
+                 mb, r, stamp, device_check, rshift, init_fill, prm);
+    } else if (W == 2) {
+      YDC_LAUNCH(c, "k_match_pass", (k_match_pass<2>), dim3(K), dim3(64), lds, st, L, T, N, cs, K,
+                 mb, r, stamp, device_check, rshift, init_fill, prm);
+    } else {
+      YDC_LAUNCH(c, "k_match_pass", (k_match_pass<4>), dim3(K), dim3(64), lds, st, L, T, N, cs, K,
+                 mb, r, stamp, device_check, rshift, init_fill, prm);
+    }
+  };
+  auto launch_finalize = [&](uint32_t check_slot) -> int {
+    if (S) HIP_TRY(c, hipMemcpyAsync(c->d_running_out.p, c->d_running.p, (size_t)S * 4,
+                                     hipMemcpyDeviceToDevice, st));
+    if (N) {
+      YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(ceil_div(N, 256)), dim3(256), 0, st, sv, c->d_slot_base.p,
+                         c->d_slot_of.p, N, d_out_idx, d_out_util, c->d_running_out.p, check_slot, prm);
+    }
+    // Not converged yet: k_finalize returned at once, running_out == running and the
+    // copies below change nothing; they are repeated after the extra rounds.
+    if ((flags & YDC_DISPATCH_COMMIT) && S)
+      HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
+                                hipMemcpyDeviceToDevice, st));
+    if (d_out_running && S)
+      HIP_TRY(c, hipMemcpyAsync(d_out_running, c->d_running_out.p, (size_t)S * 4,
+                                hipMemcpyDeviceToDevice, st));
+    return YDC_OK;
+  };
+  mark(c, 6);
+  if (wave_path) {
+    uint32_t launched = 0;
+    for (;;) {
+      const uint32_t group = launched == 0 ? std::max(2u, std::min(c->round_hint, 16u)) : 4u;
+      if (launched) {
+        // Counter slots of the rounds to come (the first group's were cleared by
+        // k_servant_scan). The stream is idle here: the host has just synchronised.
+        for (uint32_t r = launched; r < launched + group; ++r)
+          HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
+      }
+      for (uint32_t r = launched; r < launched + group; ++r) {
+        launch_round(r, 1u);
+      }
+      launched += group;
+      if (int rc = launch_finalize((launched - 1) & 63)) return rc;
+      mark(c, 7);
       HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, hipGetLastError());
       if (c->h_prm->overflow)
         return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", slot_bound);
-      if (c->h_prm->n_changed[(rounds - 1) & 1] == 0) break;
-      if (rounds > K + 4) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", rounds);
+      if (c->h_prm->need_shared) {  // the sequential path produced the result
+        rounds = 1;
+        break;
+      }
+      if (c->h_prm->n_changed[(launched - 1) & 63] == 0) {
+        // First round of this group that changed nothing.
+        rounds = launched;
+        for (uint32_t r = launched - group; r < launched; ++r)
+          if (c->h_prm->n_changed[r & 63] == 0) {
+            rounds = r + 1;
+            break;
+          }
+        c->round_hint = rounds;
+        if (c->debug_sim) {
+          fprintf(stderr, "[ydc match] K=%u cs=%u R=%u fill=%u rounds=%u sims=%u changed:", K, cs,
+                  1u << rshift, init_fill, rounds, c->h_prm->chunk_sims);
+          for (uint32_t r = 0; r < rounds; ++r) fprintf(stderr, " %u", c->h_prm->n_changed[r & 63]);
+          fprintf(stderr, "\n");
+        }
+        break;
+      }
+      if (launched > K + 4)
+        return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", launched);
     }
+  } else {
+    if (int rc = launch_finalize(kNone)) return rc;
+    mark(c, 7);
+    HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    if (c->h_prm->overflow)
+      return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", slot_bound);
   }
-  if (c->debug_sim && K && N && C) {
-    // Developer aid (YDC_DEBUG_SIM=1): per-chunk timing of the LAST simulation of each chunk.
-    std::vector<uint64_t> h((size_t)3 * K);
-    HIP_TRY(c, hipMemcpy(h.data(), c->d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
-    uint64_t t_min = ~0ull, t_max = 0, init_sum = 0, init_max = 0, loop_sum = 0, loop_max = 0;
-    uint32_t n = 0;
-    for (uint32_t k = 0; k < K; ++k) {
-      if (!h[3 * k]) continue;
-      ++n;
-      t_min = std::min(t_min, h[3 * k]);
-      t_max = std::max(t_max, h[3 * k] + h[3 * k + 1] + h[3 * k + 2]);
-      init_sum += h[3 * k + 1];
-      init_max = std::max(init_max, h[3 * k + 1]);
-      loop_sum += h[3 * k + 2];
-      loop_max = std::max(loop_max, h[3 * k + 2]);
-    }
-    if (n)
-      fprintf(stderr,
-              "[ydc sim] chunks=%u cs=%u rounds=%u: span %.1f us | init avg %.2f max %.2f us | "
-              "loop avg %.2f max %.2f us (%.1f ns/request avg)\n",
-              n, cs, rounds, (t_max - t_min) / 100.0, init_sum / 100.0 / n, init_max / 100.0,
-              loop_sum / 100.0 / n, loop_max / 100.0, loop_sum * 10.0 / n / cs);
-  }
-  mark(c, 6);
-  // ---- finalise
-  if (S) HIP_TRY(c, hipMemcpyAsync(c->d_running_out.p, c->d_running.p, (size_t)S * 4,
-                                   hipMemcpyDeviceToDevice, st));
-  if (N) {
-    YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(ceil_div(N, 256)), dim3(256), 0, st, sv, c->d_slot_base.p,
-                       c->d_slot_of.p, N, d_out_idx, d_out_util, c->d_running_out.p, prm);
-  }
-  if ((flags & YDC_DISPATCH_COMMIT) && S)
-    HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
-                              hipMemcpyDeviceToDevice, st));
-  if (d_out_running && S)
-    HIP_TRY(c, hipMemcpyAsync(d_out_running, c->d_running_out.p, (size_t)S * 4,
-                              hipMemcpyDeviceToDevice, st));
-  mark(c, 7);
-  HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
-  HIP_TRY(c, hipGetLastError());
-  if (c->h_prm->overflow)
-    return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", slot_bound);
 
   ydc_stats& s = c->stats;
   std::memset(&s, 0, sizeof(s));
