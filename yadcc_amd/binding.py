@@ -25,6 +25,12 @@ ABI_SYMBOLS = (
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
+    # host class wrapper (yadcc_amd/dispatcher.py types them)
+    "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
+    "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
+    "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
+    "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
+    "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
 )
 
 

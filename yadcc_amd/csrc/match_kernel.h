@@ -126,6 +126,33 @@ struct MatchWave {
       ring_g[at(cl, e)] = real ? L.list_g[e] : kNone;
     }
   }
+  // First fill: every lane loads `n` (<= R) entries of its own classes,
+  // 16 independent loads in flight per lane and array.
+  __device__ __forceinline__ void init_rings(uint32_t C, uint32_t n, int W_) {
+    for (int j = 0; j < W_; ++j) {
+      const uint32_t cl = lane + 64 * j;
+      LaneClass& q = k[j];
+      if (cl < C) {
+        for (uint32_t b0 = q.cursor; b0 < q.cursor + n; b0 += 16) {
+          uint32_t tp[16], tg[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const uint32_t e = b0 + u;
+            tp[u] = e < q.end ? list_rank(L, e) : kNone;
+            tg[u] = e < q.end ? L.list_g[e] : kNone;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            if (b0 + u < q.cursor + n) {  // n may be below 16 (tiny rings)
+              ring_p[at(cl, b0 + u)] = tp[u];
+              ring_g[at(cl, b0 + u)] = tg[u];
+            }
+          }
+        }
+        q.filled = q.cursor + n;
+      }
+    }
+  }
   // Entries the ring of this lane's class j still holds beyond the cursor; "plenty" once
   // the sentinels behind the end of the list are in.
   __device__ __forceinline__ uint32_t ring_left(int j) const {
@@ -154,106 +181,120 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 }
 
 
-// The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs
-// requests i, i+1, ... while each of them is "plain": no eligible class has holes, no
-// eligible class shows a slot of the requestor's own servant at its head, and the ring of
-// the class that wins is not running low. Returns
-//   0  all cnt requests done,
-//   1  request i needs the general step,
-//   2  request i-1 was served by lane `win`, whose ring must be topped up.
-// Requests whose eligible classes are all exhausted (or that have none) keep the
-// default result in `res`. Wait states (gfx940/gfx950): VALU-written SGPR -> VALU
-// read 2, VALU-written VGPR -> DPP read 2, VALU-written VGPR -> v_readlane 1; s[90:93]
-// are scratch (the 64-bit lane mask must be an aligned SGPR pair).
-__device__ __forceinline__ uint32_t match_fast_loop(
-    uint32_t& i, uint32_t cnt, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
-    uint64_t holes, uint64_t has_self, uint32_t& res, uint32_t& hp, uint32_t& hg, uint32_t& np,
-    uint32_t& ng, uint32_t& cur, uint32_t& left, uint32_t base, uint32_t rmask, uint32_t low,
-    uint32_t& win) {
-  uint32_t status, c, t, a, mn, tk, sl, s0, s1, m0save;
-  asm volatile(
-      "s_mov_b32 %[m0s], m0\n"
-      "s_mov_b32 %[st], 0\n"
-      "s_nop 3\n"
-      "L_loop%=:\n"
-      "s_cmp_ge_u32 %[i], %[cnt]\n"
-      "s_cbranch_scc1 L_out%=\n"
-      "v_readlane_b32 s90, %[mlo], %[i]\n"
-      "v_readlane_b32 s91, %[mhi], %[i]\n"
-      "s_and_b64 s[92:93], s[90:91], %[holes]\n"
-      "s_cbranch_scc1 L_slow%=\n"
-      "s_bitcmp1_b64 %[hs], %[i]\n"
-      "s_cbranch_scc1 L_self%=\n"
-      "L_cont%=:\n"
-      "v_cndmask_b32 %[c], -1, %[hp], s[90:91]\n"
-      "v_mov_b32 %[t], %[c]\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_min_u32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "s_nop 0\n"
-      "v_readlane_b32 %[mn], %[t], 63\n"
-      "s_cmp_eq_u32 %[mn], -1\n"
-      "s_cbranch_scc1 L_tmo%=\n"
-      "v_cmp_eq_u32 vcc, %[mn], %[c]\n"
-      "s_ff1_i32_b64 %[win], vcc\n"
-      "v_readlane_b32 %[tk], %[hg], %[win]\n"
-      "s_mov_b32 m0, %[i]\n"
-      "s_nop 0\n"
-      "v_writelane_b32 %[res], %[tk], m0\n"
-      "s_mov_b64 exec, vcc\n"
-      "v_add_u32 %[cur], 1, %[cur]\n"
-      "v_add_u32 %[a], 1, %[cur]\n"
-      "v_and_b32 %[a], %[rmask], %[a]\n"
-      "v_lshl_add_u32 %[a], %[a], 2, %[base]\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "v_mov_b32 %[hp], %[np]\n"
-      "v_mov_b32 %[hg], %[ng]\n"
-      "ds_read_b32 %[np], %[a]\n"
-      "ds_read_b32 %[ng], %[a] offset:8192\n"
-      "v_subrev_u32 %[left], 1, %[left]\n"
-      "s_mov_b64 exec, -1\n"
-      "s_add_u32 %[i], %[i], 1\n"
-      "v_readlane_b32 %[sl], %[left], %[win]\n"
-      "s_cmp_le_u32 %[sl], %[low]\n"
-      "s_cbranch_scc0 L_loop%=\n"
-      "s_mov_b32 %[st], 2\n"
-      "s_branch L_out%=\n"
-      "L_tmo%=:\n"
-      "s_bitcmp1_b64 %[hs], %[i]\n"
-      "s_cbranch_scc1 L_slow%=\n"
-      "s_add_u32 %[i], %[i], 1\n"
-      "s_branch L_loop%=\n"
-      "L_self%=:\n"
-      "v_readlane_b32 %[s0], %[slo], %[i]\n"
-      "v_readlane_b32 %[s1], %[shi], %[i]\n"
-      "s_sub_u32 %[s1], %[s1], %[s0]\n"
-      "v_subrev_u32 %[a], %[s0], %[hg]\n"
-      "v_cmp_gt_u32 vcc, %[s1], %[a]\n"
-      "s_and_b64 s[92:93], vcc, s[90:91]\n"
-      "s_cbranch_scc0 L_cont%=\n"
-      "L_slow%=:\n"
-      "s_mov_b32 %[st], 1\n"
-      "L_out%=:\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "s_mov_b32 m0, %[m0s]\n"
-      : [st] "=&s"(status), [i] "+s"(i), [res] "+v"(res), [hp] "+v"(hp), [hg] "+v"(hg),
-        [np] "+v"(np), [ng] "+v"(ng), [cur] "+v"(cur), [left] "+v"(left), [win] "+s"(win),
-        [c] "=&v"(c), [t] "=&v"(t), [a] "=&v"(a), [mn] "=&s"(mn), [tk] "=&s"(tk), [sl] "=&s"(sl),
-        [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
-      : [cnt] "s"(cnt), [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi),
-        [holes] "s"(holes), [hs] "s"(has_self), [base] "v"(base), [rmask] "s"(rmask), [low] "s"(low)
-      : "vcc", "scc", "memory", "s90", "s91", "s92", "s93");
-  return status;
-}
+// The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs up to
+// n requests i, i+1, ... while each of them is "plain": no eligible class has holes and no
+// eligible class shows a slot of the requestor's own servant at its head. Returns
+//   0  n requests done,
+//   1  request i needs the general step (i requests of this call were done).
+// Requests whose eligible classes are all exhausted (or that have none) keep the default
+// result in `res`. The caller guarantees that every ring holds at least n + 2 entries
+// beyond its cursor, so the loop never looks at fill levels.
+//
+// Per request: the class mask (an aligned SGPR pair, fetched one request ahead in the
+// wait states of the DPP chain) selects the eligible heads, a `steps`-step DPP min over the
+// first 2^steps lanes finds the winner, the winning lane alone (exec = the compare mask)
+// moves (next -> head), starts the LDS read of the entry after next and bumps its cursor;
+// the result is parked in the winner's lane and copied to lane i off the critical path.
+// Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR -> DPP
+// read 2, VALU-written VGPR -> v_readlane 1. s[90:95] are scratch.
+#define YDC_DPP(ctrl) "v_min_u32_dpp %[t], %[t], %[t] " ctrl "\n"
+// After step k: stop when k steps are enough (the compare + branch are the two wait states
+// the next DPP step needs anyway).
+#define YDC_DPP_STOP(k) "s_cmp_eq_u32 %[steps], " #k "\ns_cbranch_scc1 L_red%=\n"
+#define YDC_DPP_SEQ                                                            \
+  YDC_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(1)              \
+  YDC_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(2)              \
+  YDC_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(3)              \
+  YDC_DPP("row_shr:8 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(4)              \
+  YDC_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf") YDC_DPP_STOP(5)           \
+  YDC_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0\nL_red%=:\n"
+
+#define YDC_FAST_LOOP(NAME)                                                    \
+  __device__ __forceinline__ uint32_t NAME(                                                      \
+      uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,           \
+      uint64_t holes, uint64_t has_self, uint32_t& res, uint32_t& hp, uint32_t& hg,              \
+      uint32_t& np, uint32_t& ng, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4,    \
+      uint32_t steps, uint32_t last) {                                                          \
+    uint32_t status, c, t, a, tkv, mn, tk, win, i1, s0, s1, m0save;                             \
+    asm volatile(                                                                                \
+        "s_mov_b32 %[m0s], m0\n"                                                                 \
+        "s_mov_b32 %[st], 0\n"                                                                   \
+        "s_nop 3\n"                                                                              \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                 \
+        "s_cbranch_scc1 L_out%=\n"                                                               \
+        "v_readlane_b32 s90, %[mlo], %[i]\n"                                                     \
+        "v_readlane_b32 s91, %[mhi], %[i]\n"                                                     \
+        "s_add_u32 %[i1], %[i], 1\n"                                                             \
+        "L_loop%=:\n"                                                                            \
+        "s_and_b64 s[92:93], s[90:91], %[holes]\n"                                               \
+        "s_cbranch_scc1 L_slow%=\n"                                                              \
+        "s_bitcmp1_b64 %[hs], %[i]\n"                                                            \
+        "s_cbranch_scc1 L_self%=\n"                                                              \
+        "L_cont%=:\n"                                                                            \
+        "v_cndmask_b32 %[c], -1, %[hp], s[90:91]\n"                                              \
+        "v_mov_b32 %[t], %[c]\n"                                                                 \
+        "v_readlane_b32 s94, %[mlo], %[i1]\n"                                                    \
+        "v_readlane_b32 s95, %[mhi], %[i1]\n" YDC_DPP_SEQ                                        \
+        "v_readlane_b32 %[mn], %[t], %[last]\n"                                                  \
+        "s_cmp_eq_u32 %[mn], -1\n"                                                               \
+        "s_cbranch_scc1 L_tmo%=\n"                                                               \
+        "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                        \
+        "s_mov_b64 exec, vcc\n"                                                                  \
+        "v_mov_b32 %[tkv], %[hg]\n"                                                              \
+        "s_waitcnt lgkmcnt(0)\n"                                                                 \
+        "v_mov_b32 %[hp], %[np]\n"                                                               \
+        "v_mov_b32 %[hg], %[ng]\n"                                                               \
+        "v_add_u32 %[off], 4, %[off]\n"                                                          \
+        "v_and_b32 %[off], %[rmask4], %[off]\n"                                                  \
+        "v_add_u32 %[a], %[base], %[off]\n"                                                      \
+        "ds_read_b32 %[np], %[a]\n"                                                              \
+        "ds_read_b32 %[ng], %[a] offset:8192\n"                                                  \
+        "v_add_u32 %[cur], 1, %[cur]\n"                                                          \
+        "s_mov_b64 exec, -1\n"                                                                   \
+        "s_ff1_i32_b64 %[win], vcc\n"                                                            \
+        "s_mov_b32 m0, %[i]\n"                                                                   \
+        "v_readlane_b32 %[tk], %[tkv], %[win]\n"                                                 \
+        "s_mov_b64 s[90:91], s[94:95]\n"                                                         \
+        "s_nop 0\n"                                                                              \
+        "v_writelane_b32 %[res], %[tk], m0\n"                                                    \
+        "L_next%=:\n"                                                                            \
+        "s_add_u32 %[i], %[i], 1\n"                                                              \
+        "s_add_u32 %[i1], %[i1], 1\n"                                                            \
+        "s_add_u32 %[n], %[n], -1\n"                                                             \
+        "s_cmp_lg_u32 %[n], 0\n"                                                                 \
+        "s_cbranch_scc1 L_loop%=\n"                                                              \
+        "s_branch L_out%=\n"                                                                     \
+        "L_tmo%=:\n"                                                                             \
+        "s_bitcmp1_b64 %[hs], %[i]\n"                                                            \
+        "s_cbranch_scc1 L_slow%=\n"                                                              \
+        "s_mov_b64 s[90:91], s[94:95]\n"                                                         \
+        "s_branch L_next%=\n"                                                                    \
+        "L_self%=:\n"                                                                            \
+        "v_readlane_b32 %[s0], %[slo], %[i]\n"                                                   \
+        "v_readlane_b32 %[s1], %[shi], %[i]\n"                                                   \
+        "s_sub_u32 %[s1], %[s1], %[s0]\n"                                                        \
+        "v_subrev_u32 %[a], %[s0], %[hg]\n"                                                      \
+        "v_cmp_gt_u32 vcc, %[s1], %[a]\n"                                                        \
+        "s_and_b64 s[92:93], vcc, s[90:91]\n"                                                    \
+        "s_cbranch_scc0 L_cont%=\n"                                                              \
+        "L_slow%=:\n"                                                                            \
+        "s_mov_b32 %[st], 1\n"                                                                   \
+        "L_out%=:\n"                                                                             \
+        "s_waitcnt lgkmcnt(0)\n"                                                                 \
+        "s_mov_b32 m0, %[m0s]\n"                                                                 \
+        : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hp] "+v"(hp),          \
+          [hg] "+v"(hg), [np] "+v"(np), [ng] "+v"(ng), [cur] "+v"(cur), [off] "+v"(off),         \
+          [c] "=&v"(c), [t] "=&v"(t), [a] "=&v"(a), [tkv] "=&v"(tkv), [mn] "=&s"(mn),            \
+          [tk] "=&s"(tk), [win] "=&s"(win), [i1] "=&s"(i1), [s0] "=&s"(s0), [s1] "=&s"(s1),      \
+          [m0s] "=&s"(m0save)                                                                    \
+        : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [holes] "s"(holes),    \
+          [hs] "s"(has_self), [base] "v"(base), [rmask4] "s"(rmask4), [steps] "s"(steps),        \
+          [last] "s"(last)                                                                       \
+        : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95");                     \
+    return status;                                                                               \
+  }
+
+YDC_FAST_LOOP(match_fast_loop)
 
 template <int W>
 __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
@@ -275,9 +316,10 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   // addresses the second array with an immediate offset). C << rshift <= 2048.
   MatchWave<W> w{L, lds_ring, lds_ring + 2048, (1u << rshift) - 1, rshift, lane, {}};
   const uint32_t R = 1u << rshift;
-  // A class is topped up when fewer than low_water (>= 3) entries are left in its
-  // ring, so the entry after next is always there when a lane advances.
-  const uint32_t low_water = R / 4 < 3 ? 3 : (R / 4 > 16 ? 16 : R / 4);
+  // A ring is topped up when no more than `thresh` entries are left in it.
+  const uint32_t thresh = R / 4 < 4 ? 4 : (R / 4 > 12 ? 12 : R / 4);
+  uint32_t steps = 1;  // DPP steps of the min over the class lanes
+  while ((1u << steps) < C) ++steps;
 
   // ---- start state; is there anything to do? ----
   {
@@ -317,10 +359,70 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 
   bool ring_ready = false;
   uint64_t holes[W] = {};
+
+  // Tops up the ring of class j of lane `cc`: one coalesced load of up to 64 entries.
+  auto refill = [&](uint32_t cc, int bj) {
+    uint32_t f_cl = 0, f_from = 0, f_to = 0, f_end = 0;
+    if (lane == cc) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if (j == bj) {
+          LaneClass& q = w.k[j];
+          if (q.filled < q.cursor) q.filled = q.cursor;
+          f_cl = lane + 64 * j;
+          f_from = q.filled;
+          f_to = min(q.filled + 64u, q.cursor + R);
+          f_end = q.end;
+          q.filled = f_to;
+        }
+      }
+    }
+    w.fill(readlane_u32(f_cl, cc), readlane_u32(f_from, cc), readlane_u32(f_to, cc),
+           readlane_u32(f_end, cc));
+  };
+  // Refills every ring that is running low; returns how many picks are safe before the
+  // next look (every ring keeps the entry after next).
+  auto top_up = [&]() -> uint32_t {
+    uint32_t least = 0x7FFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const bool real = lane + 64 * j < C;
+      uint64_t need = __ballot(real && w.ring_left(j) <= thresh);
+      while (need) {
+        refill((uint32_t)__builtin_ctzll(need), j);
+        need &= need - 1;
+      }
+      least = min(least, real ? w.ring_left(j) : 0x7FFFFFFFu);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return wave_min_u32(least) - 2;
+  };
+
   for (;;) {  // chunk kc, then the chunks after it while the end states keep changing
     const uint32_t t0 = kc * chunk_size;
     const uint32_t t1 = min(n_tasks, t0 + chunk_size);
     bool stopped_early = false;
+
+    // Requests of a block are staged one block ahead: lane l holds request tb + l.
+    uint64_t nx_m[W];
+    uint32_t nx_slo, nx_shi;
+    ClassState nx_cp[W];
+    auto stage = [&](uint32_t tb) {
+      const uint32_t tl = tb + lane;
+      nx_slo = nx_shi = kNone;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        nx_m[j] = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
+        const uint32_t c = lane + 64 * j;
+        if (pass != 0 && tb < t1 && c < C) nx_cp[j] = B.checkpoint[(size_t)(tb >> 6) * C + c];
+      }
+      if (tl < t1) {
+        nx_slo = T.self_lo[tl];
+        nx_shi = T.self_hi[tl];
+      }
+    };
+    stage(t0);
+
     for (uint32_t tb = t0; tb < t1; tb += 64) {
       // ---- checkpoint: stop if the previous replay was in the same state here ----
       {
@@ -333,12 +435,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             const ClassState s = w.state(j);
             if (pass == 0) {
               cp[c] = s;
-            } else {
-              const ClassState old = cp[c];
-              if (!class_state_equal(old, s)) {
-                differs = true;
-                cp[c] = s;
-              }
+            } else if (!class_state_equal(nx_cp[j], s)) {
+              differs = true;
+              cp[c] = s;
             }
           }
         }
@@ -347,43 +446,31 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           break;
         }
       }
-      if (!ring_ready) {
-        // First block that really runs: fill the rings (init_fill entries per class,
-        // one coalesced load per class and array, all in flight together).
+      // ---- this block's requests; start fetching the next block's ----
+      uint32_t mlo[W], mhi[W];
+      uint64_t many = 0;
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const uint32_t nc = C > 64u * j ? min(64u, C - 64u * j) : 0u;
-          for (uint32_t cc = 0; cc < nc; ++cc) {
-            const uint32_t from = readlane_u32(w.k[j].cursor, cc);
-            const uint32_t to = from + init_fill;
-            w.fill(cc + 64 * j, from, to, readlane_u32(w.k[j].end, cc));
-            if (lane == cc) w.k[j].filled = to;
-          }
-        }
+      for (int j = 0; j < W; ++j) {
+        mlo[j] = (uint32_t)nx_m[j];
+        mhi[j] = (uint32_t)(nx_m[j] >> 32);
+        many |= nx_m[j];
+      }
+      const uint32_t slo = nx_slo, shi = nx_shi;
+      const uint32_t tl = tb + lane;
+      stage(tb + 64);
+
+      if (!ring_ready) {
+        // First block that really runs: fill the rings.
+        w.init_rings(C, init_fill, W);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          w.load_heads(j);
+          if (lane + 64 * j < C) w.load_heads(j);
           holes[j] = __ballot(w.k[j].lo < w.k[j].cursor);
         }
         ring_ready = true;
       }
 
-      // ---- stage the block's requests: lane l holds request tb + l ----
-      uint32_t mlo[W], mhi[W], slo = kNone, shi = kNone;
-      const uint32_t tl = tb + lane;
-      uint64_t many = 0;
-#pragma unroll
-      for (int j = 0; j < W; ++j) {
-        uint64_t m = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
-        mlo[j] = (uint32_t)m;
-        mhi[j] = (uint32_t)(m >> 32);
-        many |= m;
-      }
-      if (tl < t1) {
-        slo = T.self_lo[tl];
-        shi = T.self_hi[tl];
-      }
       const uint64_t has_self = __ballot(slo != kNone);
       uint32_t res = kIdxTimeout;
       const uint32_t cnt = min(64u, t1 - tb);
@@ -439,35 +526,24 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         const uint32_t taken = readlane_u32(bg, win);
         res = lane == i ? taken : res;
         bool moved = false;
-        uint32_t m_cl = 0, m_from = 0, m_to = 0, m_end = 0;
         if (lane == win) {
 #pragma unroll
           for (int j = 0; j < W; ++j) {
             if (j == bj) {
               ClassRun r = w.as_run(j);
-              const bool cursor_moved = class_consume_state(L, r, bi, self_lo, self_hi);
+              moved = class_consume_state(L, r, bi, self_lo, self_hi);
               LaneClass& q = w.k[j];
               q.cursor = r.cursor;
               q.lo = r.lo;
               q.hown_lo = r.hown_lo;
               q.hown_hi = r.hown_hi;
-              if (cursor_moved) {
-                // Entries [cursor, filled) are still in the ring unless the cursor jumped
-                // past them; top the ring up either way.
-                if (q.filled < q.cursor) q.filled = q.cursor;
-                moved = true;
-                m_cl = lane + 64 * j;
-                m_from = q.filled;
-                m_to = min(q.filled + 64u, q.cursor + R);
-                m_end = q.end;
-                q.filled = m_to;
-              }
             }
           }
         }
         if (__ballot(moved)) {
-          w.fill(readlane_u32(m_cl, win), readlane_u32(m_from, win), readlane_u32(m_to, win),
-                 readlane_u32(m_end, win));
+          // The cursor moved (possibly past what the ring held): top the ring up at the
+          // new cursor and reload (head, next).
+          refill(win, (int)readlane_u32((uint32_t)bj, win));
           __builtin_amdgcn_wave_barrier();
           if (lane == win) {
 #pragma unroll
@@ -478,49 +554,30 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 #pragma unroll
         for (int j = 0; j < W; ++j) holes[j] = __ballot(w.k[j].lo < w.k[j].cursor);
       };
-      // Tops up the ring of class j of lane `win` (which has just picked from it).
-      auto refill = [&](uint32_t win, int bj) {
-        uint32_t f_cl = 0, f_from = 0, f_to = 0, f_end = 0;
-        if (lane == win) {
-#pragma unroll
-          for (int j = 0; j < W; ++j) {
-            if (j == bj) {
-              LaneClass& q = w.k[j];
-              f_cl = lane + 64 * j;
-              f_from = q.filled;
-              f_to = min(q.filled + 64u, q.cursor + R);
-              f_end = q.end;
-              q.filled = f_to;
-            }
-          }
-        }
-        w.fill(readlane_u32(f_cl, win), readlane_u32(f_from, win), readlane_u32(f_to, win),
-               readlane_u32(f_end, win));
-        __builtin_amdgcn_wave_barrier();
-      };
 
       if constexpr (W == 1) {
         LaneClass& q = w.k[0];
         const uint32_t base = (uint32_t)(uintptr_t)lds_ring + ((lane << rshift) << 2);
-        uint32_t i = 0, win = 0;
-        for (;;) {
-          uint32_t left = w.ring_left(0);
-          const uint32_t st =
-              match_fast_loop(i, cnt, mlo[0], mhi[0], slo, shi, holes[0], has_self, res, q.head_p,
-                              q.head_g, q.next_p, q.next_g, q.cursor, left, base, w.rmask,
-                              low_water, win);
+        const uint32_t rmask4 = (R << 2) - 1;
+        uint32_t i = 0;
+        while (i < cnt) {
+          const uint32_t budget = top_up();
+          const uint32_t n = min(cnt - i, budget);
+          const uint32_t off = ((q.cursor + 1) & w.rmask) << 2;  // ring offset of `next`
+          const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, holes[0], has_self, res,
+                                              q.head_p, q.head_g, q.next_p, q.next_g, q.cursor, off,
+                                              base, rmask4, steps, (1u << steps) - 1);
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
-          if (st == 0) break;
-          if (st == 2) {
-            refill(win, 0);
-          } else {
+          if (st == 1) {
             general_step(i);
             ++i;
           }
         }
       } else {
+        uint32_t budget = 0;
         for (uint32_t i = 0; i < cnt; ++i) {
+          if (budget == 0) budget = top_up();
           uint64_t mw[W];
           bool general = false;
           uint64_t many_i = 0;
@@ -559,7 +616,6 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
               const uint32_t win = (uint32_t)__builtin_ctzll(__ballot(bp == mn));
               const uint32_t taken = readlane_u32(bg, win);
               res = lane == i ? taken : res;
-              uint32_t left = kNone;
               if (lane == win) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
@@ -572,11 +628,10 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
                     q.head_g = q.next_g;
                     q.next_p = w.ring_p[w.at(lane + 64 * j, cur + 1)];
                     q.next_g = w.ring_g[w.at(lane + 64 * j, cur + 1)];
-                    left = w.ring_left(j);
                   }
                 }
               }
-              if (readlane_u32(left, win) <= low_water) refill(win, (int)readlane_u32((uint32_t)bj, win));
+              --budget;
               continue;
             }
             // Every eligible class is exhausted: Timeout (task_dispatcher.cc:116-118 with
@@ -584,6 +639,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             if (!self) continue;
           }
           general_step(i);
+          budget = 0;
         }
       }
       // No eligible class at all: EnvironmentNotFound (task_dispatcher.cc:105-108).
