@@ -147,6 +147,22 @@ int ydc_dispatch_device(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t 
                         uint32_t flags, uint32_t* d_out_servant_idx, double* d_out_utilization,
                         uint32_t* d_out_running);
 
+/* ---- streaming mode (BASELINE.json configs[4]) -------------------------------
+ * One tick applies, in this order: n_upd heartbeats of known servants
+ * (KeepServantAlive: personality replaced, running_tasks kept, task_dispatcher.cc:195-201),
+ * n_rel released grants (FreeTask's --running_tasks, :181) and n_tasks requests that are
+ * dispatched and committed (n x WaitForStartingNewTask with timeout == now). The whole
+ * step is captured into a hipGraph once and replayed per tick; counts may vary up to the
+ * capacities given here. Host buffers in, host results out, synchronous.
+ * Heartbeats that add a servant or change its environments / version / host / capacity
+ * bound are applied eagerly (ydc_update_servants) and the step is captured again. */
+int ydc_stream_begin(ydc_context* ctx, uint32_t max_updates, uint32_t max_releases,
+                     uint32_t max_tasks);
+int ydc_stream_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                    uint32_t n_upd, const uint32_t* release_servant_idx, uint32_t n_rel,
+                    const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx);
+int ydc_stream_end(ydc_context* ctx);
+
 int ydc_synchronize(ydc_context* ctx);
 int ydc_set_profiling(ydc_context* ctx, int on);
 int ydc_get_stats(const ydc_context* ctx, ydc_stats* out);

@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
+    "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_end",
     # host class wrapper (yadcc_amd/dispatcher.py types them)
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
@@ -38,6 +39,11 @@ class ServantSoA(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("version", "num_processors", "current_load",
                                            "max_tasks", "running_tasks", "flags", "env_mask",
                                            "ip_id")]
+
+
+# numpy view of ydc_servant_row (32 bytes)
+ROW_DTYPE = np.dtype([("version", "<u4"), ("num_processors", "<u4"), ("current_load", "<u4"),
+                      ("max_tasks", "<u4"), ("flags", "<u4"), ("ip_id", "<u4"), ("env_mask", "<u8")])
 
 
 class ServantRow(C.Structure):
@@ -95,6 +101,10 @@ def lib():
                                    C.c_void_p, C.c_void_p, C.c_void_p]
         L.ydc_dispatch_device.argtypes = L.ydc_dispatch.argtypes
         L.ydc_synchronize.argtypes = [C.c_void_p]
+        L.ydc_stream_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ydc_stream_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                      C.c_uint32, C.POINTER(TaskSoA), C.c_uint32, C.c_void_p]
+        L.ydc_stream_end.argtypes = [C.c_void_p]
         L.ydc_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.ydc_kernel_profile.argtypes = [C.c_void_p]
@@ -261,6 +271,31 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ydc_synchronize(self._h), "ydc_synchronize")
+
+    # -- streaming mode: one captured step per tick ---------------------------------
+    def stream_begin(self, max_updates, max_releases, max_tasks):
+        self._check(lib().ydc_stream_begin(self._h, max_updates, max_releases, max_tasks),
+                    "ydc_stream_begin")
+
+    def stream_tick(self, upd_idx, upd_rows, release_idx, tasks):
+        """upd_rows: numpy structured array of ROW_DTYPE (one heartbeat per entry of upd_idx);
+        release_idx: servant index of every freed grant; tasks: dict of request columns.
+        Returns the servant index (or IDX_*) of every request."""
+        ui = np.ascontiguousarray(upd_idx, dtype=np.uint32)
+        ur = np.ascontiguousarray(upd_rows, dtype=ROW_DTYPE)
+        rel = np.ascontiguousarray(release_idx, dtype=np.uint32)
+        keep = [np.ascontiguousarray(tasks[k], dtype=np.uint32)
+                for k in ("env_id", "min_version", "requestor_ip")]
+        n = len(keep[0])
+        soa = TaskSoA(*[a.ctypes.data for a in keep])
+        out = np.empty(n, np.uint32)
+        self._check(lib().ydc_stream_tick(self._h, ui.ctypes.data, ur.ctypes.data, len(ui),
+                                          rel.ctypes.data, len(rel), C.byref(soa), n,
+                                          out.ctypes.data), "ydc_stream_tick")
+        return out
+
+    def stream_end(self):
+        self._check(lib().ydc_stream_end(self._h), "ydc_stream_end")
 
     def set_profiling(self, on):
         self._check(lib().ydc_set_profiling(self._h, int(on)), "ydc_set_profiling")

@@ -39,6 +39,7 @@ struct DeviceParams {
   uint32_t n_changed[64]; // end states changed in round r, at index r & 63 (match_kernel.h)
   uint32_t chunk_sims;    // chunk simulations executed (all rounds)
   uint32_t granted, timeouts, env_not_found;
+  uint32_t batch_seq;     // batches this context has started (never reset)
 };
 
 struct ServantTable {
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     for (int r = 0; r < 64; ++r) prm->n_changed[r] = 0;
     prm->chunk_sims = 0;
     prm->granted = prm->timeouts = prm->env_not_found = 0;
+    prm->batch_seq += 1;
     uint32_t acc = 0;
     for (uint32_t c = 0; c < n_classes; ++c) {
       cls_begin[c] = acc;
@@ -514,6 +516,29 @@ __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_i
                                                        uint32_t n_servants, uint32_t* running) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && servant_idx[i] < n_servants) atomicSub(&running[servant_idx[i]], 1u);
+}
+
+// Heartbeats of known servants (KeepServantAlive replaces the personality and keeps
+// running_tasks, task_dispatcher.cc:195-201): thread per update; idx >= n_servants is padding.
+struct ServantRowDev {  // == ydc_servant_row (include/yadcc_dispatch.h)
+  uint32_t version, num_processors, current_load, max_tasks, flags, ip_id;
+  uint64_t env_mask;
+};
+__global__ __launch_bounds__(256) void k_apply_rows(const uint32_t* idx, const ServantRowDev* rows,
+                                                    uint32_t n, uint32_t n_servants,
+                                                    uint32_t* version, uint32_t* nproc,
+                                                    uint32_t* load, uint32_t* max_tasks,
+                                                    uint32_t* flags) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = idx[i];
+  if (s >= n_servants) return;
+  const ServantRowDev r = rows[i];
+  version[s] = r.version;
+  nproc[s] = r.num_processors;
+  load[s] = r.current_load;
+  max_tasks[s] = r.max_tasks;
+  flags[s] = r.flags;
 }
 
 }  // namespace ydc

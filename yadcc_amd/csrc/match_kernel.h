@@ -47,7 +47,7 @@ struct MatchBuffers {
   const ClassState* guess0;  // [K * C] level guesses (start states of pass 0)
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
-  uint32_t* claim;           // [K] stamp of the pass in which a wave took the chunk
+  unsigned long long* claim; // [K] (batch, pass) stamp of the pass in which a wave took the chunk
   uint32_t* slot_of;         // [N] generation index of the slot each request takes
   // Multi-GPU: this rank's chunks continue the previous rank's. boundary_in (C
   // entries, or NULL) is the end state of the predecessor's last chunk.
@@ -299,7 +299,7 @@ YDC_FAST_LOOP(match_fast_loop)
 template <int W>
 __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
-                                                   MatchBuffers B, uint32_t pass, uint32_t stamp,
+                                                   MatchBuffers B, uint32_t pass,
                                                    uint32_t device_check, uint32_t rshift,
                                                    uint32_t init_fill, DeviceParams* prm) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
@@ -311,6 +311,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   if (kc >= n_chunks) return;
   const uint32_t C = L.n_classes;
   const bool multi = B.boundary_in != nullptr;
+  // Unique per pass launch and ever growing (the batch counter lives on the device, so a
+  // replayed graph gets fresh stamps too).
+  const unsigned long long stamp = ((unsigned long long)prm->batch_seq << 16) | (pass + 1);
 
   // Fixed layout: ranks in the first 8 KB, generation indexes 8 KB further (the asm loop
   // addresses the second array with an immediate offset). C << rshift <= 2048.
@@ -348,12 +351,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     if (pass != 0) {
       if (__ballot(differs) == 0) return;  // consistent
       // Inconsistent: this pass has work. One wave per chunk and pass.
-      uint32_t old = 0;
+      uint32_t taken = 0;
       if (lane == 0) {
         atomicAdd(&prm->n_changed[pass & (kPassSlots - 1)], 1u);
-        old = atomicMax(&B.claim[kc], stamp);
+        taken = atomicMax(&B.claim[kc], stamp) == stamp;
       }
-      if (readlane_u32(old, 0) == stamp) return;  // a wave following its chain got here first
+      if (readlane_u32(taken, 0)) return;  // a wave following its chain got here first
     }
   }
 
@@ -674,9 +677,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     // another follower) has it in this pass; then the next pass picks it up.
     if (kc + 1 >= n_chunks) return;
     ++kc;
-    uint32_t old = 0;
-    if (lane == 0) old = atomicMax(&B.claim[kc], stamp);
-    if (readlane_u32(old, 0) == stamp) return;
+    uint32_t taken = 0;
+    if (lane == 0) taken = atomicMax(&B.claim[kc], stamp) == stamp;
+    if (readlane_u32(taken, 0)) return;
   }
 }
 
