@@ -163,6 +163,30 @@ int ydc_stream_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant
                     const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx);
 int ydc_stream_end(ydc_context* ctx);
 
+/* ---- multi-GPU group: one batch sharded by rank range (BASELINE.json configs[3]) ------
+ * One process per GPU; every rank creates its context and uploads the SAME servant table.
+ * Rank 0 gets a 128-byte id (ncclGetUniqueId), the launcher hands it to every rank (any
+ * side channel), every rank calls ydc_group_init — collective, like ncclCommInitRank.
+ * librccl.so.1 is resolved with dlopen here, so single-GPU use has no RCCL dependency. */
+#define YDC_GROUP_ID_BYTES 128
+int ydc_group_unique_id(void* out_id128);
+int ydc_group_init(ydc_context* ctx, const void* id128, int rank, int n_ranks);
+/* Several contexts of ONE process on ONE device as the ranks of a group, exchanging through
+ * device copies instead of RCCL (each rank's calls must come from its own thread): how the
+ * sharding protocol is exercised on a single-GPU machine. */
+int ydc_group_init_local(ydc_context** ctxs, int n);
+int ydc_group_destroy(ydc_context* ctx);
+/* Collective. The global batch is the concatenation, in rank order, of the slices the ranks
+ * pass in (device pointers; a slice may be empty); placement is identical to
+ * ydc_dispatch_device of the whole batch on one GPU. d_out_servant_idx / d_out_utilization
+ * cover the rank's own slice, d_out_running (nullable, n_servants entries) is the global
+ * running_tasks after the batch, identical on all ranks; YDC_DISPATCH_COMMIT applies it.
+ * Exchanges: all-gathers of 4 B, (n_classes + 1) * 16 B per matching pass, n_servants * 4 B
+ * (the per-rank servant-slot deltas) per rank. */
+int ydc_dispatch_sharded(ydc_context* ctx, const ydc_task_soa* d_tasks_slice, uint32_t n_slice,
+                         uint32_t flags, uint32_t* d_out_servant_idx, double* d_out_utilization,
+                         uint32_t* d_out_running);
+
 int ydc_synchronize(ydc_context* ctx);
 int ydc_set_profiling(ydc_context* ctx, int on);
 int ydc_get_stats(const ydc_context* ctx, ydc_stats* out);

@@ -1,0 +1,132 @@
+"""Multi-GPU sharding protocol on the single GPU of the test box.
+
+(1) ydc_group_init + ydc_dispatch_sharded over RCCL with a 1-rank communicator (the library
+    loads librccl, creates the communicator, runs the three all-gathers).
+(2) The real protocol with 2, 3 and 5 ranks: several contexts on device 0 as the ranks,
+    exchanging through the single-process transport (ydc_group_init_local), each rank driven
+    by its own thread. The concatenation of the ranks' results must equal the placement of the
+    whole batch by the oracle, and every rank must end with the same running_tasks."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oraclebind as O
+from tests import cases
+from yadcc_amd import binding, pack, synth
+
+pytestmark = pytest.mark.gpu
+DA = binding.DeviceArray
+
+
+def sharded_run(ctxs, sv, tk, cuts, commit=False):
+    """cuts: slice boundaries [0, ..., N]. Returns (per-rank idx, per-rank util, per-rank running)."""
+    G = len(ctxs)
+    res = [None] * G
+    errs = []
+
+    def worker(r):
+        try:
+            c = ctxs[r]
+            lo, hi = cuts[r], cuts[r + 1]
+            d = [DA.from_numpy(tk[k][lo:hi]) for k in ("env_id", "min_version", "requestor_ip")]
+            out = DA(hi - lo, np.uint32)
+            util = DA(hi - lo, np.float64)
+            run = DA(len(sv["version"]), np.uint32)
+            c.dispatch_sharded(d[0], d[1], d[2], out, util, run, commit=commit)
+            res[r] = (out.numpy(), util.numpy(), run.numpy(), c.stats())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    [t.start() for t in ths]
+    [t.join(120) for t in ths]
+    assert not errs, errs
+    assert all(x is not None for x in res), "a rank did not finish"
+    return res
+
+
+def make_group(G, sv):
+    ctxs = [binding.Context(device=0) for _ in range(G)]
+    cols = pack.to_abi_columns(sv)
+    for c in ctxs:
+        c.upload_servants(cols)
+    binding.group_init_local(ctxs)
+    return ctxs
+
+
+def check_against_oracle(res, sv, tk, method="sorted"):
+    want, wutil, wrun = O.dispatch(sv, tk, method)
+    got = np.concatenate([r[0] for r in res])
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at request %d (gpu %d oracle %d), %d total" % (
+        bad[0], got[bad[0]], want[bad[0]], bad.size)
+    assert np.array_equal(np.concatenate([r[1] for r in res]), wutil)
+    for r in res:
+        assert np.array_equal(r[2], wrun)
+    assert sum(r[3]["granted"] for r in res) == int((want < O.IDX_ENV_NOT_FOUND).sum())
+
+
+def test_rccl_single_rank_group():
+    sv, tk = cases.random_case(seed=41, n_tasks=30_000, n_servants=700, n_envs=3, self_frac=0.1,
+                               unknown_env_frac=0.001)
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.group_init(binding.group_unique_id(), 0, 1)
+    res = sharded_run([ctx], sv, tk, [0, len(tk["env_id"])])
+    check_against_oracle(res, sv, tk)
+    ctx.group_destroy()
+    ctx.close()
+
+
+@pytest.mark.parametrize("G", [2, 3, 5])
+def test_local_ranks_match_oracle(G):
+    sv, tk = cases.random_case(seed=50 + G, n_tasks=60_000, n_servants=1200, n_envs=4,
+                               self_frac=0.15, unknown_env_frac=0.002)
+    n = len(tk["env_id"])
+    ctxs = make_group(G, sv)
+    cuts = [0] + sorted(np.random.default_rng(G).integers(0, n, G - 1).tolist()) + [n]
+    res = sharded_run(ctxs, sv, tk, cuts)
+    check_against_oracle(res, sv, tk)
+    assert max(r[3]["rounds"] for r in res) == min(r[3]["rounds"] for r in res)  # lockstep
+    [c.close() for c in ctxs]
+
+
+def test_local_ranks_empty_slices_and_oversubscription():
+    """Ranks without requests pass their predecessor's state on; the tail times out."""
+    sv, tk = cases.random_case(seed=61, n_tasks=40_000, n_servants=300, n_envs=2,
+                               oversubscribed=True)
+    n = len(tk["env_id"])
+    ctxs = make_group(4, sv)
+    res = sharded_run(ctxs, sv, tk, [0, 0, n // 3, n // 3, n])  # ranks 0 and 2 are empty
+    check_against_oracle(res, sv, tk)
+    assert (np.concatenate([r[0] for r in res]) == binding.IDX_TIMEOUT).sum() > 1000
+    [c.close() for c in ctxs]
+
+
+def test_local_ranks_commit_two_batches():
+    """COMMIT applies the global deltas on every rank: two sharded batches == one big batch."""
+    sv, tk = cases.random_case(seed=62, n_tasks=50_000, n_servants=900, n_envs=3, self_frac=0.1)
+    half = 25_000
+    a = {k: v[:half] for k, v in tk.items()}
+    b = {k: v[half:] for k, v in tk.items()}
+    ctxs = make_group(2, sv)
+    r1 = sharded_run(ctxs, sv, a, [0, 10_000, half], commit=True)
+    r2 = sharded_run(ctxs, sv, b, [0, 20_000, half], commit=True)
+    want, _, wrun = O.dispatch(sv, tk, "sorted")
+    got = np.concatenate([r[0] for r in r1] + [r[0] for r in r2])
+    assert np.array_equal(got, want)
+    for c in ctxs:
+        assert np.array_equal(c.get_running(), wrun)
+    [c.close() for c in ctxs]
+
+
+def test_cfg4_shape_eight_ranks():
+    """BASELINE.json configs[3] scaled to the test box: 8 ranks, 4 digests, 400k x 16k."""
+    sv, tk = synth.make_config("cfg4", n_tasks=400_000)
+    n = len(tk["env_id"])
+    ctxs = make_group(8, sv)
+    cuts = [n * r // 8 for r in range(9)]
+    res = sharded_run(ctxs, sv, tk, cuts)
+    check_against_oracle(res, sv, tk)
+    [c.close() for c in ctxs]

@@ -26,6 +26,8 @@ ABI_SYMBOLS = (
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
     "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_end",
+    "ydc_group_unique_id", "ydc_group_init", "ydc_group_init_local", "ydc_group_destroy",
+    "ydc_dispatch_sharded",
     # host class wrapper (yadcc_amd/dispatcher.py types them)
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
@@ -105,6 +107,11 @@ def lib():
         L.ydc_stream_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                       C.c_uint32, C.POINTER(TaskSoA), C.c_uint32, C.c_void_p]
         L.ydc_stream_end.argtypes = [C.c_void_p]
+        L.ydc_group_unique_id.argtypes = [C.c_void_p]
+        L.ydc_group_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ydc_group_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.ydc_group_destroy.argtypes = [C.c_void_p]
+        L.ydc_dispatch_sharded.argtypes = L.ydc_dispatch.argtypes
         L.ydc_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.ydc_kernel_profile.argtypes = [C.c_void_p]
@@ -136,6 +143,25 @@ def device_count():
         return int(lib().ydc_device_count())
     except (YdcError, OSError):
         return 0
+
+
+def group_unique_id():
+    """128-byte id for Context.group_init (ncclGetUniqueId); call on one rank, hand to all."""
+    buf = C.create_string_buffer(128)
+    rc = lib().ydc_group_unique_id(buf)
+    if rc:
+        raise YdcError("ydc_group_unique_id: %s (%s)" % (lib().ydc_strerror(rc).decode(),
+                                                         lib().ydc_last_error(None).decode()))
+    return buf.raw
+
+
+def group_init_local(contexts):
+    """Makes the given contexts (one process, one device) the ranks of a group that exchanges
+    through device copies; each rank's dispatch_sharded must then run in its own thread."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib().ydc_group_init_local(arr, len(contexts))
+    if rc:
+        raise YdcError("ydc_group_init_local: %s" % lib().ydc_strerror(rc).decode())
 
 
 class DeviceArray:
@@ -271,6 +297,25 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ydc_synchronize(self._h), "ydc_synchronize")
+
+    # -- multi-GPU group ---------------------------------------------------------------
+    def group_init(self, unique_id, rank, n_ranks):
+        """Collective (like ncclCommInitRank). unique_id: the 128 bytes of group_unique_id()."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(lib().ydc_group_init(self._h, buf, rank, n_ranks), "ydc_group_init")
+
+    def group_destroy(self):
+        self._check(lib().ydc_group_destroy(self._h), "ydc_group_destroy")
+
+    def dispatch_sharded(self, d_env, d_minv, d_ip, d_out_idx=None, d_out_util=None,
+                         d_out_running=None, commit=False):
+        """Collective: this rank's slice of the global batch (device buffers)."""
+        soa = TaskSoA(_ptr(d_env), _ptr(d_minv), _ptr(d_ip))
+        n = int(d_env.numel())
+        self._check(lib().ydc_dispatch_sharded(self._h, C.byref(soa), n,
+                                               DISPATCH_COMMIT if commit else 0, _ptr(d_out_idx),
+                                               _ptr(d_out_util), _ptr(d_out_running)),
+                    "ydc_dispatch_sharded")
 
     # -- streaming mode: one captured step per tick ---------------------------------
     def stream_begin(self, max_updates, max_releases, max_tasks):

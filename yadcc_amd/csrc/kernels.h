@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void k_task_classify(
     atomicAdd(&chunk_consuming[t / chunk_size], (uint32_t)__popcll(consuming));
 }
 
-// ONE workgroup: before[k] = number of consuming tasks in the chunks before k.
+// ONE workgroup: before[k] = number of consuming tasks in the chunks before k;
+// before[n_chunks] = their total.
 __global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_consuming,
                                                        uint32_t n_chunks, uint32_t* before) {
   __shared__ uint32_t lds[17];
@@ -400,17 +401,19 @@ __global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_con
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
+  if (threadIdx.x == 0) before[n_chunks] = carry;
 }
 
 // Thread per (chunk, class): level guess, everything dirty.
+// base (nullable): consuming requests of the ranks before this one (multi-GPU).
 __global__ __launch_bounds__(256) void k_guess_init(ClassLists L, const uint32_t* before,
-                                                    uint32_t n_chunks, ClassState* guess,
-                                                    uint8_t* dirty) {
+                                                    uint32_t n_chunks, const uint32_t* base,
+                                                    ClassState* guess, uint8_t* dirty) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t C = L.n_classes;
   if (i >= n_chunks * C) return;
   uint32_t k = i / C, c = i - k * C;
-  guess[i] = level_guess(L, c, before[k]);
+  guess[i] = level_guess(L, c, before[k] + (base ? *base : 0u));
   if (c == 0) dirty[k] = 1;
 }
 
@@ -516,6 +519,62 @@ __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_i
                                                        uint32_t n_servants, uint32_t* running) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && servant_idx[i] < n_servants) atomicSub(&running[servant_idx[i]], 1u);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU helpers (rank-range sharding of one batch).
+// ---------------------------------------------------------------------------
+// base = consuming requests of the ranks before `rank`.
+__global__ void k_rank_base(const uint32_t* totals, uint32_t rank, uint32_t* base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t g = 0; g < rank; ++g) acc += totals[g];
+    *base = acc;
+  }
+}
+// What a rank publishes after a matching pass: the end state of its last chunk (C
+// entries; a rank without requests passes its predecessor's on, rank 0 the state before
+// the first request) followed by one entry whose cursor is the number of chunks the pass
+// found inconsistent.
+__global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const ClassState* endst,
+                                                       uint32_t n_chunks, const ClassState* boundary_in,
+                                                       const DeviceParams* prm, uint32_t pass,
+                                                       ClassState* out) {
+  const uint32_t C = L.n_classes;
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    ClassState s;
+    if (n_chunks) {
+      s = endst[(size_t)(n_chunks - 1) * C + c];
+    } else if (boundary_in) {
+      s = boundary_in[c];
+    } else {
+      s.cursor = s.lo = L.cls_begin[c];
+      s.hown_lo = s.hown_hi = kNone;
+    }
+    out[c] = s;
+  } else if (c == C) {
+    ClassState s;
+    s.cursor = prm->need_shared ? 0u : prm->n_changed[pass & 63];
+    s.lo = prm->overflow;
+    s.hown_lo = s.hown_hi = 0;
+    out[C] = s;
+  }
+}
+// delta[s] = grants of this rank's slice on servant s.
+__global__ __launch_bounds__(256) void k_slot_delta(const uint32_t* running, const uint32_t* running_out,
+                                                    uint32_t n, uint32_t* delta) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) delta[s] = running_out[s] - running[s];
+}
+// running_out[s] = running[s] + sum over ranks of delta[g][s].
+__global__ __launch_bounds__(256) void k_sum_deltas(const uint32_t* running, const uint32_t* deltas,
+                                                    uint32_t n, uint32_t n_ranks, uint32_t* running_out) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  uint32_t acc = running[s];
+  for (uint32_t g = 0; g < n_ranks; ++g) acc += deltas[(size_t)g * n + s];
+  running_out[s] = acc;
 }
 
 // Heartbeats of known servants (KeepServantAlive replaces the personality and keeps

@@ -2,8 +2,12 @@
 // resident servant registry, per-batch launch sequence. gfx950 only; there is
 // no CPU fallback — without a device every call fails with YDC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is resolved with dlopen at ydc_group_init
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -87,6 +91,23 @@ struct ydc_context {
   DevBuf<unsigned long long> d_claim;
   uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
 
+  // Multi-GPU group (ydc_group_*): this context is one rank of a sharded dispatcher.
+  struct LocalHub;  // single-process transport: several contexts on one device
+  struct Group {
+    int rank = 0, n_ranks = 0;  // n_ranks == 0: not in a group
+    void* rccl = nullptr;       // dlopen handle
+    ncclComm_t comm = nullptr;
+    decltype(&ncclAllGather) all_gather_fn = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy_fn = nullptr;
+    decltype(&ncclGetErrorString) error_string_fn = nullptr;
+    LocalHub* hub = nullptr;
+    DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
+    DevBuf<ClassState> d_send, d_bounds;
+    ClassState* h_bounds = nullptr;  // pinned
+    size_t h_bounds_cap = 0;
+    uint32_t passes = 0;             // of the last sharded batch
+  } group;
+
   // Streaming mode (ydc_stream_*): one tick = row updates + slot releases + one
   // committed batch, replayed from a captured graph.
   struct Stream {
@@ -135,6 +156,7 @@ struct ydc_context {
 namespace {
 
 void stream_release(ydc_context* c);  // streaming mode, defined further down
+void group_release(ydc_context* c);   // multi-GPU group, defined further down
 
 std::string g_create_error;  // errors raised before a context exists
 
@@ -363,6 +385,7 @@ int ydc_destroy(ydc_context* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   stream_release(c);
+  group_release(c);
   for (auto* b : {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
                   &c->d_flags, &c->d_class_of, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
                   &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist,
@@ -575,7 +598,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_self_hi.reserve(N));
   HIP_TRY(c, c->d_slot_of.reserve(N));
   HIP_TRY(c, c->d_chunk_consuming.reserve((size_t)K + 1));
-  HIP_TRY(c, c->d_before.reserve((size_t)K + 1));
+  HIP_TRY(c, c->d_before.reserve((size_t)K + 2));
   HIP_TRY(c, c->d_dirty.reserve((size_t)K + 1));
   HIP_TRY(c, c->d_guess[0].reserve((size_t)K * C + 1));
   HIP_TRY(c, c->d_endst.reserve((size_t)K * C + 1));
@@ -627,8 +650,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   return YDC_OK;
 }
 
-// Everything before the matching passes.
-int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
+// Everything before the level guesses: slots, sort, class lists, request classification.
+int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
   const uint32_t N = p.N, S = p.S, C = p.C, K = p.K, W = p.W, cs = p.cs;
   DeviceParams* prm = c->d_prm.p;
   hipStream_t st = c->stream;
@@ -688,10 +711,19 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
                c->d_chunk_consuming.p, prm);
     YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, c->d_chunk_consuming.p, K,
                c->d_before.p);
-    if (C)
-      YDC_LAUNCH(c, "k_guess_init", k_guess_init, dim3(ceil_div(K * C, 256)), dim3(256), 0, st, p.L,
-                 c->d_before.p, K, c->d_guess[0].p, c->d_dirty.p);
   }
+  return YDC_OK;
+}
+
+// Level guesses of the chunks' start states (base: consuming requests of earlier ranks,
+// multi-GPU only) and the two special cases that bypass the matching passes.
+int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) {
+  const uint32_t N = p.N, S = p.S, C = p.C, K = p.K;
+  DeviceParams* prm = c->d_prm.p;
+  hipStream_t st = c->stream;
+  if (N && C)
+    YDC_LAUNCH(c, "k_guess_init", k_guess_init, dim3(ceil_div(K * C, 256)), dim3(256), 0, st, p.L,
+               c->d_before.p, K, d_base, c->d_guess[0].p, c->d_dirty.p);
   mark(c, 5);
   if (N && C == 0) {
     // No eligible servant at all: every request fails with EnvironmentNotFound
@@ -710,6 +742,11 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
                prm);
   }
   return YDC_OK;
+}
+
+int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
+  if (int rc = enqueue_front_a(c, p, tk)) return rc;
+  return enqueue_front_b(c, p, nullptr);
 }
 
 // One matching pass (match_kernel.h). device_check: return at once when the previous pass
@@ -944,6 +981,261 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
 }
 
 }  // extern "C" (reopened below)
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: rank-range sharding of one batch. The global batch is the
+// concatenation, in rank order, of the slices the ranks pass to ydc_dispatch_sharded;
+// every rank holds the same servant table and computes the same sorted slot lists, and
+// replays only its own slice. Exchanges (all-gathers, a few hundred bytes to S*4 bytes per
+// rank): the slices' consuming-request counts (level guesses), after every matching pass
+// the end state of each rank's last chunk + its count of inconsistent chunks, and finally
+// the per-servant slot deltas. Transport: RCCL (librccl.so.1, resolved with dlopen so
+// that a single-GPU scheduler has no RCCL dependency), or — for several contexts of one
+// process on one device, which is how the protocol is tested on a single-GPU box — a
+// barrier + device copies.
+// ---------------------------------------------------------------------------
+struct ydc_context::LocalHub {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<const void*> send;
+  int refs = 0;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+namespace {
+
+int group_all_gather(ydc_context* c, const void* send, void* recv, size_t bytes) {
+  auto& g = c->group;
+  if (g.comm) {
+    ncclResult_t r = g.all_gather_fn(send, recv, bytes, ncclUint8, g.comm, c->stream);
+    if (r != ncclSuccess)
+      return fail(c, YDC_ERR_HIP, "ncclAllGather: %s", g.error_string_fn ? g.error_string_fn(r) : "?");
+    return YDC_OK;
+  }
+  if (g.hub) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the send buffer is complete
+    g.hub->send[g.rank] = send;
+    g.hub->barrier();
+    for (int r = 0; r < g.n_ranks; ++r)
+      HIP_TRY(c, hipMemcpyAsync((char*)recv + (size_t)r * bytes, g.hub->send[r], bytes,
+                                hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    g.hub->barrier();  // nobody rewrites its send buffer before everybody has read it
+    return YDC_OK;
+  }
+  return fail(c, YDC_ERR_INVALID_ARGUMENT, "context is not part of a group");
+}
+
+void group_release(ydc_context* c) {
+  auto& g = c->group;
+  if (g.comm && g.comm_destroy_fn) (void)g.comm_destroy_fn(g.comm);
+  g.comm = nullptr;
+  if (g.rccl) (void)dlclose(g.rccl);
+  g.rccl = nullptr;
+  if (g.hub) {
+    bool last;
+    {
+      std::lock_guard<std::mutex> lk(g.hub->mu);
+      last = --g.hub->refs == 0;
+    }
+    if (last) delete g.hub;
+    g.hub = nullptr;
+  }
+  for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas}) b->release();
+  g.d_send.release();
+  g.d_bounds.release();
+  if (g.h_bounds) (void)hipHostFree(g.h_bounds);
+  g.h_bounds = nullptr;
+  g.h_bounds_cap = 0;
+  g.n_ranks = 0;
+}
+
+void* open_rccl(std::string* err) {
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h && err) *err = std::string("dlopen librccl.so.1: ") + dlerror();
+  return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ydc_group_unique_id(void* out_id128) {
+  if (!out_id128) return YDC_ERR_INVALID_ARGUMENT;
+  static_assert(sizeof(ncclUniqueId) == 128, "ydc_group_unique_id hands out 128 bytes");
+  void* h = open_rccl(&g_create_error);
+  if (!h) return YDC_ERR_HIP;
+  auto fn = (decltype(&ncclGetUniqueId))dlsym(h, "ncclGetUniqueId");
+  if (!fn) {
+    g_create_error = "librccl has no ncclGetUniqueId";
+    return YDC_ERR_HIP;
+  }
+  ncclUniqueId id;
+  ncclResult_t r = fn(&id);
+  if (r != ncclSuccess) {
+    g_create_error = "ncclGetUniqueId failed";
+    return YDC_ERR_HIP;
+  }
+  std::memcpy(out_id128, &id, sizeof(id));
+  return YDC_OK;  // the handle stays open: ydc_group_init reuses the loaded library
+}
+
+int ydc_group_init(ydc_context* c, const void* id128, int rank, int n_ranks) {
+  if (!c || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return YDC_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  group_release(c);
+  auto& g = c->group;
+  std::string err;
+  g.rccl = open_rccl(&err);
+  if (!g.rccl) return fail(c, YDC_ERR_HIP, "%s", err.c_str());
+  auto init_fn = (decltype(&ncclCommInitRank))dlsym(g.rccl, "ncclCommInitRank");
+  g.all_gather_fn = (decltype(&ncclAllGather))dlsym(g.rccl, "ncclAllGather");
+  g.comm_destroy_fn = (decltype(&ncclCommDestroy))dlsym(g.rccl, "ncclCommDestroy");
+  g.error_string_fn = (decltype(&ncclGetErrorString))dlsym(g.rccl, "ncclGetErrorString");
+  if (!init_fn || !g.all_gather_fn || !g.comm_destroy_fn)
+    return fail(c, YDC_ERR_HIP, "librccl lacks ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclResult_t r = init_fn(&g.comm, n_ranks, id, rank);
+  if (r != ncclSuccess) {
+    g.comm = nullptr;
+    return fail(c, YDC_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks,
+                g.error_string_fn ? g.error_string_fn(r) : "?");
+  }
+  g.rank = rank;
+  g.n_ranks = n_ranks;
+  return YDC_OK;
+}
+
+int ydc_group_init_local(ydc_context** ctxs, int n) {
+  if (!ctxs || n < 1) return YDC_ERR_INVALID_ARGUMENT;
+  auto* hub = new ydc_context::LocalHub();
+  hub->n = n;
+  hub->send.assign(n, nullptr);
+  hub->refs = n;
+  for (int r = 0; r < n; ++r) {
+    if (!ctxs[r]) return YDC_ERR_INVALID_ARGUMENT;
+    group_release(ctxs[r]);
+    ctxs[r]->group.hub = hub;
+    ctxs[r]->group.rank = r;
+    ctxs[r]->group.n_ranks = n;
+  }
+  return YDC_OK;
+}
+
+int ydc_group_destroy(ydc_context* c) {
+  if (!c) return YDC_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  group_release(c);
+  return YDC_OK;
+}
+
+int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
+                         uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running) {
+  if (!c || (N && !tk)) return YDC_ERR_INVALID_ARGUMENT;
+  auto& g = c->group;
+  if (g.n_ranks < 1) return fail(c, YDC_ERR_INVALID_ARGUMENT, "ydc_group_init first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  BatchPlan p;
+  if (int rc = plan_batch(c, N, &p)) return rc;
+  if (p.use_generic || p.any_shared)
+    return fail(c, YDC_ERR_TOO_MANY_CLASSES,
+                "sharded dispatch needs <= %u servant classes and one servant per host "
+                "(dispatch such registries on one GPU)", kMaxWaveClasses);
+  const uint32_t G = (uint32_t)g.n_ranks, C = p.C, S = p.S, K = p.K;
+  const size_t rec = (size_t)C + 1;  // ClassStates a rank publishes per pass
+  HIP_TRY(c, g.d_totals.reserve(G));
+  HIP_TRY(c, g.d_base.reserve(1));
+  HIP_TRY(c, g.d_send.reserve(rec));
+  HIP_TRY(c, g.d_bounds.reserve(rec * G));
+  HIP_TRY(c, g.d_delta.reserve(S));
+  HIP_TRY(c, g.d_deltas.reserve((size_t)S * G));
+  if (g.h_bounds_cap < rec * G) {
+    if (g.h_bounds) (void)hipHostFree(g.h_bounds);
+    g.h_bounds = nullptr;
+    HIP_TRY(c, hipHostMalloc((void**)&g.h_bounds, rec * G * sizeof(ClassState)));
+    g.h_bounds_cap = rec * G;
+  }
+  hipStream_t st = c->stream;
+  DeviceParams* prm = c->d_prm.p;
+  // The chunks of this rank continue the previous rank's.
+  p.mb.boundary_in = g.rank > 0 ? g.d_bounds.p + (size_t)(g.rank - 1) * rec : nullptr;
+
+  if (int rc = enqueue_front_a(c, p, tk)) return rc;
+  if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, 4, st));  // before[K == 0] = total = 0
+  // Level guesses count the consuming requests of the ranks before this one.
+  if (int rc = group_all_gather(c, c->d_before.p + K, g.d_totals.p, 4)) return rc;
+  hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, g.d_base.p);
+  if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
+  mark(c, 6);
+
+  uint32_t pass = 0, rounds = 0;
+  for (;;) {
+    if (pass >= 64) HIP_TRY(c, hipMemsetAsync(&prm->n_changed[pass & 63], 0, 4, st));
+    if (p.wave_path) enqueue_pass(c, p, pass, 0u);
+    hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
+                       c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, pass, g.d_send.p);
+    if (int rc = group_all_gather(c, g.d_send.p, g.d_bounds.p, rec * sizeof(ClassState))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(g.h_bounds, g.d_bounds.p, rec * G * sizeof(ClassState),
+                              hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    uint64_t busy = 0;
+    bool overflow = false;
+    for (uint32_t r = 0; r < G; ++r) {
+      busy += g.h_bounds[r * rec + C].cursor;
+      overflow |= g.h_bounds[r * rec + C].lo != 0;
+    }
+    if (overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
+    ++pass;
+    if (busy == 0) {  // every chunk of every rank was consistent with its predecessor
+      rounds = pass;
+      break;
+    }
+    // Worst case one chunk per pass becomes final; K differs per rank, so bound it loosely.
+    if (pass > (uint64_t)4 * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
+  }
+  g.passes = rounds;
+
+  // Placement of this rank's slice; then the global running_tasks from everybody's deltas.
+  if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, kNone)) return rc;
+  if (S) {
+    hipLaunchKernelGGL(k_slot_delta, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
+                       c->d_running_out.p, S, g.d_delta.p);
+    if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
+    hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
+                       g.d_deltas.p, S, G, c->d_running_out.p);
+    if (flags & YDC_DISPATCH_COMMIT)
+      HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
+                                hipMemcpyDeviceToDevice, st));
+    if (d_out_running)
+      HIP_TRY(c, hipMemcpyAsync(d_out_running, c->d_running_out.p, (size_t)S * 4,
+                                hipMemcpyDeviceToDevice, st));
+  }
+  mark(c, 7);
+  HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, hipGetLastError());
+  fill_stats(c, p, rounds);
+  return YDC_OK;
+}
+
+}  // extern "C"
 
 // ---------------------------------------------------------------------------
 // Streaming mode (BASELINE.json configs[4]): a tick is
