@@ -112,8 +112,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("YDC_BENCH_FORCE_DIST") == "1"
+    dist = torch = None
+    if use_dist:
+        # Rendezvous, barriers and the max over ranks go through gloo (CPU); the data path of
+        # the sharded batch is RCCL inside libydc.so (ydc_group_init / ydc_dispatch_sharded).
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -124,11 +127,34 @@ def main():
         if dist:
             dist.barrier()
 
-    # Weak scaling: every rank owns one snapshot of the named config (own seed).
-    sv, tk = synth.make_config(args.config, seed=42 + rank)
-    n_tasks, n_serv = len(tk["env_id"]), len(sv["version"])
+    # Weak scaling: G ranks place ONE global batch of G x (the config's requests) on a pool of
+    # G x (the config's servants); rank r owns the r-th range of the batch (arrival order).
+    n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[args.config]
+    sv = synth.make_servants(s_cfg * world, n_tasks_hint=n_cfg * world, n_envs=n_envs, seed=42)
+    tk_all = synth.make_tasks(n_cfg * world, sv, n_envs=n_envs, unknown_env_frac=unk)
+    lo, hi = n_cfg * rank, n_cfg * (rank + 1)
+    tk = {k: v[lo:hi] for k, v in tk_all.items()}
+    n_tasks, n_serv = hi - lo, len(sv["version"])
     ctx = binding.Context(device=local_rank)
     ctx.upload_servants(pack.to_abi_columns(sv))
+    group_note = None
+    sharded = False
+    if use_dist:
+        try:
+            ids = [binding.group_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.group_init(ids[0], rank, world)
+            sharded = True
+        except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
+            group_note = "RCCL group init failed (%s): ranks ran independent batches" % e
+        flags = [1 if sharded else 0]
+        if dist:
+            t = torch.tensor(flags, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t[0]) == 0 and sharded:
+                ctx.group_destroy()
+                sharded = False
+                group_note = group_note or "another rank could not join the RCCL group"
     DA = binding.DeviceArray
     d_env = DA.from_numpy(tk["env_id"], local_rank)
     d_minv = DA.from_numpy(tk["min_version"], local_rank)
@@ -138,7 +164,10 @@ def main():
 
     def step():
         # Returns after the batch's results are final in HBM (stream sync inside).
-        ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run)
+        if sharded:
+            ctx.dispatch_sharded(d_env, d_minv, d_ip, d_out, None, d_run)
+        else:
+            ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run)
 
     for _ in range(args.warmup):
         step()
@@ -161,6 +190,17 @@ def main():
         g = torch.tensor([granted_all], dtype=torch.float64)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         elapsed, granted_all = float(t[0]), float(g[0])
+
+    # Host-buffer entry point (H2D of 12 B/request + D2H of 4 B/request over PCIe): reported
+    # beside `value`, never as `value`.
+    host_rate = None
+    if not use_dist:
+        n_host = max(3, min(20, args.steps))
+        ctx.dispatch(tk, want_util=False, want_running=False)
+        h0 = time.perf_counter()
+        for _ in range(n_host):
+            ctx.dispatch(tk, want_util=False, want_running=False)
+        host_rate = st["granted"] * n_host / (time.perf_counter() - h0)
 
     # Per-kernel durations: HIP events on the dispatch stream, separate profiled steps so
     # the events do not perturb the timed region.
@@ -188,9 +228,12 @@ def main():
             "dtype": "u32" if st["key_bits"] <= 32 else "u64",
             "data": "synthetic",
             "config": {"workload": "%s: %d pending requests x %d servants per GPU, %d classes"
-                                   % (args.config, n_tasks, n_serv, st["n_classes"]),
+                                   % (args.config, n_cfg, s_cfg, st["n_classes"]),
                        "parallelism": "1 GPU" if world == 1 else
-                                      "%d independent snapshots, one per GPU" % world,
+                                      ("one global batch of %d requests x %d servants sharded by "
+                                       "rank range over %d GPUs, RCCL all-gather of boundary states "
+                                       "and servant-slot deltas" % (n_cfg * world, n_serv, world)
+                                       if sharded else group_note),
                        "inputs": "request columns + servant table resident in HBM; results in HBM"},
             "p99_dispatch_latency_ms": 1e3 * percentile(lat, 0.99),
             "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
@@ -198,14 +241,19 @@ def main():
             "stage_ms": stage_ms,
             "kernels_us_per_step": {k: 1e3 * v[1] / n_prof for k, v in prof.items()},
         }
+        if host_rate:
+            out["host_buffers_assignments_per_s"] = host_rate
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
             launches, total_ms = prof[dom]
-            alg_bytes = 16 * n_tasks + 40 * n_serv  # bytes(batch) = 16 N + 40 S
+            # bytes(batch) = 16 N + 40 S; one launch of the dominant kernel
+            # (a matching pass) works on the whole batch of this rank.
+            alg_bytes = 16 * n_tasks + 40 * n_serv
             avg_launch_s = (total_ms / launches) * 1e-3
             ach = alg_bytes / avg_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "unit": "GB/s", "frac": ach / 8000.0,
+                               "traffic": pmc_traffic(dom),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_us": avg_launch_s * 1e6,
                                "launches_per_step": launches / n_prof}
@@ -214,10 +262,28 @@ def main():
             out["cpu_baseline"] = base
             out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
         print(json.dumps(out))
+    if sharded:
+        ctx.group_destroy()
     ctx.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_hbm.json: FETCH_SIZE doubled for wide coalesced reads + WRITE_SIZE, per
+    MI355X_MICROARCH.md §HBM), or None when no profile of this kernel is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if kernel in j.get("kernels", {}):
+            best = j["kernels"][kernel].get("hbm_bytes_per_launch")
+    return best
 
 
 if __name__ == "__main__":

@@ -195,4 +195,186 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// One rank of the multi-GPU sharding protocol, replayed on the CPU so that
+// the protocol can be exercised by real processes exchanging over gloo
+// (tests/test_sharded_protocol_gloo.py). Same steps as ydc_dispatch_sharded: every rank
+// builds the same slot lists from the full servant table, classifies and replays only its
+// own slice of the batch, publishes after every pass the end state of its last chunk and
+// how many of its chunks were inconsistent, and finally its per-servant slot deltas.
+// ---------------------------------------------------------------------------
+struct model_shard {
+  uint32_t S = 0, C = 0, N = 0, K = 0, W = 1, chunk = 256;
+  std::vector<uint32_t> base, running, nproc, load, max_tasks;
+  std::vector<uint32_t> cls_begin, list_p, list_g;
+  std::vector<uint64_t> tmask;
+  std::vector<uint32_t> tself_lo, tself_hi, slot_of, consuming_before;
+  std::vector<ClassState> guess0, used_start, endst;
+  std::vector<uint8_t> replayed_once;
+  ClassLists L{};
+  TaskTable ti{};
+  uint32_t consuming_total = 0;
+};
+
+model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_t* nproc,
+                              const uint32_t* load, const uint32_t* max_tasks,
+                              const uint32_t* running, const uint32_t* flags,
+                              const uint64_t* env_mask, const uint32_t* ip_id, uint32_t N,
+                              const uint32_t* env_id, const uint32_t* min_version,
+                              const uint32_t* requestor_ip, uint32_t chunk_size) {
+  auto* m = new model_shard();
+  HostTables T;
+  T.build(S, env_mask, version, max_tasks, nproc, ip_id);
+  if (T.any_shared_ip) {  // not supported by the sharded path (neither is it on the GPU)
+    delete m;
+    return nullptr;
+  }
+  const uint32_t C = T.n_classes();
+  KeyFormat kf = choose_key_format(T.cap_bits);
+  m->S = S;
+  m->C = C;
+  m->N = N;
+  m->chunk = chunk_size ? chunk_size : 256;
+  m->K = N ? (N + m->chunk - 1) / m->chunk : 0;
+  m->running.assign(running, running + S);
+  m->nproc.assign(nproc, nproc + S);
+  m->load.assign(load, load + S);
+  m->max_tasks.assign(max_tasks, max_tasks + S);
+  m->base.assign(S + 1, 0);
+  for (uint32_t s = 0; s < S; ++s) {
+    uint32_t k = T.class_of[s] == kNone
+                     ? 0
+                     : servant_slot_count(nproc[s], load[s], max_tasks[s], running[s], flags[s]);
+    m->base[s + 1] = m->base[s] + k;
+  }
+  const uint32_t M = m->base[S];
+  std::vector<uint64_t> key(M);
+  for (uint32_t s = 0; s < S; ++s)
+    for (uint32_t g = m->base[s]; g < m->base[s + 1]; ++g) {
+      uint32_t r = running[s] + (g - m->base[s]);
+      uint32_t cap = slot_capacity(nproc[s], load[s], max_tasks[s], r);
+      uint32_t tier = slot_tier(nproc[s], flags[s], r);
+      key[g] = kf.exact ? slot_key_exact(tier, r, cap, kf.cap_bits) : slot_key_fp64(tier, r, cap);
+    }
+  std::vector<uint32_t> sorted_g(M);
+  std::iota(sorted_g.begin(), sorted_g.end(), 0u);
+  std::stable_sort(sorted_g.begin(), sorted_g.end(),
+                   [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+  m->cls_begin.assign(C + 1, 0);
+  m->list_p.resize(M);
+  m->list_g.resize(M);
+  {
+    std::vector<uint32_t> cnt(C + 1, 0), owner(M);
+    for (uint32_t p = 0; p < M; ++p) {
+      owner[p] = owner_of_slot(m->base.data(), S, sorted_g[p]);
+      cnt[T.class_of[owner[p]] + 1]++;
+    }
+    for (uint32_t c = 0; c < C; ++c) m->cls_begin[c + 1] = m->cls_begin[c] + cnt[c + 1];
+    std::vector<uint32_t> fill(m->cls_begin.begin(), m->cls_begin.end() - 1);
+    for (uint32_t p = 0; p < M; ++p) {
+      uint32_t c = T.class_of[owner[p]];
+      m->list_p[fill[c]] = p;
+      m->list_g[fill[c]] = sorted_g[p];
+      fill[c]++;
+    }
+  }
+  m->L.list_p = C > 1 ? m->list_p.data() : nullptr;
+  m->L.list_g = m->list_g.data();
+  m->L.cls_begin = m->cls_begin.data();
+  m->L.n_classes = C;
+  m->W = std::max<uint32_t>(1, (C + 63) / 64);
+  m->tmask.assign((size_t)N * m->W, 0);
+  m->tself_lo.assign(N, kNone);
+  m->tself_hi.assign(N, kNone);
+  for (uint32_t t = 0; t < N; ++t) {
+    task_class_mask(env_id[t], min_version[t], T.cls_env.data(), T.cls_ver.data(), C, m->W,
+                    &m->tmask[(size_t)t * m->W]);
+    uint32_t i = lower_bound_u32(T.ip_sorted.data(), S, requestor_ip[t]);
+    if (i < S && T.ip_sorted[i] == requestor_ip[t]) {
+      uint32_t s = T.ip_servant[i];
+      if (m->base[s + 1] > m->base[s]) {
+        m->tself_lo[t] = m->base[s];
+        m->tself_hi[t] = m->base[s + 1];
+      }
+    }
+  }
+  m->ti = TaskTable{m->tmask.data(), m->tself_lo.data(), m->tself_hi.data(), m->W};
+  m->consuming_before.assign(m->K + 1, 0);
+  for (uint32_t k = 0; k < m->K; ++k) {
+    uint32_t n = 0;
+    for (uint32_t t = k * m->chunk; t < std::min(N, (k + 1) * m->chunk); ++t)
+      n += !task_mask_empty(m->ti, t);
+    m->consuming_before[k + 1] = m->consuming_before[k] + n;
+  }
+  m->consuming_total = m->consuming_before[m->K];
+  m->slot_of.assign(N, kIdxTimeout);
+  m->guess0.resize((size_t)m->K * C);
+  m->used_start.resize((size_t)m->K * C);
+  m->endst.resize((size_t)m->K * C);
+  return m;
+}
+
+uint32_t model_shard_n_classes(const model_shard* m) { return m->C; }
+uint32_t model_shard_consuming(const model_shard* m) { return m->consuming_total; }
+
+// One matching pass. base: consuming requests of the ranks before this one (pass 0).
+// boundary_in: end state of the previous rank's last chunk (NULL on rank 0; unused in pass
+// 0). out_end[C]: what this rank publishes. Returns the number of inconsistent chunks
+// (pass 0: the number of chunks).
+uint32_t model_shard_pass(model_shard* m, uint32_t pass, uint32_t base,
+                          const ClassState* boundary_in, ClassState* out_end) {
+  const uint32_t C = m->C, K = m->K;
+  std::vector<ClassRun> runs(std::max<uint32_t>(C, 1));
+  uint32_t busy = 0;
+  for (uint32_t k = 0; k < K; ++k) {
+    const ClassState* start;
+    std::vector<ClassState> lvl;
+    if (pass == 0) {
+      lvl.resize(C);
+      for (uint32_t c = 0; c < C; ++c) lvl[c] = level_guess(m->L, c, base + m->consuming_before[k]);
+      start = lvl.data();
+    } else {
+      if (k == 0 && !boundary_in) continue;  // rank 0, chunk 0: started from the true state
+      start = k == 0 ? boundary_in : &m->endst[(size_t)(k - 1) * C];
+      bool same = true;
+      for (uint32_t c = 0; c < C; ++c)
+        same &= class_state_equal(start[c], m->used_start[(size_t)k * C + c]);
+      if (same) continue;  // consistent
+    }
+    ++busy;
+    std::vector<ClassState> st(start, start + C);  // endst[k-1] may be rewritten below? no: k ascending
+    for (uint32_t c = 0; c < C; ++c) m->used_start[(size_t)k * C + c] = st[c];
+    sim_chunk(m->L, m->ti, k * m->chunk, std::min(m->N, (k + 1) * m->chunk), st.data(),
+              &m->endst[(size_t)k * C], m->slot_of.data(), runs.data(), nullptr);
+  }
+  for (uint32_t c = 0; c < C; ++c) {
+    if (K) {
+      out_end[c] = m->endst[(size_t)(K - 1) * C + c];
+    } else if (boundary_in) {
+      out_end[c] = boundary_in[c];
+    } else {
+      out_end[c].cursor = out_end[c].lo = m->cls_begin[c];
+      out_end[c].hown_lo = out_end[c].hown_hi = kNone;
+    }
+  }
+  return busy;
+}
+
+void model_shard_finalize(const model_shard* m, uint32_t* out_idx, uint32_t* out_delta) {
+  std::memset(out_delta, 0, m->S * sizeof(uint32_t));
+  for (uint32_t t = 0; t < m->N; ++t) {
+    uint32_t g = m->slot_of[t];
+    if (g >= kIdxEnvNotFound) {
+      out_idx[t] = g;
+      continue;
+    }
+    uint32_t s = owner_of_slot(m->base.data(), m->S, g);
+    out_idx[t] = s;
+    out_delta[s]++;
+  }
+}
+
+void model_shard_close(model_shard* m) { delete m; }
+
 }  // extern "C"
