@@ -9,9 +9,6 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from oracle import oraclebind as O
 from tests import cases
@@ -26,6 +23,8 @@ def _free_port():
 
 
 def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
+    import torch
+    import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -94,6 +93,9 @@ def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
 
 
 def _run(world, case_kw, cuts, chunk=256):
+    # torch only inside the test (and its children): the GPU test process of this repo must not
+    # load a second HIP runtime by merely collecting this file.
+    import torch.multiprocessing as mp
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_rank_main, args=(world, _free_port(), case_kw, cuts, chunk, ret), nprocs=world,

@@ -24,8 +24,6 @@
 
 namespace ydc {
 
-constexpr int kRadixBits = 8;
-constexpr int kRadix = 1 << kRadixBits;
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 slots per workgroup
@@ -185,23 +183,28 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
 }
 
 // ---------------------------------------------------------------------------
-// Stable LSD radix sort, 8-bit digits, three kernels per pass.
-// Digit of element i: bits [shift, shift+8) of keys[i], or (class pass) of
+// Stable LSD radix sort, three kernels per pass, digit width chosen per pass (up
+// to kMaxRadixBits: 17-bit keys sort in two 9-bit passes, 21-bit keys in 11 + 10).
+// Digit of element i: bits [shift, shift + bits) of keys[i], or (class pass) of
 // cls_by_g[vals[i]] with the element's key being its index (== global rank).
 // ---------------------------------------------------------------------------
+constexpr int kMaxRadixBits = 11;
+
 template <typename KeyT>
 struct SortIn {
   const KeyT* keys;         // NULL in the class pass: key == index
   const uint32_t* vals;
   const uint16_t* cls_by_g; // non-NULL in the class pass
   uint32_t shift;
+  uint32_t bits;            // digit width of this pass
 };
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t i, KeyT key,
                                                uint32_t val) {
-  if (in.cls_by_g) return ((uint32_t)in.cls_by_g[val] >> in.shift) & (kRadix - 1);
-  return (uint32_t)(key >> in.shift) & (kRadix - 1);
+  const uint32_t mask = (1u << in.bits) - 1;
+  if (in.cls_by_g) return ((uint32_t)in.cls_by_g[val] >> in.shift) & mask;
+  return (uint32_t)(key >> in.shift) & mask;
 }
 
 // hist[d * n_tiles + tile] = number of elements of the tile with digit d.
@@ -209,10 +212,11 @@ template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in,
                                                              const DeviceParams* prm,
                                                              uint32_t n_tiles, uint32_t* hist) {
-  __shared__ uint32_t h[kRadix];
+  extern __shared__ uint32_t h[];  // radix
+  const uint32_t radix = 1u << in.bits;
   const uint32_t M = prm->n_slots;
   const uint32_t tile = blockIdx.x;
-  h[threadIdx.x] = 0;
+  for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) h[d] = 0;
   __syncthreads();
   const uint32_t base = tile * kSortTile;
   if (base < M) {
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in,
     }
   }
   __syncthreads();
-  hist[threadIdx.x * n_tiles + tile] = h[threadIdx.x];
+  for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) hist[d * n_tiles + tile] = h[d];
 }
 
 // One workgroup per digit: exclusive scan of its row of tile counts, row total.
@@ -259,25 +263,36 @@ template <typename KeyT, typename OutKeyT>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     SortIn<KeyT> in, const DeviceParams* prm, uint32_t n_tiles, const uint32_t* hist,
     const uint32_t* row_total, OutKeyT* out_keys, uint32_t* out_vals) {
-  __shared__ uint32_t cnt[kSortWaves][kRadix];
-  __shared__ uint32_t dstart[kRadix];
+  extern __shared__ uint32_t sm[];  // cnt[kSortWaves][radix] | dstart[radix]
   __shared__ uint32_t lds[17];
+  const uint32_t radix = 1u << in.bits;
+  uint32_t* cnt = sm;
+  uint32_t* dstart = sm + kSortWaves * radix;
   const uint32_t M = prm->n_slots;
   const uint32_t tile = blockIdx.x;
   const uint32_t base = tile * kSortTile;
   if (base >= M) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
+    // Start of every digit: exclusive scan of the row totals (each thread owns
+    // radix / 256 consecutive digits) + the elements of earlier tiles.
+    const uint32_t per = (radix + kSortThreads - 1) / kSortThreads;
+    const uint32_t d0 = threadIdx.x * per, d1 = min(radix, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += row_total[d];
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(row_total[threadIdx.x], lds, &total);
-    dstart[threadIdx.x] = ex + hist[threadIdx.x * n_tiles + tile];
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) cnt[w][threadIdx.x] = 0;
+    uint32_t acc = block_exclusive_scan(sum, lds, &total);
+    for (uint32_t d = d0; d < d1; ++d) {
+      dstart[d] = acc + hist[d * n_tiles + tile];
+      acc += row_total[d];
+    }
+    for (uint32_t d = threadIdx.x; d < kSortWaves * radix; d += kSortThreads) cnt[d] = 0;
   }
   __syncthreads();
   KeyT key[kSortItems];
   uint32_t val[kSortItems], dig[kSortItems], rank[kSortItems];
   const uint64_t lt_mask = (1ull << lane) - 1;
+  uint32_t* wcnt = cnt + wave * radix;
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
@@ -293,24 +308,26 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     dig[j] = d;
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < kRadixBits; ++b) {
-      const uint64_t m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
+    for (int b = 0; b < kMaxRadixBits; ++b) {
+      if ((uint32_t)b < in.bits) {
+        const uint64_t m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+      }
     }
     uint32_t before = 0;
-    if (valid) before = cnt[wave][d];
+    if (valid) before = wcnt[d];
     rank[j] = before + (uint32_t)__popcll(peers & lt_mask);
     // The lowest lane of each peer group publishes the group's size. All lanes
-    // of this wave have read cnt[wave][d] in the instruction above.
-    if (valid && (peers & lt_mask) == 0) cnt[wave][d] = before + (uint32_t)__popcll(peers);
+    // of this wave have read wcnt[d] in the instruction above.
+    if (valid && (peers & lt_mask) == 0) wcnt[d] = before + (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  {
+  for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) {
     uint32_t off = 0;
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) {
-      uint32_t t = cnt[w][threadIdx.x];
-      cnt[w][threadIdx.x] = off;
+      uint32_t t = cnt[w * radix + d];
+      cnt[w * radix + d] = off;
       off += t;
     }
   }
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
     if (i < M) {
-      const uint32_t pos = dstart[dig[j]] + cnt[wave][dig[j]] + rank[j];
+      const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       out_keys[pos] = (OutKeyT)key[j];
       out_vals[pos] = val[j];
     }

@@ -51,7 +51,7 @@ namespace {
 // Sizes, workspace views and kernel argument blocks of one batch (plan_batch).
 struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
-  uint32_t key_passes = 0, cls_passes = 0, rshift = 4, init_fill = 8;
+  uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8;
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
   ServantTable sv{};
   ClassLists L{};
@@ -186,7 +186,7 @@ int rebuild_tables(ydc_context* c) {
   const uint32_t n = c->n_servants;
   c->tables.build(n, c->h_env.data(), c->h_version.data(), c->h_max_tasks.data(),
                   c->h_nproc.data(), c->h_ip.data());
-  c->kf = choose_key_format(c->tables.cap_bits, kRadixBits);
+  c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits);
   const uint32_t C = c->tables.n_classes();
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
@@ -262,17 +262,19 @@ struct KernelTimer {
 template <typename KeyT>
 int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in, uint32_t n_tiles, void* out_keys,
                      bool out_u32, uint32_t* out_vals) {
-  YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles), dim3(kSortThreads), 0,
+  const uint32_t radix = 1u << in.bits;
+  YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles), dim3(kSortThreads), radix * 4,
              c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p);
-  YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(kRadix), dim3(256), 0, c->stream, n_tiles,
+  YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(radix), dim3(256), 0, c->stream, n_tiles,
              c->d_hist.p, c->d_row_total.p);
+  const size_t lds = (size_t)(kSortWaves + 1) * radix * 4;
   if (out_u32) {
     YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint32_t>), dim3(n_tiles),
-               dim3(kSortThreads), 0, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
+               dim3(kSortThreads), lds, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint32_t*)out_keys, out_vals);
   } else {
     YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint64_t>), dim3(n_tiles),
-               dim3(kSortThreads), 0, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
+               dim3(kSortThreads), lds, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint64_t*)out_keys, out_vals);
   }
   return YDC_OK;
@@ -360,7 +362,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   }
   if (c->d_prm.reserve(1) != hipSuccess ||
       hipHostMalloc((void**)&c->h_prm, sizeof(DeviceParams)) != hipSuccess ||
-      c->d_row_total.reserve(kRadix) != hipSuccess) {
+      c->d_row_total.reserve(1u << kMaxRadixBits) != hipSuccess) {
     ydc_destroy(c);
     return YDC_ERR_HIP;
   }
@@ -591,7 +593,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_keys[1].reserve(p.key32 ? (slot_bound + 1) / 2 : slot_bound));
   HIP_TRY(c, c->d_vals[0].reserve(slot_bound));
   HIP_TRY(c, c->d_vals[1].reserve(slot_bound));
-  HIP_TRY(c, c->d_hist.reserve((size_t)kRadix * p.n_tiles));
+  HIP_TRY(c, c->d_hist.reserve(((size_t)1 << kMaxRadixBits) * p.n_tiles));
   if (C > 1) HIP_TRY(c, c->d_cls_by_g.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
   HIP_TRY(c, c->d_self_lo.reserve(N));
@@ -615,12 +617,13 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
 
   p.sv = ServantTable{c->d_version.p, c->d_nproc.p,  c->d_load.p,     c->d_max_tasks.p,
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
-  p.key_passes = ceil_div(c->kf.key_bits, kRadixBits);
+  p.key_passes = c->kf.passes;
   p.cls_passes = 0;
   if (C > 1 && slot_bound) {
     uint32_t cls_bits = 1;
     while ((1u << cls_bits) < C) ++cls_bits;
-    p.cls_passes = ceil_div(cls_bits, kRadixBits);
+    p.cls_passes = ceil_div(cls_bits, kMaxRadixBits);
+    p.cls_bits = ceil_div(cls_bits, p.cls_passes);
   }
   // The sort ping-pongs between the two key/value buffers: where the lists end up.
   const int cur = (int)(((slot_bound ? p.key_passes : 0) + p.cls_passes) & 1);
@@ -679,13 +682,15 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   }
   mark(c, 2);
   // ---- sort by key
+  const uint32_t bpp = c->kf.bits_per_pass;
+  auto bits_of = [&](uint32_t q) { return std::min(bpp, c->kf.key_bits - q * bpp); };
   if (p.slot_bound) {
     for (uint32_t q = 0; q < p.key_passes; ++q) {
       if (p.key32) {
-        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], nullptr, q * kRadixBits};
+        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q)};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
       } else {
-        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], nullptr, q * kRadixBits};
+        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q)};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1]);
       }
       cur ^= 1;
@@ -696,7 +701,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   for (uint32_t q = 0; q < p.cls_passes; ++q) {
     // First pass: key == index (global rank). Later passes carry the rank along.
     SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
-                        q * kRadixBits};
+                        q * p.cls_bits, p.cls_bits};
     launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
     cur ^= 1;
   }
@@ -1063,11 +1068,31 @@ void group_release(ydc_context* c) {
   g.n_ranks = 0;
 }
 
+// librccl must sit on the SAME HIP runtime as this library: a process may hold two
+// (e.g. /opt/rocm's and the one bundled with a PyTorch wheel), and RCCL calls on device
+// memory of the other runtime fail. So look next to the libamdhip64 this library is bound
+// to first, and only then fall back to the soname.
 void* open_rccl(std::string* err) {
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!h && err) *err = std::string("dlopen librccl.so.1: ") + dlerror();
-  return h;
+  std::vector<std::string> names;
+  Dl_info info;
+  if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash);
+      names.push_back(dir + "/librccl.so.1");
+      names.push_back(dir + "/librccl.so");
+    }
+  }
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  std::string tried;
+  for (auto& n : names) {
+    if (void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)) return h;
+    tried += n + " ";
+  }
+  if (err) *err = "dlopen failed for: " + tried + "(" + (dlerror() ? dlerror() : "?") + ")";
+  return nullptr;
 }
 
 }  // namespace
