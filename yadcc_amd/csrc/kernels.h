@@ -36,7 +36,8 @@ struct DeviceParams {
   uint32_t need_shared;   // some task's host runs several servants
   uint32_t n_changed[64]; // end states changed in round r, at index r & 63 (match_kernel.h)
   uint32_t chunk_sims;    // chunk simulations executed (all rounds)
-  uint32_t granted, timeouts, env_not_found;
+  uint32_t granted;       // requests that got a slot (k_running_out)
+  uint32_t consuming;     // requests with at least one eligible class (k_chunk_prefix)
   uint32_t batch_seq;     // batches this context has started (never reset)
 };
 
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     prm->need_shared = 0;
     for (int r = 0; r < 64; ++r) prm->n_changed[r] = 0;
     prm->chunk_sims = 0;
-    prm->granted = prm->timeouts = prm->env_not_found = 0;
+    prm->granted = 0;
+    prm->consuming = 0;
     prm->batch_seq += 1;
     uint32_t acc = 0;
     for (uint32_t c = 0; c < n_classes; ++c) {
@@ -167,11 +169,14 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_t* slot_base,
                                                   const DeviceParams* prm, uint32_t exact,
                                                   uint32_t cap_bits, KeyT* keys, uint32_t* vals,
-                                                  uint16_t* cls_by_g) {
+                                                  uint16_t* cls_by_g, uint32_t* owner,
+                                                  uint8_t* consumed) {
   const uint32_t M = prm->n_slots;
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= M) return;
   uint32_t s = owner_of_slot(slot_base, sv.n, g);
+  owner[g] = s;
+  consumed[g] = 0;
   uint32_t r = sv.running[s] + (g - slot_base[s]);
   uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
   uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
@@ -403,7 +408,8 @@ __global__ __launch_bounds__(256) void k_task_classify(
 // ONE workgroup: before[k] = number of consuming tasks in the chunks before k;
 // before[n_chunks] = their total.
 __global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_consuming,
-                                                       uint32_t n_chunks, uint32_t* before) {
+                                                       uint32_t n_chunks, uint32_t* before,
+                                                       DeviceParams* prm) {
   __shared__ uint32_t lds[17];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -418,7 +424,10 @@ __global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_con
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) before[n_chunks] = carry;
+  if (threadIdx.x == 0) {
+    before[n_chunks] = carry;
+    prm->consuming = carry;
+  }
 }
 
 // Thread per (chunk, class): level guess, everything dirty.
@@ -495,40 +504,68 @@ __global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_c
 }
 
 // ---------------------------------------------------------------------------
-// k_finalize: thread per task.
+// k_finalize: thread per request. slot_of[t] is the global rank of the request's slot
+// (matching passes) or its generation index (sequential paths: slot_is_rank == 0, or
+// need_shared); rank -> slot through the key-sorted order, slot -> servant through the
+// owner table slot_gen left. Marks the slot consumed — no atomics: k_running_out counts.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_t* slot_base,
+                                                  const uint32_t* owner, const uint32_t* rank_to_g,
                                                   const uint32_t* slot_of, uint32_t n_tasks,
-                                                  uint32_t* out_idx, double* out_util,
-                                                  uint32_t* running_out, uint32_t check_slot,
-                                                  DeviceParams* prm) {
-  // Pre-launched behind the matching rounds: only runs once they have converged.
+                                                  uint32_t slot_is_rank, uint32_t* out_idx,
+                                                  double* out_util, uint8_t* consumed,
+                                                  uint32_t check_slot, const DeviceParams* prm) {
+  // Pre-launched behind the matching passes: only runs once they have converged.
   if (check_slot != kNone && prm->n_changed[check_slot] != 0) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t kind = 3;  // 0 granted, 1 timeout, 2 env-not-found, 3 inactive lane
   if (t < n_tasks) {
     uint32_t g = slot_of[t];
     if (g >= kIdxEnvNotFound) {
-      kind = g == kIdxTimeout ? 1 : 2;
       if (out_idx) out_idx[t] = g;
       if (out_util) out_util[t] = -1.0;
     } else {
-      kind = 0;
-      uint32_t s = owner_of_slot(slot_base, sv.n, g);
+      if (slot_is_rank && !prm->need_shared) g = rank_to_g[g];
+      const uint32_t s = owner[g];
       if (out_idx) out_idx[t] = s;
       if (out_util) {
         uint32_t r = sv.running[s] + (g - slot_base[s]);
         out_util[t] = slot_utilization(r, slot_capacity(sv.nproc[s], sv.load[s], sv.max_tasks[s], r));
       }
-      atomicAdd(&running_out[s], 1u);
+      consumed[g] = 1;
     }
   }
-  uint64_t g0 = __ballot(kind == 0), g1 = __ballot(kind == 1), g2 = __ballot(kind == 2);
-  if ((threadIdx.x & 63) == 0) {
-    if (g0) atomicAdd(&prm->granted, (uint32_t)__popcll(g0));
-    if (g1) atomicAdd(&prm->timeouts, (uint32_t)__popcll(g1));
-    if (g2) atomicAdd(&prm->env_not_found, (uint32_t)__popcll(g2));
+}
+
+// Thread per servant: running_out = running + consumed slots. A servant's slots are
+// consumed in ascending order of `running` (its slots sit in one class list in that
+// order, and the list is consumed smallest-first, holes included), so the consumed ones
+// are a prefix of its slot range: binary search for the first free one.
+__global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, const uint32_t* slot_base,
+                                                     const uint8_t* consumed, uint32_t n_servants,
+                                                     uint32_t* running_out, uint32_t check_slot,
+                                                     uint32_t count_all, DeviceParams* prm) {
+  __shared__ uint32_t lds[17];
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t taken = 0;
+  if (s < n_servants && (check_slot == kNone || prm->n_changed[check_slot] == 0)) {
+    uint32_t lo = slot_base[s], hi = slot_base[s + 1];
+    if (count_all) {
+      // One rank of a sharded batch: its requests took a run somewhere inside the range.
+      for (uint32_t g = lo; g < hi; ++g) taken += consumed[g];
+    } else {
+      const uint32_t b = lo;  // first free slot in [lo, hi]
+      while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (consumed[mid]) lo = mid + 1; else hi = mid;
+      }
+      taken = lo - b;
+    }
   }
+  if (s < n_servants) running_out[s] = running[s] + taken;
+  // One counter update per workgroup (same-address atomics serialise at ~10 ns each).
+  uint32_t total;
+  (void)block_exclusive_scan(taken, lds, &total);
+  if (threadIdx.x == 0 && total) atomicAdd(&prm->granted, total);
 }
 
 // Registry maintenance.

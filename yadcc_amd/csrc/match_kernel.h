@@ -26,11 +26,15 @@
 // harmless) state; the inconsistency shows in the next pass.
 //
 // The pick of one request depends on the previous one, so the inner loop is a
-// dependency chain. Per request: two v_readlane (the request's class mask), one
-// v_cndmask that uses the mask as a lane mask, a 6-step DPP min, a ballot, a
-// v_readlane of the winning slot; the winning lane advances its class from
-// registers (head and next entry are kept in VGPRs, the LDS ring read for the
-// entry after next is not waited for until the lane wins again).
+// dependency chain, and a single wave issues at most one instruction every ~4-5
+// cycles whatever its kind: what counts is the instruction count per request. The
+// loop works on *inverted* ranks (~rank, 0 = no slot) so that the winner is a DPP
+// max with zero fill (no identity moves), the request's class mask is used
+// directly as a lane mask (v_cndmask with an SGPR pair), the result of a request is
+// its slot's global rank (the reduced value itself; k_finalize maps rank -> slot ->
+// servant), and the winning lane advances from registers (head / next kept in
+// VGPRs, the LDS read of the entry after next is only waited for when the lane wins
+// again). About 34 instructions per request at 32 classes.
 #ifndef YADCC_AMD_MATCH_KERNEL_H_
 #define YADCC_AMD_MATCH_KERNEL_H_
 
@@ -48,7 +52,7 @@ struct MatchBuffers {
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
   unsigned long long* claim; // [K] (batch, pass) stamp of the pass in which a wave took the chunk
-  uint32_t* slot_of;         // [N] generation index of the slot each request takes
+  uint32_t* slot_of;         // [N] global rank of the slot each request takes (or kIdx*)
   // Multi-GPU: this rank's chunks continue the previous rank's. boundary_in (C
   // entries, or NULL) is the end state of the predecessor's last chunk.
   const ClassState* boundary_in;
@@ -57,9 +61,9 @@ struct MatchBuffers {
 // Everything a lane keeps about one of its classes.
 struct LaneClass {
   uint32_t cursor, lo, hown_lo, hown_hi, end;
-  uint32_t head_p, head_g;  // entry at `cursor`     (kNone past the end)
-  uint32_t next_p, next_g;  // entry at `cursor + 1` (kNone past the end)
-  uint32_t filled;          // ring holds list entries [cursor, filled)
+  uint32_t hq;      // ~rank of the entry at `cursor`     (0 past the end)
+  uint32_t nq;      // ~rank of the entry at `cursor + 1` (0 past the end)
+  uint32_t filled;  // ring holds list entries [cursor, filled)
 };
 
 template <int W>
@@ -82,8 +86,8 @@ struct MatchWave {
     r.hown_lo = k[j].hown_lo;
     r.hown_hi = k[j].hown_hi;
     r.end = k[j].end;
-    r.head_p = k[j].head_p;
-    r.head_g = k[j].head_g;
+    r.head_p = ~k[j].hq;  // 0 -> kNone
+    r.head_g = k[j].cursor < k[j].end ? ring_g[at(lane + 64 * j, k[j].cursor)] : kNone;
     return r;
   }
   __device__ __forceinline__ ClassState state(int j) const {
@@ -94,6 +98,10 @@ struct MatchWave {
     s.hown_lo = holes ? k[j].hown_lo : kNone;
     s.hown_hi = holes ? k[j].hown_hi : kNone;
     return s;
+  }
+  // Generation index of the head of this lane's class j (kNone past the end).
+  __device__ __forceinline__ uint32_t head_g(int j) const {
+    return k[j].cursor < k[j].end ? ring_g[at(lane + 64 * j, k[j].cursor)] : kNone;
   }
   // Robust against arbitrary (speculative or torn) states: indexes are clamped.
   __device__ __forceinline__ void set_state(int j, const ClassState& st, uint32_t c, uint32_t C) {
@@ -112,17 +120,17 @@ struct MatchWave {
       q.cursor = q.lo = q.end = 0;
       q.hown_lo = q.hown_hi = kNone;
     }
-    q.head_p = q.head_g = q.next_p = q.next_g = kNone;
+    q.hq = q.nq = 0;
     q.filled = q.cursor;
   }
   // Wave-uniform: all lanes load list entries [from, to) of class cl (to - from <= 64).
-  // Positions at or after the end of the class's list (`end`) get the sentinel kNone, so
-  // that (head, next) read past the end of a list are "no slot" without a compare.
+  // ring_p holds ~rank. Positions at or after the end of the class's list (`end`) get the
+  // sentinel 0 ("no slot"), so (head, next) read past the end need no compare.
   __device__ __forceinline__ void fill(uint32_t cl, uint32_t from, uint32_t to, uint32_t end) {
     const uint32_t e = from + lane;
     if (e < to) {
       const bool real = e < end;
-      ring_p[at(cl, e)] = real ? list_rank(L, e) : kNone;
+      ring_p[at(cl, e)] = real ? ~list_rank(L, e) : 0u;
       ring_g[at(cl, e)] = real ? L.list_g[e] : kNone;
     }
   }
@@ -138,7 +146,7 @@ struct MatchWave {
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
             const uint32_t e = b0 + u;
-            tp[u] = e < q.end ? list_rank(L, e) : kNone;
+            tp[u] = e < q.end ? ~list_rank(L, e) : 0u;
             tg[u] = e < q.end ? L.list_g[e] : kNone;
           }
 #pragma unroll
@@ -162,18 +170,27 @@ struct MatchWave {
   __device__ __forceinline__ void load_heads(int j) {
     const uint32_t cl = lane + 64 * j;
     LaneClass& q = k[j];
-    q.head_p = ring_p[at(cl, q.cursor)];
-    q.head_g = ring_g[at(cl, q.cursor)];
-    q.next_p = ring_p[at(cl, q.cursor + 1)];
-    q.next_g = ring_g[at(cl, q.cursor + 1)];
+    q.hq = ring_p[at(cl, q.cursor)];
+    q.nq = ring_p[at(cl, q.cursor + 1)];
   }
 };
 
-// bit `lane` of m ? v : kNone — the request's class mask used as a lane mask.
+// bit `lane` of m ? v : 0 — the request's class mask used as a lane mask.
 __device__ __forceinline__ uint32_t select_by_lane_mask(uint64_t m, uint32_t v) {
   uint32_t out;
-  asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(kNone), "v"(v), "s"(m));
+  asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(out) : "v"(v), "s"(m));
   return out;
+}
+
+// Maximum over the 64 lanes (every lane gets it).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, dpp_u32<0x111>(0u, v));       // row_shr:1
+  v = max(v, dpp_u32<0x112>(0u, v));       // row_shr:2
+  v = max(v, dpp_u32<0x114>(0u, v));       // row_shr:4
+  v = max(v, dpp_u32<0x118>(0u, v));       // row_shr:8
+  v = max(v, dpp_u32<0x142, 0xa>(0u, v));  // row_bcast:15
+  v = max(v, dpp_u32<0x143, 0xc>(0u, v));  // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
@@ -182,129 +199,142 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 
 
 // The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs up to
-// n requests i, i+1, ... while each of them is "plain": no eligible class has holes and no
-// eligible class shows a slot of the requestor's own servant at its head. Returns
+// n (>= 1) requests i, i+1, ... while each of them is "plain". Returns
 //   0  n requests done,
-//   1  request i needs the general step (i requests of this call were done).
-// Requests whose eligible classes are all exhausted (or that have none) keep the default
-// result in `res`. The caller guarantees that every ring holds at least n + 2 entries
-// beyond its cursor, so the loop never looks at fill levels.
+//   1  request i needs the general step (the requests before it were done).
+// `special` marks the requests of the block that need a look first: `hole_hit` ones (an
+// eligible class has holes) leave at once; `has_self` ones leave only if an eligible class
+// shows a slot of the requestor's own servant at its head, or if nothing is left for them
+// (last-resort self pick). Requests whose eligible classes are all exhausted keep the
+// default in `res`; a served request gets the global rank of its slot. The caller
+// guarantees that every ring holds at least n + 2 entries beyond its cursor.
 //
-// Per request: the class mask (an aligned SGPR pair, fetched one request ahead in the
-// wait states of the DPP chain) selects the eligible heads, a `steps`-step DPP min over the
-// first 2^steps lanes finds the winner, the winning lane alone (exec = the compare mask)
-// moves (next -> head), starts the LDS read of the entry after next and bumps its cursor;
-// the result is parked in the winner's lane and copied to lane i off the critical path.
-// Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR -> DPP
-// read 2, VALU-written VGPR -> v_readlane 1. s[90:95] are scratch.
-#define YDC_DPP(ctrl) "v_min_u32_dpp %[t], %[t], %[t] " ctrl "\n"
-// After step k: stop when k steps are enough (the compare + branch are the two wait states
-// the next DPP step needs anyway).
-#define YDC_DPP_STOP(k) "s_cmp_eq_u32 %[steps], " #k "\ns_cbranch_scc1 L_red%=\n"
-#define YDC_DPP_SEQ                                                            \
-  YDC_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(1)              \
-  YDC_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(2)              \
-  YDC_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(3)              \
-  YDC_DPP("row_shr:8 row_mask:0xf bank_mask:0xf") YDC_DPP_STOP(4)              \
-  YDC_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf") YDC_DPP_STOP(5)           \
-  YDC_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0\nL_red%=:\n"
+// Registers: hq / nq = ~rank of head / next of the lane's class (0: none), `off` = ring
+// byte offset of `next`, ring_p at LDS `base`, ring_g 8192 bytes further. m0 = i,
+// s[90:91] = class mask of request i (fetched one request ahead, in the wait states of
+// the DPP chain), s[92:93] scratch. One loop body per DPP depth (2^steps >= classes).
+// Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR ->
+// DPP read 2, VALU-written VGPR -> v_readlane 1.
+#define YDC_MAXDPP(first, ctrl) "v_max_u32_dpp %[t], " first " " ctrl " bound_ctrl:0\n"
+#define YDC_GAP "s_nop 1\n"
+#define YDC_RED_1(K) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_2(K) YDC_RED_1(K) "v_readlane_b32 s91, %[mhi], %[ip]\ns_nop 0\n" \
+  YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_3(K) YDC_RED_2(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:4 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_4(K) YDC_RED_3(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_5(K) YDC_RED_4(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+#define YDC_RED_6(K) YDC_RED_5(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+// With one step the second mask word has no gap to hide in.
+#define YDC_TAILFILL_1 "v_readlane_b32 s91, %[mhi], %[ip]\n"
+#define YDC_TAILFILL_N "s_nop 0\n"
 
-#define YDC_FAST_LOOP(NAME)                                                    \
-  __device__ __forceinline__ uint32_t NAME(                                                      \
-      uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,           \
-      uint64_t holes, uint64_t has_self, uint32_t& res, uint32_t& hp, uint32_t& hg,              \
-      uint32_t& np, uint32_t& ng, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4,    \
-      uint32_t steps, uint32_t last) {                                                          \
-    uint32_t status, c, t, a, tkv, mn, tk, win, i1, s0, s1, m0save;                             \
-    asm volatile(                                                                                \
-        "s_mov_b32 %[m0s], m0\n"                                                                 \
-        "s_mov_b32 %[st], 0\n"                                                                   \
-        "s_nop 3\n"                                                                              \
-        "s_cmp_eq_u32 %[n], 0\n"                                                                 \
-        "s_cbranch_scc1 L_out%=\n"                                                               \
-        "v_readlane_b32 s90, %[mlo], %[i]\n"                                                     \
-        "v_readlane_b32 s91, %[mhi], %[i]\n"                                                     \
-        "s_add_u32 %[i1], %[i], 1\n"                                                             \
-        "L_loop%=:\n"                                                                            \
-        "s_and_b64 s[92:93], s[90:91], %[holes]\n"                                               \
-        "s_cbranch_scc1 L_slow%=\n"                                                              \
-        "s_bitcmp1_b64 %[hs], %[i]\n"                                                            \
-        "s_cbranch_scc1 L_self%=\n"                                                              \
-        "L_cont%=:\n"                                                                            \
-        "v_cndmask_b32 %[c], -1, %[hp], s[90:91]\n"                                              \
-        "v_mov_b32 %[t], %[c]\n"                                                                 \
-        "v_readlane_b32 s94, %[mlo], %[i1]\n"                                                    \
-        "v_readlane_b32 s95, %[mhi], %[i1]\n" YDC_DPP_SEQ                                        \
-        "v_readlane_b32 %[mn], %[t], %[last]\n"                                                  \
-        "s_cmp_eq_u32 %[mn], -1\n"                                                               \
-        "s_cbranch_scc1 L_tmo%=\n"                                                               \
-        "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                        \
-        "s_mov_b64 exec, vcc\n"                                                                  \
-        "v_mov_b32 %[tkv], %[hg]\n"                                                              \
-        "s_waitcnt lgkmcnt(0)\n"                                                                 \
-        "v_mov_b32 %[hp], %[np]\n"                                                               \
-        "v_mov_b32 %[hg], %[ng]\n"                                                               \
-        "v_add_u32 %[off], 4, %[off]\n"                                                          \
-        "v_and_b32 %[off], %[rmask4], %[off]\n"                                                  \
-        "v_add_u32 %[a], %[base], %[off]\n"                                                      \
-        "ds_read_b32 %[np], %[a]\n"                                                              \
-        "ds_read_b32 %[ng], %[a] offset:8192\n"                                                  \
-        "v_add_u32 %[cur], 1, %[cur]\n"                                                          \
-        "s_mov_b64 exec, -1\n"                                                                   \
-        "s_ff1_i32_b64 %[win], vcc\n"                                                            \
-        "s_mov_b32 m0, %[i]\n"                                                                   \
-        "v_readlane_b32 %[tk], %[tkv], %[win]\n"                                                 \
-        "s_mov_b64 s[90:91], s[94:95]\n"                                                         \
-        "s_nop 0\n"                                                                              \
-        "v_writelane_b32 %[res], %[tk], m0\n"                                                    \
-        "L_next%=:\n"                                                                            \
-        "s_add_u32 %[i], %[i], 1\n"                                                              \
-        "s_add_u32 %[i1], %[i1], 1\n"                                                            \
-        "s_add_u32 %[n], %[n], -1\n"                                                             \
-        "s_cmp_lg_u32 %[n], 0\n"                                                                 \
-        "s_cbranch_scc1 L_loop%=\n"                                                              \
-        "s_branch L_out%=\n"                                                                     \
-        "L_tmo%=:\n"                                                                             \
-        "s_bitcmp1_b64 %[hs], %[i]\n"                                                            \
-        "s_cbranch_scc1 L_slow%=\n"                                                              \
-        "s_mov_b64 s[90:91], s[94:95]\n"                                                         \
-        "s_branch L_next%=\n"                                                                    \
-        "L_self%=:\n"                                                                            \
-        "v_readlane_b32 %[s0], %[slo], %[i]\n"                                                   \
-        "v_readlane_b32 %[s1], %[shi], %[i]\n"                                                   \
-        "s_sub_u32 %[s1], %[s1], %[s0]\n"                                                        \
-        "v_subrev_u32 %[a], %[s0], %[hg]\n"                                                      \
-        "v_cmp_gt_u32 vcc, %[s1], %[a]\n"                                                        \
-        "s_and_b64 s[92:93], vcc, s[90:91]\n"                                                    \
-        "s_cbranch_scc0 L_cont%=\n"                                                              \
-        "L_slow%=:\n"                                                                            \
-        "s_mov_b32 %[st], 1\n"                                                                   \
-        "L_out%=:\n"                                                                             \
-        "s_waitcnt lgkmcnt(0)\n"                                                                 \
-        "s_mov_b32 m0, %[m0s]\n"                                                                 \
-        : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hp] "+v"(hp),          \
-          [hg] "+v"(hg), [np] "+v"(np), [ng] "+v"(ng), [cur] "+v"(cur), [off] "+v"(off),         \
-          [c] "=&v"(c), [t] "=&v"(t), [a] "=&v"(a), [tkv] "=&v"(tkv), [mn] "=&s"(mn),            \
-          [tk] "=&s"(tk), [win] "=&s"(win), [i1] "=&s"(i1), [s0] "=&s"(s0), [s1] "=&s"(s1),      \
-          [m0s] "=&s"(m0save)                                                                    \
-        : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [holes] "s"(holes),    \
-          [hs] "s"(has_self), [base] "v"(base), [rmask4] "s"(rmask4), [steps] "s"(steps),        \
-          [last] "s"(last)                                                                       \
-        : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95");                     \
-    return status;                                                                               \
-  }
+#define YDC_LOOP_BODY(K, RED, TAILFILL, LASTLANE)                                  \
+  "L" #K "_loop%=:\n"                                                              \
+  "s_bitcmp1_b64 %[special], m0\n"                                                 \
+  "s_cbranch_scc1 L" #K "_special%=\n"                                             \
+  "L" #K "_cont%=:\n"                                                              \
+  "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                       \
+  "s_add_u32 %[ip], %[ip], 1\n"                                                    \
+  "v_readlane_b32 s90, %[mlo], %[ip]\n" RED TAILFILL                               \
+  "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                     \
+  "s_cmp_eq_u32 %[mn], 0\n"                                                        \
+  "s_cbranch_scc1 L" #K "_tmo%=\n"                                                 \
+  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                \
+  "s_not_b32 %[sp], %[mn]\n"                                                       \
+  "s_mov_b64 exec, vcc\n"                                                          \
+  "s_waitcnt lgkmcnt(0)\n"                                                         \
+  "v_mov_b32 %[hq], %[nq]\n"                                                       \
+  "v_add_u32 %[off], 4, %[off]\n"                                                  \
+  "v_and_b32 %[off], %[rmask4], %[off]\n"                                          \
+  "v_add_u32 %[a], %[base], %[off]\n"                                              \
+  "ds_read_b32 %[nq], %[a]\n"                                                      \
+  "v_add_u32 %[cur], 1, %[cur]\n"                                                  \
+  "s_mov_b64 exec, -1\n"                                                           \
+  "v_writelane_b32 %[res], %[sp], m0\n"                                            \
+  "L" #K "_next%=:\n"                                                              \
+  "s_add_u32 m0, m0, 1\n"                                                          \
+  "s_add_u32 %[n], %[n], -1\n"                                                     \
+  "s_cbranch_scc1 L" #K "_loop%=\n"                                                \
+  "s_branch L_out%=\n"                                                             \
+  "L" #K "_tmo%=:\n"                                                               \
+  "s_bitcmp1_b64 %[hs], m0\n"                                                      \
+  "s_cbranch_scc0 L" #K "_next%=\n"                                                \
+  "s_branch L_slow%=\n"                                                            \
+  "L" #K "_special%=:\n"                                                           \
+  "s_bitcmp1_b64 %[hh], m0\n"                                                      \
+  "s_cbranch_scc1 L_slow%=\n"                                                      \
+  "v_readlane_b32 %[s0], %[slo], m0\n"                                             \
+  "v_readlane_b32 %[s1], %[shi], m0\n"                                             \
+  "v_add_u32 %[a], -4, %[off]\n"                                                   \
+  "v_and_b32 %[a], %[rmask4], %[a]\n"                                              \
+  "v_add_u32 %[a], %[base], %[a]\n"                                                \
+  "ds_read_b32 %[a], %[a] offset:8192\n"                                           \
+  "s_sub_u32 %[s1], %[s1], %[s0]\n"                                                \
+  "s_waitcnt lgkmcnt(0)\n"                                                         \
+  "v_subrev_u32 %[a], %[s0], %[a]\n"                                               \
+  "v_cmp_gt_u32 vcc, %[s1], %[a]\n"                                                \
+  "s_and_b64 s[92:93], vcc, s[90:91]\n"                                            \
+  "s_cbranch_scc0 L" #K "_cont%=\n"                                                \
+  "s_branch L_slow%=\n"
 
-YDC_FAST_LOOP(match_fast_loop)
+__device__ __forceinline__ uint32_t match_fast_loop(
+    uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
+    uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& res, uint32_t& hq,
+    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4, uint32_t steps) {
+  uint32_t status, c, t, a, mn, sp, ip, s0, s1, m0save;
+  asm volatile(
+      "s_mov_b32 %[m0s], m0\n"
+      "s_mov_b32 %[st], 0\n"
+      "s_mov_b32 m0, %[i]\n"
+      "s_add_u32 %[ip], %[i], 0\n"
+      "s_add_u32 %[n], %[n], -1\n"
+      "s_nop 2\n"
+      "v_readlane_b32 s90, %[mlo], %[ip]\n"
+      "v_readlane_b32 s91, %[mhi], %[ip]\n"
+      "s_cmp_eq_u32 %[steps], 1\n"
+      "s_cbranch_scc1 L1_loop%=\n"
+      "s_cmp_eq_u32 %[steps], 2\n"
+      "s_cbranch_scc1 L2_loop%=\n"
+      "s_cmp_eq_u32 %[steps], 3\n"
+      "s_cbranch_scc1 L3_loop%=\n"
+      "s_cmp_eq_u32 %[steps], 4\n"
+      "s_cbranch_scc1 L4_loop%=\n"
+      "s_cmp_eq_u32 %[steps], 5\n"
+      "s_cbranch_scc1 L5_loop%=\n"
+      "s_branch L6_loop%=\n"
+      YDC_LOOP_BODY(1, YDC_RED_1(1), YDC_TAILFILL_1, "1")
+      YDC_LOOP_BODY(2, YDC_RED_2(2), YDC_TAILFILL_N, "3")
+      YDC_LOOP_BODY(3, YDC_RED_3(3), YDC_TAILFILL_N, "7")
+      YDC_LOOP_BODY(4, YDC_RED_4(4), YDC_TAILFILL_N, "15")
+      YDC_LOOP_BODY(5, YDC_RED_5(5), YDC_TAILFILL_N, "31")
+      YDC_LOOP_BODY(6, YDC_RED_6(6), YDC_TAILFILL_N, "63")
+      "L_slow%=:\n"
+      "s_mov_b32 %[st], 1\n"
+      "L_out%=:\n"
+      "s_mov_b32 %[i], m0\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_mov_b32 m0, %[m0s]\n"
+      : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hq] "+v"(hq), [nq] "+v"(nq),
+        [cur] "+v"(cur), [off] "+v"(off), [c] "=&v"(c), [t] "=&v"(t), [a] "=&v"(a), [mn] "=&s"(mn),
+        [sp] "=&s"(sp), [ip] "=&s"(ip), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
+      : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [special] "s"(special),
+        [hh] "s"(hole_hit), [hs] "s"(has_self), [base] "v"(base), [rmask4] "s"(rmask4),
+        [steps] "s"(steps)
+      : "vcc", "scc", "memory", "s90", "s91", "s92", "s93");
+  return status;
+}
 
 template <int W>
 __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
                                                    MatchBuffers B, uint32_t pass,
-                                                   uint32_t device_check, uint32_t rshift,
+                                                   uint32_t flags, uint32_t rshift,
                                                    uint32_t init_fill, DeviceParams* prm) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
   if (prm->need_shared) return;  // the batch went through the sequential path
   // An earlier pass found every chunk consistent: nothing to do.
+  const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
+  const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
   if (device_check && pass > 0 && prm->n_changed[(pass - 1) & (kPassSlots - 1)] == 0) return;
   const uint32_t lane = threadIdx.x;
   uint32_t kc = blockIdx.x;  // chunk
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     const ClassState* start;
     if (pass == 0) {
       start = B.guess0 + (size_t)kc * C;
-      if (kc == 0 && lane == 0) atomicAdd(&prm->n_changed[0], 1u);  // pass 0 always has work
+      if (kc == 0 && lane == 0) prm->n_changed[0] = 1;  // pass 0 always has work
     } else {
       if (kc == 0 && !multi) return;  // chunk 0 started from the true state
       start = kc == 0 ? B.boundary_in : B.endst + (size_t)(kc - 1) * C;
@@ -353,7 +383,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       // Inconsistent: this pass has work. One wave per chunk and pass.
       uint32_t taken = 0;
       if (lane == 0) {
-        atomicAdd(&prm->n_changed[pass & (kPassSlots - 1)], 1u);
+        // "this pass had work": everybody stores the same 1 (no same-address atomics).
+        prm->n_changed[pass & (kPassSlots - 1)] = 1;
         taken = atomicMax(&B.claim[kc], stamp) == stamp;
       }
       if (readlane_u32(taken, 0)) return;  // a wave following its chain got here first
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           mw[j] = ((uint64_t)readlane_u32(mhi[j], i) << 32) | readlane_u32(mlo[j], i);
         const uint32_t self_lo = readlane_u32(slo, i);
         const uint32_t self_hi = readlane_u32(shi, i);
-        uint32_t bp = kNone, bi = 0, bg = 0;
+        uint32_t bp = kNone, bi = 0;
         int bj = 0;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
@@ -497,13 +528,13 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             if (class_candidate(L, w.as_run(j), self_lo, self_hi, ci, cp, cg) && cp < bp) {
               bp = cp;
               bi = ci;
-              bg = cg;
               bj = j;
             }
           }
         }
         const uint32_t mn = wave_min_u32(bp);
         uint64_t winners;
+        uint32_t self_rank = kNone;
         if (mn != kNone) {
           winners = __ballot(bp == mn);
         } else {
@@ -516,8 +547,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
                 if (class_self_candidate(L, w.as_run(j), self_lo, self_hi, ci, cg)) {
                   ok = true;
                   bi = ci;
-                  bg = cg;
                   bj = j;
+                  self_rank = list_rank(L, ci);
                 }
               }
             }
@@ -526,7 +557,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
         if (winners == 0) return;  // Timeout (res default) — or no class at all (fixed below)
         const uint32_t win = (uint32_t)__builtin_ctzll(winners);
-        const uint32_t taken = readlane_u32(bg, win);
+        // The result of a request is the global rank of its slot.
+        const uint32_t taken = mn != kNone ? mn : readlane_u32(self_rank, win);
         res = lane == i ? taken : res;
         bool moved = false;
         if (lane == win) {
@@ -562,14 +594,17 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         LaneClass& q = w.k[0];
         const uint32_t base = (uint32_t)(uintptr_t)lds_ring + ((lane << rshift) << 2);
         const uint32_t rmask4 = (R << 2) - 1;
+        const uint64_t my_mask = ((uint64_t)mhi[0] << 32) | mlo[0];
         uint32_t i = 0;
         while (i < cnt) {
           const uint32_t budget = top_up();
           const uint32_t n = min(cnt - i, budget);
           const uint32_t off = ((q.cursor + 1) & w.rmask) << 2;  // ring offset of `next`
-          const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, holes[0], has_self, res,
-                                              q.head_p, q.head_g, q.next_p, q.next_g, q.cursor, off,
-                                              base, rmask4, steps, (1u << steps) - 1);
+          // Requests that need a look before the plain step.
+          const uint64_t hole_hit = holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull;
+          const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
+                                              hole_hit, has_self, res, q.hq, q.nq, q.cursor, off,
+                                              base, rmask4, steps);
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
           if (st == 1) {
@@ -598,27 +633,24 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             bool own = false;  // an eligible class shows a slot of the requestor's own servant
 #pragma unroll
             for (int j = 0; j < W; ++j)
-              own |= ((mw[j] >> lane) & 1u) && (w.k[j].head_g - self_lo < self_len);
+              own |= ((mw[j] >> lane) & 1u) && (w.head_g(j) - self_lo < self_len);
             general = __ballot(own) != 0;
           }
           if (!general) {
-            uint32_t bp = select_by_lane_mask(mw[0], w.k[0].head_p);
-            uint32_t bg = w.k[0].head_g;
+            uint32_t bp = select_by_lane_mask(mw[0], w.k[0].hq);
             int bj = 0;
 #pragma unroll
             for (int j = 1; j < W; ++j) {
-              const uint32_t c = select_by_lane_mask(mw[j], w.k[j].head_p);
-              if (c < bp) {
+              const uint32_t c = select_by_lane_mask(mw[j], w.k[j].hq);
+              if (c > bp) {
                 bp = c;
-                bg = w.k[j].head_g;
                 bj = j;
               }
             }
-            const uint32_t mn = wave_min_u32(bp);
-            if (mn != kNone) {
-              const uint32_t win = (uint32_t)__builtin_ctzll(__ballot(bp == mn));
-              const uint32_t taken = readlane_u32(bg, win);
-              res = lane == i ? taken : res;
+            const uint32_t mx = wave_max_u32(bp);  // ~rank: the largest is the best slot
+            if (mx != 0) {
+              const uint32_t win = (uint32_t)__builtin_ctzll(__ballot(bp == mx));
+              res = lane == i ? ~mx : res;
               if (lane == win) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
@@ -627,10 +659,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
                     const uint32_t cur = q.cursor + 1;
                     q.cursor = cur;
                     q.lo = cur;
-                    q.head_p = q.next_p;
-                    q.head_g = q.next_g;
-                    q.next_p = w.ring_p[w.at(lane + 64 * j, cur + 1)];
-                    q.next_g = w.ring_g[w.at(lane + 64 * j, cur + 1)];
+                    q.hq = q.nq;
+                    q.nq = w.ring_p[w.at(lane + 64 * j, cur + 1)];
                   }
                 }
               }
@@ -649,7 +679,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       if (many == 0) res = kIdxEnvNotFound;
       if (tl < t1) B.slot_of[tl] = res;
     }
-    if (lane == 0) atomicAdd(&prm->chunk_sims, 1u);
+    if (count_sims && lane == 0) atomicAdd(&prm->chunk_sims, 1u);
     if (stopped_early) return;  // same remainder as last time: the end state stands
 
     // ---- end state ----

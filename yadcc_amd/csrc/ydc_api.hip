@@ -57,6 +57,7 @@ struct BatchPlan {
   ClassLists L{};
   TaskTable T{};
   MatchBuffers mb{};
+  const uint32_t* rank_to_g = nullptr;  // slots in key order (before the class partition)
 };
 }  // namespace
 
@@ -84,6 +85,8 @@ struct ydc_context {
   DevBuf<uint32_t> d_slot_base, d_cls_begin, d_vals[2], d_hist, d_row_total;
   DevBuf<uint64_t> d_keys[2];  // viewed as u32 when the key fits
   DevBuf<uint16_t> d_cls_by_g;
+  DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
+  DevBuf<uint8_t> d_consumed;   // slot taken by a request of this batch
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
   DevBuf<uint32_t> d_running_out;
@@ -397,6 +400,8 @@ int ydc_destroy(ydc_context* c) {
     b->release();
   for (auto* b : {&c->d_cls_env, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
   c->d_cls_by_g.release();
+  c->d_owner.release();
+  c->d_consumed.release();
   c->d_guess[0].release();
   c->d_guess[1].release();
   c->d_endst.release();
@@ -595,6 +600,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_vals[1].reserve(slot_bound));
   HIP_TRY(c, c->d_hist.reserve(((size_t)1 << kMaxRadixBits) * p.n_tiles));
   if (C > 1) HIP_TRY(c, c->d_cls_by_g.reserve(slot_bound));
+  HIP_TRY(c, c->d_owner.reserve(slot_bound));
+  HIP_TRY(c, c->d_consumed.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
   HIP_TRY(c, c->d_self_lo.reserve(N));
   HIP_TRY(c, c->d_self_hi.reserve(N));
@@ -627,6 +634,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   }
   // The sort ping-pongs between the two key/value buffers: where the lists end up.
   const int cur = (int)(((slot_bound ? p.key_passes : 0) + p.cls_passes) & 1);
+  p.rank_to_g = c->d_vals[(slot_bound ? p.key_passes : 0) & 1].p;
   p.L.n_classes = C;
   p.L.cls_begin = c->d_cls_begin.p;
   p.L.list_p = p.cls_passes ? (const uint32_t*)c->d_keys[cur].p : nullptr;
@@ -673,11 +681,11 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
     if (p.key32) {
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks), dim3(256), 0, st, p.sv,
                  c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint32_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr);
+                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p);
     } else {
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks), dim3(256), 0, st, p.sv,
                  c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint64_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr);
+                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p);
     }
   }
   mark(c, 2);
@@ -715,7 +723,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
                c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
                c->d_chunk_consuming.p, prm);
     YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, c->d_chunk_consuming.p, K,
-               c->d_before.p);
+               c->d_before.p, prm);
   }
   return YDC_OK;
 }
@@ -758,6 +766,7 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
 // found every chunk consistent.
 void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t device_check) {
   const size_t lds = 16384;
+  device_check |= c->debug_sim ? 2u : 0u;
   DeviceParams* prm = c->d_prm.p;
   if (p.W == 1) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
@@ -777,14 +786,17 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
                      double* d_out_util, uint32_t* d_out_running, uint32_t check_slot) {
   hipStream_t st = c->stream;
   const uint32_t S = p.S, N = p.N;
-  if (S) HIP_TRY(c, hipMemcpyAsync(c->d_running_out.p, c->d_running.p, (size_t)S * 4,
-                                   hipMemcpyDeviceToDevice, st));
   if (N) {
     YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(ceil_div(N, 256)), dim3(256), 0, st, p.sv,
-               c->d_slot_base.p, c->d_slot_of.p, N, d_out_idx, d_out_util, c->d_running_out.p,
-               check_slot, c->d_prm.p);
+               c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N,
+               p.wave_path ? 1u : 0u, d_out_idx, d_out_util, c->d_consumed.p, check_slot, c->d_prm.p);
   }
-  // Not converged yet: k_finalize returned at once, running_out == running and the copies
+  if (S) {
+    YDC_LAUNCH(c, "k_running_out", k_running_out, dim3(ceil_div(S, 256)), dim3(256), 0, st,
+               c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p, check_slot,
+               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p);
+  }
+  // Not converged yet: both kernels did nothing (running_out == running) and the copies
   // below change nothing; they are repeated after the extra passes.
   if ((flags & YDC_DISPATCH_COMMIT) && S)
     HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
@@ -830,9 +842,11 @@ void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   s.n_chunks = p.K;
   s.rounds = rounds;
   s.chunk_sims = c->h_prm->chunk_sims;
+  // Every request is exactly one of: granted, Timeout (eligible classes exist but are full),
+  // EnvironmentNotFound (no eligible class).
   s.granted = c->h_prm->granted;
-  s.timeouts = c->h_prm->timeouts;
-  s.env_not_found = c->h_prm->env_not_found;
+  s.env_not_found = p.N - std::min(p.N, c->h_prm->consuming);
+  s.timeouts = p.N - s.env_not_found - std::min(p.N - s.env_not_found, s.granted);
 }
 
 // Passes [launched, ...) in groups until one finds every chunk consistent, each group
