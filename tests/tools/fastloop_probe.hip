@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
   // ring: class c entry e has rank e * n_classes + c (round robin), all resident.
   for (uint32_t e = 0; e < R; ++e) {
     if (lane < n_classes) {
-      lds[(lane << rshift) + e] = e * n_classes + lane;
+      lds[(lane << rshift) + e] = ~(e * n_classes + lane);
       lds[2048 + (lane << rshift) + e] = 1000 + e * n_classes + lane;
     }
   }
@@ -22,9 +22,9 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
   uint64_t t_asm = 0;
   const uint64_t t0 = __builtin_readcyclecounter();
   for (uint32_t b = 0; b < blocks; ++b) {
-    uint32_t hp = lane < n_classes ? lane : kNone, hg = 1000 + lane, np = n_classes + lane,
-             ng = 1000 + n_classes + lane, cur = 0, res = kIdxTimeout;
-    if (lane >= n_classes) hp = hg = np = ng = kNone;
+    // inverted ranks: class c entry e has rank e * n_classes + c
+    uint32_t hq = lane < n_classes ? ~lane : 0u, nq = lane < n_classes ? ~(n_classes + lane) : 0u;
+    uint32_t cur = 0, res = kIdxTimeout;
     uint32_t i = 0;
     const uint32_t mlo = n_classes >= 32 ? 0xFFFFFFFFu : ((1u << n_classes) - 1);
     const uint32_t mhi = n_classes > 32 ? (n_classes >= 64 ? 0xFFFFFFFFu : (1u << (n_classes - 32)) - 1) : 0;
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
     while ((1u << steps) < n_classes) ++steps;
     const uint64_t a = __builtin_readcyclecounter();
     // 20 requests per block: at most 20 picks per class, the ring (32) never wraps.
-    uint32_t st = match_fast_loop(i, 20, mlo, mhi, kNone, kNone, 0ull, 0ull, res, hp, hg, np, ng, cur,
+    uint32_t st = match_fast_loop(i, 20, mlo, mhi, kNone, kNone, 0ull, 0ull, 0ull, res, hq, nq, cur,
                                   4u, (uint32_t)(uintptr_t)lds + ((lane << rshift) << 2), R * 4 - 1,
-                                  steps, (1u << steps) - 1);
+                                  steps);
     t_asm += __builtin_readcyclecounter() - a;
     total_i += i + st + (res & 1);
   }
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
 int main() {
   uint64_t* d;
   hipMalloc(&d, 64);
-  for (uint32_t nc : {2u, 30u, 64u}) {
+  for (uint32_t nc : {2u, 16u, 30u, 64u}) {
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(probe, dim3(1), dim3(64), 16384, 0, nc, 2000u, d);
       hipDeviceSynchronize();

@@ -33,6 +33,36 @@ def pmc(path):
     return "\n".join(out)
 
 
+def plain(name):
+    """void ydc::k_match_pass<1>(...) -> k_match_pass (the name bench.py uses)."""
+    n = short(name)
+    n = n.split("<")[0]
+    return n.split("::")[-1].strip()
+
+
+def hbmjson(fetch_db, write_db):
+    """HBM bytes per launch per kernel from the two PMC passes. FETCH_SIZE / WRITE_SIZE are
+    reported in KB; gfx950: FETCH_SIZE reports exactly half the bytes of wide coalesced
+    streaming reads (MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is taken
+    as reported (uncalibrated)."""
+    import json
+    out = {}
+    q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+         "where counter_name = ? group by kernel_name")
+    for db, counter, key in ((fetch_db, "FETCH_SIZE", "fetch_kb"), (write_db, "WRITE_SIZE", "write_kb")):
+        for n, c, a, d in sqlite3.connect(db).execute(q, (counter,)):
+            e = out.setdefault(plain(n), {"launches_profiled": c, "avg_ns": d})
+            e[key] = e.get(key, 0.0) + a  # template instances of one kernel are merged
+    for e in out.values():
+        e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e.get("fetch_kb", 0.0) + e.get("write_kb", 0.0))
+    return json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+                       "correction": "hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes)",
+                       "kernels": out}, indent=1)
+
+
 if __name__ == "__main__":
-    mode, path = sys.argv[1], sys.argv[2]
-    print(stats(path) if mode == "stats" else pmc(path))
+    mode = sys.argv[1]
+    if mode == "hbmjson":
+        print(hbmjson(sys.argv[2], sys.argv[3]))
+    else:
+        print(stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2]))
