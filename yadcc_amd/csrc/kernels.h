@@ -34,7 +34,7 @@ struct DeviceParams {
   uint32_t n_slots;       // M: free slots of this batch
   uint32_t overflow;      // M exceeded the workspace
   uint32_t need_shared;   // some task's host runs several servants
-  uint32_t n_changed[64]; // end states changed in round r, at index r & 63 (match_kernel.h)
+  uint32_t n_changed[64]; // pass r (index r & 63) changed some chunk's end state: not final yet
   uint32_t chunk_sims;    // chunk simulations executed (all rounds)
   uint32_t granted;       // requests that got a slot (k_running_out)
   uint32_t consuming;     // requests with at least one eligible class (k_chunk_prefix)
@@ -115,7 +115,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
                                                        uint32_t max_slots, uint32_t* slot_base,
-                                                       uint32_t* cls_begin, DeviceParams* prm) {
+                                                       uint32_t* cls_begin, uint32_t* chunk_consuming,
+                                                       uint32_t n_chunks, DeviceParams* prm) {
+  // Per-batch reset of the request-side counters (saves a memset launch).
+  for (uint32_t k = threadIdx.x; k < n_chunks; k += blockDim.x) chunk_consuming[k] = 0;
   __shared__ uint32_t lds[17];
   __shared__ uint32_t carry;
   extern __shared__ uint32_t cls_cnt[];  // n_classes + 1
@@ -542,7 +545,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
 // are a prefix of its slot range: binary search for the first free one.
 __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, const uint32_t* slot_base,
                                                      const uint8_t* consumed, uint32_t n_servants,
-                                                     uint32_t* running_out, uint32_t check_slot,
+                                                     uint32_t* running_out, uint32_t* out_a,
+                                                     uint32_t* out_b, uint32_t check_slot,
                                                      uint32_t count_all, DeviceParams* prm) {
   __shared__ uint32_t lds[17];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,7 +565,14 @@ __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, co
       taken = lo - b;
     }
   }
-  if (s < n_servants) running_out[s] = running[s] + taken;
+  if (s < n_servants) {
+    // out_a / out_b (nullable): the caller's copy and, when committing, the resident column
+    // itself (same index read and written by this thread only).
+    const uint32_t v = running[s] + taken;
+    running_out[s] = v;
+    if (out_a) out_a[s] = v;
+    if (out_b) out_b[s] = v;
+  }
   // One counter update per workgroup (same-address atomics serialise at ~10 ns each).
   uint32_t total;
   (void)block_exclusive_scan(taken, lds, &total);

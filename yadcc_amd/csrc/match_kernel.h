@@ -15,11 +15,12 @@
 //            wave carries on into chunk k+1 unless another wave has claimed it
 //            in this pass — a perturbation that needs thousands of requests to
 //            die out is followed by one wave instead of one launch per chunk.
-//   A pass that finds every chunk consistent changes nothing and proves that
-//   every chunk was replayed from its predecessor's final state: the result is
-//   the sequential one (chunk 0 always starts from the true state). The host
-//   pre-launches a few passes; a pass returns at once when an earlier one found
-//   nothing to do, and k_finalize only runs behind such a pass.
+//   A pass in which no chunk's end state changed (pass 0: every end state equals the
+//   next chunk's level guess) proves that every chunk's last replay started from its
+//   predecessor's final end state: the result is the sequential one (chunk 0 always
+//   starts from the true state). Such a pass leaves its flag in DeviceParams::
+//   n_changed at 0. The host pre-launches a few passes; a pass returns at once when
+//   an earlier one already was final, and k_finalize only runs behind a final pass.
 //
 // End states are updated in place. A wave that reads its predecessor's end
 // state while that is being rewritten replays from a mixed (meaningless but
@@ -56,6 +57,7 @@ struct MatchBuffers {
   // Multi-GPU: this rank's chunks continue the previous rank's. boundary_in (C
   // entries, or NULL) is the end state of the predecessor's last chunk.
   const ClassState* boundary_in;
+  uint32_t has_successor;  // multi-GPU: another rank continues after this rank's last chunk
 };
 
 // Everything a lane keeps about one of its classes.
@@ -134,9 +136,43 @@ struct MatchWave {
       ring_g[at(cl, e)] = real ? L.list_g[e] : kNone;
     }
   }
-  // First fill: every lane loads `n` (<= R) entries of its own classes,
-  // 16 independent loads in flight per lane and array.
+  // First fill, n (<= R) entries per class. Few classes (C * ceil(n / 64) <= 16): one
+  // coalesced 64-entry load per class and 64 entries, all of them in flight before the
+  // first LDS store — one memory round trip. Otherwise every lane loads the entries of its
+  // own classes, 16 independent loads in flight per lane and array.
   __device__ __forceinline__ void init_rings(uint32_t C, uint32_t n, int W_) {
+    const uint32_t per = (n + 63) / 64;
+    if (W_ == 1 && C * per <= 16) {
+      uint32_t tp[16], tg[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        tp[u] = 0;
+        tg[u] = kNone;
+        if ((uint32_t)u < C * per) {
+          const uint32_t cc = (uint32_t)u / per, part = (uint32_t)u % per;
+          const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)k[0].cursor, (int)cc);
+          const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)k[0].end, (int)cc);
+          const uint32_t e = cur + part * 64 + lane;
+          if (e < end && part * 64 + lane < n) {
+            tp[u] = ~list_rank(L, e);
+            tg[u] = L.list_g[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if ((uint32_t)u < C * per) {
+          const uint32_t cc = (uint32_t)u / per, part = (uint32_t)u % per;
+          const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)k[0].cursor, (int)cc);
+          if (part * 64 + lane < n) {
+            ring_p[at(cc, cur + part * 64 + lane)] = tp[u];
+            ring_g[at(cc, cur + part * 64 + lane)] = tg[u];
+          }
+        }
+      }
+      if (lane < C) k[0].filled = k[0].cursor + n;
+      return;
+    }
     for (int j = 0; j < W_; ++j) {
       const uint32_t cl = lane + 64 * j;
       LaneClass& q = k[j];
@@ -359,7 +395,6 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     const ClassState* start;
     if (pass == 0) {
       start = B.guess0 + (size_t)kc * C;
-      if (kc == 0 && lane == 0) prm->n_changed[0] = 1;  // pass 0 always has work
     } else {
       if (kc == 0 && !multi) return;  // chunk 0 started from the true state
       start = kc == 0 ? B.boundary_in : B.endst + (size_t)(kc - 1) * C;
@@ -382,11 +417,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       if (__ballot(differs) == 0) return;  // consistent
       // Inconsistent: this pass has work. One wave per chunk and pass.
       uint32_t taken = 0;
-      if (lane == 0) {
-        // "this pass had work": everybody stores the same 1 (no same-address atomics).
-        prm->n_changed[pass & (kPassSlots - 1)] = 1;
-        taken = atomicMax(&B.claim[kc], stamp) == stamp;
-      }
+      if (lane == 0) taken = atomicMax(&B.claim[kc], stamp) == stamp;
       if (readlane_u32(taken, 0)) return;  // a wave following its chain got here first
     }
   }
@@ -692,6 +723,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         ClassState* e = B.endst + (size_t)kc * C + c;
         if (pass == 0) {
           *e = s;
+          // Is the next chunk's level guess what this chunk really ends in?
+          if (kc + 1 < n_chunks) differs |= !class_state_equal(B.guess0[(size_t)(kc + 1) * C + c], s);
         } else {
           const ClassState old = *e;
           if (!class_state_equal(old, s)) {
@@ -701,8 +734,13 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
       }
     }
+    bool changed = __ballot(differs) != 0;
+    // The first chunk of the next rank starts from a guess of its own in pass 0.
+    if (pass == 0 && kc + 1 == n_chunks && B.has_successor) changed = true;
+    // "Not final yet": everybody stores the same 1 (no same-address atomics).
+    if (changed && lane == 0) prm->n_changed[pass & (kPassSlots - 1)] = 1;
     if (pass == 0) return;
-    if (__ballot(differs) == 0) return;  // nothing downstream is affected
+    if (!changed) return;  // nothing downstream is affected
     // The next chunk is now inconsistent. Follow the chain unless its own wave (or
     // another follower) has it in this pass; then the next pass picks it up.
     if (kc + 1 >= n_chunks) return;

@@ -657,6 +657,10 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.init_fill = 8;
     while (p.init_fill < want && p.init_fill < 64) p.init_fill <<= 1;
     p.init_fill = std::min(std::max(p.init_fill, 32u), R);
+    // Few classes: the first fill is one coalesced load per class and 64 entries; take
+    // enough for a whole block of 64 requests from one class.
+    if (C <= 8) p.init_fill = std::min(128u, R);
+    else if (C <= 16) p.init_fill = std::min(64u, R);
   }
   return YDC_OK;
 }
@@ -670,7 +674,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   mark(c, 0);
   // ---- servant scan (also resets the per-batch device counters)
   YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (C + 1) * sizeof(uint32_t), st,
-             p.sv, C, p.slot_bound, c->d_slot_base.p, c->d_cls_begin.p, prm);
+             p.sv, C, p.slot_bound, c->d_slot_base.p, c->d_cls_begin.p, c->d_chunk_consuming.p, K, prm);
   mark(c, 1);
   // ---- slot generation
   void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
@@ -716,7 +720,6 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   mark(c, 4);
   // ---- request classification + level guesses
   if (N) {
-    HIP_TRY(c, hipMemsetAsync(c->d_chunk_consuming.p, 0, (size_t)K * 4, st));
     TaskColumns cols{tk->env_id, tk->min_version, tk->requestor_ip};
     YDC_LAUNCH(c, "k_task_classify", k_task_classify, dim3(ceil_div(N, 256)), dim3(256), 0, st, cols, N,
                c->d_cls_env.p, c->d_cls_ver.p, C, W, c->d_ip_sorted.p, c->d_ip_servant.p, S,
@@ -792,18 +795,13 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
                p.wave_path ? 1u : 0u, d_out_idx, d_out_util, c->d_consumed.p, check_slot, c->d_prm.p);
   }
   if (S) {
+    // Also writes the caller's copy and (COMMIT) the resident column; when the passes have not
+    // converged yet it writes running unchanged everywhere and is repeated later.
     YDC_LAUNCH(c, "k_running_out", k_running_out, dim3(ceil_div(S, 256)), dim3(256), 0, st,
-               c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p, check_slot,
+               c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p,
+               d_out_running, (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr, check_slot,
                c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p);
   }
-  // Not converged yet: both kernels did nothing (running_out == running) and the copies
-  // below change nothing; they are repeated after the extra passes.
-  if ((flags & YDC_DISPATCH_COMMIT) && S)
-    HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
-                              hipMemcpyDeviceToDevice, st));
-  if (d_out_running && S)
-    HIP_TRY(c, hipMemcpyAsync(d_out_running, c->d_running_out.p, (size_t)S * 4,
-                              hipMemcpyDeviceToDevice, st));
   return YDC_OK;
 }
 
@@ -873,7 +871,7 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
     if (done < 0) return done;
     if (done) {
       if (c->debug_sim) {
-        fprintf(stderr, "[ydc match] K=%u cs=%u R=%u fill=%u rounds=%u sims=%u busy chunks:", p.K,
+        fprintf(stderr, "[ydc match] K=%u cs=%u R=%u fill=%u rounds=%u sims=%u pass changed ends:", p.K,
                 p.cs, 1u << p.rshift, p.init_fill, *rounds, c->h_prm->chunk_sims);
         for (uint32_t r = 0; r < *rounds; ++r) fprintf(stderr, " %u", c->h_prm->n_changed[r & 63]);
         fprintf(stderr, "\n");
@@ -1214,6 +1212,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   DeviceParams* prm = c->d_prm.p;
   // The chunks of this rank continue the previous rank's.
   p.mb.boundary_in = g.rank > 0 ? g.d_bounds.p + (size_t)(g.rank - 1) * rec : nullptr;
+  p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
 
   if (int rc = enqueue_front_a(c, p, tk)) return rc;
   if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, 4, st));  // before[K == 0] = total = 0
