@@ -25,8 +25,7 @@
 namespace ydc {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 8;
-constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 slots per workgroup
+constexpr int kSortItems = 8;  // most; a pass may use fewer (SortIn::items) for more, smaller tiles
 constexpr int kSortWaves = kSortThreads / 64;
 
 // Device-resident scalars produced and consumed by the kernels.
@@ -205,6 +204,7 @@ struct SortIn {
   const uint16_t* cls_by_g; // non-NULL in the class pass
   uint32_t shift;
   uint32_t bits;            // digit width of this pass
+  uint32_t items;           // elements per thread (tile = 256 * items), <= kSortItems
 };
 
 template <typename KeyT>
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in,
   const uint32_t tile = blockIdx.x;
   for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) h[d] = 0;
   __syncthreads();
-  const uint32_t base = tile * kSortTile;
+  const uint32_t base = tile * (kSortThreads * in.items);
   if (base < M) {
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
       uint32_t i = base + j * kSortThreads + threadIdx.x;
-      if (i < M) {
+      if ((uint32_t)j < in.items && i < M) {
         KeyT key = in.keys ? in.keys[i] : (KeyT)i;
         uint32_t d = sort_digit(in, i, key, in.vals[i]);
         atomicAdd(&h[d], 1u);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t n_tiles, uint32_t* 
   if (threadIdx.x == 0) row_total[blockIdx.x] = total;
 }
 
-// Scatter. Within a tile, wave w owns elements [w*512, (w+1)*512) and walks them
+// Scatter. Within a tile, wave w owns items*64 consecutive elements and walks them
 // 64 at a time, so (tile, wave, round, lane) order == index order and the rank of
 // an element among equal digits is: digit start + earlier tiles (scanned hist) +
 // earlier waves + earlier rounds of this wave + lower lanes with the same digit
@@ -278,9 +278,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   uint32_t* dstart = sm + kSortWaves * radix;
   const uint32_t M = prm->n_slots;
   const uint32_t tile = blockIdx.x;
-  const uint32_t base = tile * kSortTile;
+  const uint32_t base = tile * (kSortThreads * in.items);
   if (base >= M) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wave_span = in.items * 64;  // consecutive elements a wave owns
   {
     // Start of every digit: exclusive scan of the row totals (each thread owns
     // radix / 256 consecutive digits) + the elements of earlier tiles.
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   uint32_t* wcnt = cnt + wave * radix;
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
-    const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
-    const bool valid = i < M;
+    const uint32_t i = base + wave * wave_span + j * 64 + lane;
+    const bool valid = (uint32_t)j < in.items && i < M;
     key[j] = 0;
     val[j] = 0;
     uint32_t d = 0;
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
-    const uint32_t i = base + wave * (kSortItems * 64) + j * 64 + lane;
-    if (i < M) {
+    const uint32_t i = base + wave * wave_span + j * 64 + lane;
+    if ((uint32_t)j < in.items && i < M) {
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       out_keys[pos] = (OutKeyT)key[j];
       out_vals[pos] = val[j];

@@ -51,7 +51,7 @@ namespace {
 // Sizes, workspace views and kernel argument blocks of one batch (plan_batch).
 struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
-  uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8;
+  uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
   ServantTable sv{};
   ClassLists L{};
@@ -579,7 +579,11 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     return fail(c, YDC_ERR_CAPACITY, "registry can offer %llu slots > max_slots %u",
                 (unsigned long long)slot_bound64, c->max_slots);
   p.slot_bound = (uint32_t)slot_bound64;
-  p.n_tiles = std::max<uint32_t>(1, ceil_div(p.slot_bound, kSortTile));
+  // Sort tiles: 256 threads x `items` elements; fewer elements per thread while that still
+  // leaves the chip short of workgroups (the passes are latency-bound at this size).
+  p.sort_items = p.slot_bound <= 300000 ? 2 : (p.slot_bound <= 700000 ? 4 : 8);
+  if (const char* e = getenv("YDC_SORT_ITEMS")) p.sort_items = std::min(8, std::max(1, atoi(e)));
+  p.n_tiles = std::max<uint32_t>(1, ceil_div(p.slot_bound, kSortThreads * p.sort_items));
   p.any_shared = c->tables.any_shared_ip;
   p.use_generic = p.C > kMaxWaveClasses;
   p.wave_path = N && p.C && !p.use_generic;
@@ -699,10 +703,10 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   if (p.slot_bound) {
     for (uint32_t q = 0; q < p.key_passes; ++q) {
       if (p.key32) {
-        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q)};
+        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q), p.sort_items};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
       } else {
-        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q)};
+        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q), p.sort_items};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1]);
       }
       cur ^= 1;
@@ -713,7 +717,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   for (uint32_t q = 0; q < p.cls_passes; ++q) {
     // First pass: key == index (global rank). Later passes carry the rank along.
     SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
-                        q * p.cls_bits, p.cls_bits};
+                        q * p.cls_bits, p.cls_bits, p.sort_items};
     launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
     cur ^= 1;
   }
