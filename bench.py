@@ -253,7 +253,7 @@ def main():
             ach = alg_bytes / avg_launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
                                "unit": "GB/s", "frac": ach / 8000.0,
-                               "traffic": pmc_traffic(dom),
+                               "traffic": pmc_traffic(dom, args.config),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_us": avg_launch_s * 1e6,
                                "launches_per_step": launches / n_prof}
@@ -270,13 +270,15 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_hbm.json: FETCH_SIZE doubled for wide coalesced reads + WRITE_SIZE, per
-    MI355X_MICROARCH.md §HBM), or None when no profile of this kernel is committed."""
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this config
+    (profiles/*_<config>_pmc_hbm.json, written by tools/profile.sh: FETCH_SIZE doubled for wide
+    coalesced reads + WRITE_SIZE, per MI355X_MICROARCH.md §HBM; separate --pmc passes), or None
+    when no profile of this kernel is committed. PMC counters cannot be read from inside the
+    timed run, so this is the figure of the profiled run of the same command."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_hbm.json" % config))):
         try:
             j = json.load(open(f))
         except Exception:  # noqa: BLE001
