@@ -627,6 +627,21 @@ __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const Class
     out[C] = s;
   }
 }
+// After the all-gather of a pass's records: the pass was final only if NO rank changed an end
+// state. Overwrites this rank's flag of the pass with the global one, so that the gating of
+// the pre-launched passes (and the host's single look) is the same on every rank.
+__global__ void k_global_flag(const ClassState* bounds, uint32_t rec, uint32_t n_classes,
+                              uint32_t n_ranks, uint32_t pass, DeviceParams* prm) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t any = 0, over = 0;
+    for (uint32_t g = 0; g < n_ranks; ++g) {
+      any |= bounds[(size_t)g * rec + n_classes].cursor;
+      over |= bounds[(size_t)g * rec + n_classes].lo;
+    }
+    prm->n_changed[pass & 63] = any ? 1u : 0u;
+    if (over) prm->overflow = 1;
+  }
+}
 // delta[s] = grants of this rank's slice on servant s.
 __global__ __launch_bounds__(256) void k_slot_delta(const uint32_t* running, const uint32_t* running_out,
                                                     uint32_t n, uint32_t* delta) {

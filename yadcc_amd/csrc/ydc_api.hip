@@ -109,6 +109,7 @@ struct ydc_context {
     ClassState* h_bounds = nullptr;  // pinned
     size_t h_bounds_cap = 0;
     uint32_t passes = 0;             // of the last sharded batch
+    uint32_t pass_hint = 3;          // passes to pre-launch before looking at the outcome
   } group;
 
   // Streaming mode (ydc_stream_*): one tick = row updates + slot releases + one
@@ -1226,31 +1227,40 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
   mark(c, 6);
 
-  uint32_t pass = 0, rounds = 0;
+  // Matching passes, pre-launched in groups like on one GPU: after every pass the ranks
+  // all-gather (end state of the last chunk, "changed an end state" flag); k_global_flag turns
+  // the flags into one global flag per pass, which gates the following passes on every rank
+  // alike. The host looks at the outcome once per group.
+  uint32_t launched = 0, rounds = 0;
   for (;;) {
-    if (pass >= 64) HIP_TRY(c, hipMemsetAsync(&prm->n_changed[pass & 63], 0, 4, st));
-    if (p.wave_path) enqueue_pass(c, p, pass, 0u);
-    hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
-                       c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, pass, g.d_send.p);
-    if (int rc = group_all_gather(c, g.d_send.p, g.d_bounds.p, rec * sizeof(ClassState))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(g.h_bounds, g.d_bounds.p, rec * G * sizeof(ClassState),
-                              hipMemcpyDeviceToHost, st));
+    const uint32_t group = launched == 0 ? std::max(2u, std::min(g.pass_hint, 12u)) : 3u;
+    for (uint32_t r = launched; r < launched + group; ++r) {
+      if (launched) HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
+      if (p.wave_path) enqueue_pass(c, p, r, 1u);
+      hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
+                         c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, r, g.d_send.p);
+      if (int rc = group_all_gather(c, g.d_send.p, g.d_bounds.p, rec * sizeof(ClassState))) return rc;
+      hipLaunchKernelGGL(k_global_flag, dim3(1), dim3(64), 0, st, g.d_bounds.p, (uint32_t)rec, C, G, r,
+                         prm);
+    }
+    const uint32_t first = launched;
+    launched += group;
+    HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
-    uint64_t busy = 0;
-    bool overflow = false;
-    for (uint32_t r = 0; r < G; ++r) {
-      busy += g.h_bounds[r * rec + C].cursor;
-      overflow |= g.h_bounds[r * rec + C].lo != 0;
-    }
-    if (overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
-    ++pass;
-    if (busy == 0) {  // every chunk of every rank was consistent with its predecessor
-      rounds = pass;
+    if (c->h_prm->overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
+    if (c->h_prm->n_changed[(launched - 1) & 63] == 0) {
+      rounds = launched;
+      for (uint32_t r = first; r < launched; ++r)
+        if (c->h_prm->n_changed[r & 63] == 0) {
+          rounds = r + 1;  // first pass in which no rank changed anything
+          break;
+        }
+      g.pass_hint = rounds;
       break;
     }
     // Worst case one chunk per pass becomes final; K differs per rank, so bound it loosely.
-    if (pass > (uint64_t)4 * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
+    if (launched > 4u * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
   }
   g.passes = rounds;
 
