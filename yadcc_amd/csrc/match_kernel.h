@@ -13,8 +13,10 @@
 //            stops as soon as the states equal a checkpoint of the previous
 //            replay (identical remainder). If its own end state changed, the
 //            wave carries on into chunk k+1 unless another wave has claimed it
-//            in this pass — a perturbation that needs thousands of requests to
-//            die out is followed by one wave instead of one launch per chunk.
+//            in this pass; from pass 2 on a chunk behind an inconsistent chunk
+//            leaves itself to that follower — a perturbation that needs thousands
+//            of requests to die out is followed by one wave in one launch instead
+//            of one launch per chunk.
 //   A pass in which no chunk's end state changed (pass 0: every end state equals the
 //   next chunk's level guess) proves that every chunk's last replay started from its
 //   predecessor's final end state: the result is the sequential one (chunk 0 always
@@ -415,6 +417,28 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     }
     if (pass != 0) {
       if (__ballot(differs) == 0) return;  // consistent
+      if (pass >= 2 && kc >= 1) {
+        // From the third pass on what is left are chains: chunks whose predecessor's end
+        // state keeps changing. A chunk whose predecessor is itself inconsistent would
+        // replay from a stale state; it leaves the work to the wave that follows the chain
+        // from its head (below), and says that the batch is not final yet.
+        const ClassState* pstart = kc == 1 ? B.boundary_in : B.endst + (size_t)(kc - 2) * C;
+        bool pdiff = false;
+        if (pstart) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const uint32_t c = lane + 64 * j;
+            if (c < C) {
+              const ClassState used = B.checkpoint[(size_t)(((kc - 1) * chunk_size) >> 6) * C + c];
+              pdiff |= !class_state_equal(used, pstart[c]);
+            }
+          }
+        }
+        if (__ballot(pdiff) != 0) {
+          if (lane == 0) prm->n_changed[pass & (kPassSlots - 1)] = 1;
+          return;
+        }
+      }
       // Inconsistent: this pass has work. One wave per chunk and pass.
       uint32_t taken = 0;
       if (lane == 0) taken = atomicMax(&B.claim[kc], stamp) == stamp;
