@@ -8,7 +8,7 @@ CSRC := yadcc_amd/csrc
 HIP_SRCS := $(CSRC)/ydc_api.hip $(wildcard $(CSRC)/*.cc)
 HDRS := $(wildcard $(CSRC)/*.h) include/yadcc_dispatch.h
 
-all: lib oracle model
+all: lib oracle model native
 
 lib: yadcc_amd/libydc.so
 yadcc_amd/libydc.so: $(HIP_SRCS) $(HDRS)
@@ -19,7 +19,12 @@ oracle:
 	$(MAKE) -s -C oracle
 model:
 	$(MAKE) -s -C tests/model
+# Native (C++) drive of the dispatcher through the scheduler harness; plain g++, links libydc.so.
+native: tests/native/harness_test
+tests/native/harness_test: tests/native/harness_test.cc yadcc_amd/libydc.so $(HDRS)
+	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tests/native/harness_test.cc \
+	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../../yadcc_amd' -lpthread
 clean:
 	rm -f yadcc_amd/libydc.so tests/model/libmodel.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle model clean
+.PHONY: all lib oracle model native clean

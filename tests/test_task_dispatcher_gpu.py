@@ -235,3 +235,16 @@ def test_event_stream_matches_reference(seed):
         assert (int(st[k]), locs[k] or None) == (rst, rloc), (seed, "drain", k)
     ref.close()
     td.close()
+
+
+def test_native_scheduler_harness():
+    """tests/native/harness_test: the dispatcher driven natively (C++) through
+    SchedulerHarness, the call pattern of the reference's SchedulerServiceImpl."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "harness_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "native"], cwd=root)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "HARNESS-OK" in out.stdout, (out.stdout, out.stderr)

@@ -87,7 +87,7 @@ const char* ReasonName(int r) {  // NotAcceptingTaskReason_Name, api/scheduler.p
     case 2: return "NOT_ACCEPTING_TASK_REASON_POOR_MACHINE";
     case 3: return "NOT_ACCEPTING_TASK_REASON_CGROUPS_PRESENT";
     case 4: return "NOT_ACCEPTING_TASK_REASON_BEHIND_NAT";
-    case 5: return "NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED";
+    case 100: return "NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED";
     default: return "NOT_ACCEPTING_TASK_REASON_UNKNOWN";
   }
 }
