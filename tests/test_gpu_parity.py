@@ -199,3 +199,20 @@ def test_many_classes_paths(ctx):
     sv["version"] = (20 + np.arange(3000) % 3).astype(np.uint32)
     st = check(ctx, sv, tk)
     assert st["n_classes"] > 256
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_ragged_batch_sizes(ctx, n):
+    """Batches that are not a multiple of the 64-request block / of the chunk size."""
+    sv, tk = cases.random_case(seed=40 + n, n_tasks=n, n_servants=30, n_envs=3, self_frac=0.3,
+                               unknown_env_frac=0.05)
+    check(ctx, sv, tk, "scan")
+
+
+def test_single_class_no_self(ctx):
+    """One class and nobody on a servant host: the merge degenerates to rank == request index."""
+    sv, tk = cases.random_case(seed=51, n_tasks=30_000, n_servants=400, self_frac=0.0,
+                               min_version_20_frac=0.0)
+    sv["version"][:] = 20
+    st = check(ctx, sv, tk)
+    assert st["n_classes"] == 1 and st["rounds"] <= 2

@@ -164,3 +164,15 @@ def test_cfg4_shape_eight_ranks():
     res = sharded_run(ctxs, sv, tk, cuts)
     check_against_oracle(res, sv, tk)
     [c.close() for c in ctxs]
+
+
+def test_local_ranks_many_classes():
+    """> 64 classes (two classes per lane) across 3 ranks."""
+    sv, tk = cases.random_case(seed=63, n_tasks=30_000, n_servants=1500, n_envs=7,
+                               unknown_env_frac=0.002)
+    n = len(tk["env_id"])
+    ctxs = make_group(3, sv)
+    res = sharded_run(ctxs, sv, tk, [0, n // 4, n // 2, n])
+    check_against_oracle(res, sv, tk)
+    assert res[0][3]["n_classes"] > 64
+    [c.close() for c in ctxs]

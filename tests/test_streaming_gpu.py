@@ -73,3 +73,57 @@ def test_stream_structural_heartbeat_recaptures():
         assert np.array_equal(ctx.get_running(), wrun)
     ctx.stream_end()
     ctx.close()
+
+
+def test_stream_hosts_with_several_servants():
+    """Registries where a host runs several servants take the sequential path on the device;
+    inside the captured step that path is selected by a device-side flag."""
+    sv = synth.make_servants(120, n_tasks_hint=3000, n_envs=2, seed=9, shared_ip_frac=0.3)
+    es = streaming.EventStream(sv, 600, 400, n_envs=2)
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.stream_begin(es.hb + 8, 400, 600)
+    for t in range(5):
+        who, rows, rel, tk = es.next_tick()
+        # a third of the requests come from servant hosts (some of them shared)
+        want, _, wrun = O.dispatch(es.registry_snapshot(), tk, "scan")
+        got = ctx.stream_tick(who, rows, rel, tk)
+        assert np.array_equal(got, want), t
+        es.commit(got)
+        assert np.array_equal(ctx.get_running(), wrun)
+    ctx.stream_end()
+    ctx.close()
+
+
+def test_stream_new_servant_appends():
+    """A heartbeat of an unknown servant (index == current count) appends it; the step is
+    captured again and the newcomer takes requests from then on."""
+    sv = synth.make_servants(40, n_tasks_hint=900, seed=12)
+    es = streaming.EventStream(sv, 300, 100)
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.stream_begin(64, 100, 300)
+    who, rows, rel, tk = es.next_tick()
+    es.commit(ctx.stream_tick(who, rows, rel, tk))
+    # a big idle dedicated servant joins
+    new = {"version": 20, "num_processors": 256, "current_load": 0, "max_tasks": 243,
+           "priority": 1, "total_memory": 256 << 30, "memory_available": 128 << 30, "env_mask": 1,
+           "ip": (10 << 24) + 9999, "port": 8335, "running_tasks": 0}
+    for k, v in new.items():
+        es.sv[k] = np.append(es.sv[k], np.array([v], dtype=es.sv[k].dtype))
+    es.n += 1
+    es.foreign = np.append(es.foreign, 0)
+    es.running = np.append(es.running, 0)
+    es.abi = pack.to_abi_columns(es.sv)
+    row = np.zeros(1, dtype=binding.ROW_DTYPE)
+    for k in ("version", "num_processors", "current_load", "max_tasks"):
+        row[k] = es.sv[k][-1]
+    row["flags"], row["ip_id"], row["env_mask"] = es.abi["flags"][-1], es.abi["ip_id"][-1], 1
+    tk = synth.make_tasks(300, es.sv, seed=77)
+    want, _, wrun = O.dispatch(es.registry_snapshot(), tk, "scan")
+    got = ctx.stream_tick(np.array([es.n - 1], np.uint32), row, np.empty(0, np.uint32), tk)
+    assert np.array_equal(got, want) and (got == es.n - 1).sum() > 50
+    ctx.n_servants = es.n
+    assert np.array_equal(ctx.get_running(), wrun)
+    ctx.stream_end()
+    ctx.close()
