@@ -649,13 +649,17 @@ __global__ __launch_bounds__(256) void k_slot_delta(const uint32_t* running, con
   if (s < n) delta[s] = running_out[s] - running[s];
 }
 // running_out[s] = running[s] + sum over ranks of delta[g][s].
+// out_a / out_b (nullable): the caller's copy and, when committing, the resident column.
 __global__ __launch_bounds__(256) void k_sum_deltas(const uint32_t* running, const uint32_t* deltas,
-                                                    uint32_t n, uint32_t n_ranks, uint32_t* running_out) {
+                                                    uint32_t n, uint32_t n_ranks, uint32_t* running_out,
+                                                    uint32_t* out_a, uint32_t* out_b) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   uint32_t acc = running[s];
   for (uint32_t g = 0; g < n_ranks; ++g) acc += deltas[(size_t)g * n + s];
   running_out[s] = acc;
+  if (out_a) out_a[s] = acc;
+  if (out_b) out_b[s] = acc;
 }
 
 // Heartbeats of known servants (KeepServantAlive replaces the personality and keeps

@@ -1271,13 +1271,8 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
                        c->d_running_out.p, S, g.d_delta.p);
     if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
     hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
-                       g.d_deltas.p, S, G, c->d_running_out.p);
-    if (flags & YDC_DISPATCH_COMMIT)
-      HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4,
-                                hipMemcpyDeviceToDevice, st));
-    if (d_out_running)
-      HIP_TRY(c, hipMemcpyAsync(d_out_running, c->d_running_out.p, (size_t)S * 4,
-                                hipMemcpyDeviceToDevice, st));
+                       g.d_deltas.p, S, G, c->d_running_out.p, d_out_running,
+                       (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr);
   }
   mark(c, 7);
   HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
