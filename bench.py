@@ -135,6 +135,10 @@ def main():
     lo, hi = n_cfg * rank, n_cfg * (rank + 1)
     tk = {k: v[lo:hi] for k, v in tk_all.items()}
     n_tasks, n_serv = hi - lo, len(sv["version"])
+    # One rank per GPU; if the launcher narrowed this process to a single visible device it is 0.
+    n_dev = binding.device_count()
+    if n_dev and local_rank >= n_dev:
+        local_rank = local_rank % n_dev
     ctx = binding.Context(device=local_rank)
     ctx.upload_servants(pack.to_abi_columns(sv))
     group_note = None
