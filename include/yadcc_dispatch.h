@@ -34,10 +34,14 @@ extern "C" {
 #define YDC_ERR_HIP (-2)             /* a HIP runtime call failed; see ydc_last_error() */
 #define YDC_ERR_NO_DEVICE (-3)       /* no usable gfx950 device: there is NO CPU fallback */
 #define YDC_ERR_CAPACITY (-4)        /* more servants/tasks/slots than the context was created for */
-#define YDC_ERR_TOO_MANY_CLASSES (-5)/* > YDC_MAX_CLASSES distinct (env set, version) signatures */
+#define YDC_ERR_TOO_MANY_CLASSES (-5)/* more (env set, version) signatures than the entry point takes */
 #define YDC_ERR_NOT_CONVERGED (-6)   /* internal invariant broken (never expected) */
 
-#define YDC_MAX_CLASSES 64u
+/* Servant classes = distinct (env set, version) signatures among servants with max_tasks != 0.
+ * Batch dispatch takes up to 65535 (a slower kernel above 256); streaming and sharded
+ * dispatch take up to 256. */
+#define YDC_MAX_CLASSES 65535u
+#define YDC_MAX_FAST_CLASSES 256u
 #define YDC_MAX_ENVS 64u
 
 /* ---- servant flags --------------------------------------------------------- */

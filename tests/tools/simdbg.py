@@ -1,4 +1,5 @@
-"""Developer aid: prints k_sim_wave's per-chunk timing (YDC_DEBUG_SIM=1)."""
+"""Developer aid: prints the matching passes' outcome per batch (YDC_DEBUG_SIM=1: which passes
+changed an end state, number of chunk replays)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ["YDC_DEBUG_SIM"] = "1"

@@ -90,7 +90,7 @@ struct ydc_context {
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
   DevBuf<uint32_t> d_running_out;
-  DevBuf<ClassState> d_guess[2], d_endst, d_checkpoint;
+  DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint;
   DevBuf<unsigned long long> d_claim;
   uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
 
@@ -130,7 +130,6 @@ struct ydc_context {
   } stream_mode;
   DevBuf<ClassRun> d_runs;
   DevBuf<uint8_t> d_dirty;
-  DevBuf<uint64_t> d_dbg;
   bool debug_sim = false;
   DevBuf<DeviceParams> d_prm;
   DeviceParams* h_prm = nullptr;  // pinned
@@ -404,13 +403,11 @@ int ydc_destroy(ydc_context* c) {
   c->d_owner.release();
   c->d_consumed.release();
   c->d_guess[0].release();
-  c->d_guess[1].release();
   c->d_endst.release();
   c->d_checkpoint.release();
   c->d_claim.release();
   c->d_runs.release();
   c->d_dirty.release();
-  c->d_dbg.release();
   c->d_prm.release();
   c->d_out_util.release();
   if (c->h_prm) (void)hipHostFree(c->h_prm);
