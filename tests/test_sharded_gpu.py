@@ -155,9 +155,11 @@ def test_local_ranks_commit_two_batches():
     [c.close() for c in ctxs]
 
 
-def test_cfg4_shape_eight_ranks():
-    """BASELINE.json configs[3] scaled to the test box: 8 ranks, 4 digests, 400k x 16k."""
-    sv, tk = synth.make_config("cfg4", n_tasks=400_000)
+@pytest.mark.parametrize("n_tasks", [400_000, 4_000_000])
+def test_cfg4_shape_eight_ranks(n_tasks):
+    """BASELINE.json configs[3]: 4M requests x 16k servants, 4 digests, sharded over 8 ranks
+    (here: 8 contexts on the one GPU of the test box), and a tenth of it."""
+    sv, tk = synth.make_config("cfg4", n_tasks=n_tasks)
     n = len(tk["env_id"])
     ctxs = make_group(8, sv)
     cuts = [n * r // 8 for r in range(9)]
