@@ -186,7 +186,9 @@ int ydc_group_destroy(ydc_context* ctx);
  * cover the rank's own slice, d_out_running (nullable, n_servants entries) is the global
  * running_tasks after the batch, identical on all ranks; YDC_DISPATCH_COMMIT applies it.
  * Exchanges: all-gathers of 4 B, (n_classes + 1) * 16 B per matching pass, n_servants * 4 B
- * (the per-rank servant-slot deltas) per rank. */
+ * (the per-rank servant-slot deltas) per rank. Registries with more than 256 servant classes or
+ * with hosts that run several servants are not sharded: every rank gathers the whole batch and
+ * places it redundantly (same results, no speed-up). */
 int ydc_dispatch_sharded(ydc_context* ctx, const ydc_task_soa* d_tasks_slice, uint32_t n_slice,
                          uint32_t flags, uint32_t* d_out_servant_idx, double* d_out_utilization,
                          uint32_t* d_out_running);

@@ -178,3 +178,24 @@ def test_local_ranks_many_classes():
     check_against_oracle(res, sv, tk)
     assert res[0][3]["n_classes"] > 64
     [c.close() for c in ctxs]
+
+
+@pytest.mark.parametrize("kind", ["shared_hosts", "many_classes"])
+def test_local_ranks_unsharded_registries(kind):
+    """Registries the sharded matching does not take (hosts with several servants; more than 256
+    classes): every rank places the whole batch redundantly and keeps its slice — same results."""
+    if kind == "shared_hosts":
+        sv, tk = cases.random_case(seed=64, n_tasks=6000, n_servants=200, n_envs=3,
+                                   shared_ip_frac=0.25, self_frac=0.3)
+    else:
+        sv, tk = cases.random_case(seed=65, n_tasks=9000, n_servants=3000, n_envs=10)
+        sv["version"] = (20 + np.arange(3000) % 3).astype(np.uint32)
+    n = len(tk["env_id"])
+    ctxs = make_group(3, sv)
+    res = sharded_run(ctxs, sv, tk, [0, n // 5, n // 5, n], commit=True)
+    want, wutil, wrun = O.dispatch(sv, tk, "scan" if kind == "shared_hosts" else "sorted")
+    assert np.array_equal(np.concatenate([r[0] for r in res]), want)
+    assert np.array_equal(np.concatenate([r[1] for r in res]), wutil)
+    for r, c in zip(res, ctxs):
+        assert np.array_equal(r[2], wrun) and np.array_equal(c.get_running(), wrun)
+    [c.close() for c in ctxs]

@@ -105,6 +105,8 @@ struct ydc_context {
     decltype(&ncclGetErrorString) error_string_fn = nullptr;
     LocalHub* hub = nullptr;
     DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
+    DevBuf<uint32_t> d_pad, d_gather, d_all[3], d_all_idx;  // replicated fallback (whole batch)
+    DevBuf<double> d_all_util;
     DevBuf<ClassState> d_send, d_bounds;
     ClassState* h_bounds = nullptr;  // pinned
     size_t h_bounds_cap = 0;
@@ -1073,7 +1075,10 @@ void group_release(ydc_context* c) {
     if (last) delete g.hub;
     g.hub = nullptr;
   }
-  for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas}) b->release();
+  for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas, &g.d_pad, &g.d_gather,
+                  &g.d_all[0], &g.d_all[1], &g.d_all[2], &g.d_all_idx})
+    b->release();
+  g.d_all_util.release();
   g.d_send.release();
   g.d_bounds.release();
   if (g.h_bounds) (void)hipHostFree(g.h_bounds);
@@ -1192,10 +1197,60 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   HIP_TRY(c, hipSetDevice(c->device));
   BatchPlan p;
   if (int rc = plan_batch(c, N, &p)) return rc;
-  if (p.use_generic || p.any_shared)
-    return fail(c, YDC_ERR_TOO_MANY_CLASSES,
-                "sharded dispatch needs <= %u servant classes and one servant per host "
-                "(dispatch such registries on one GPU)", kMaxWaveClasses);
+  if (p.use_generic || p.any_shared) {
+    // Registries the sharded matching does not take (> 256 classes, or hosts that run several
+    // servants: both go through sequential paths): every rank gathers the whole batch, places
+    // it redundantly with the single-GPU pipeline — identical on all ranks — and keeps its own
+    // slice of the placement.
+    const uint32_t G = (uint32_t)g.n_ranks;
+    HIP_TRY(c, g.d_totals.reserve(G + 1));
+    HIP_TRY(c, hipMemcpyAsync(g.d_totals.p + G, &N, 4, hipMemcpyHostToDevice, c->stream));
+    if (int rc = group_all_gather(c, g.d_totals.p + G, g.d_totals.p, 4)) return rc;
+    std::vector<uint32_t> sizes(G);
+    HIP_TRY(c, hipMemcpyAsync(sizes.data(), g.d_totals.p, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t max_n = 1, total = 0, my_off = 0;
+    for (uint32_t r = 0; r < G; ++r) {
+      max_n = std::max(max_n, sizes[r]);
+      if (r < (uint32_t)g.rank) my_off += sizes[r];
+      total += sizes[r];
+    }
+    HIP_TRY(c, g.d_pad.reserve(max_n));
+    HIP_TRY(c, g.d_gather.reserve((size_t)max_n * G));
+    HIP_TRY(c, g.d_all[0].reserve(total));
+    HIP_TRY(c, g.d_all[1].reserve(total));
+    HIP_TRY(c, g.d_all[2].reserve(total));
+    HIP_TRY(c, g.d_all_idx.reserve(total));
+    if (d_out_util) HIP_TRY(c, g.d_all_util.reserve(total));
+    const uint32_t* cols[3] = {N ? tk->env_id : nullptr, N ? tk->min_version : nullptr,
+                               N ? tk->requestor_ip : nullptr};
+    for (int k = 0; k < 3; ++k) {
+      if (N) HIP_TRY(c, hipMemcpyAsync(g.d_pad.p, cols[k], (size_t)N * 4, hipMemcpyDeviceToDevice, c->stream));
+      if (int rc = group_all_gather(c, g.d_pad.p, g.d_gather.p, (size_t)max_n * 4)) return rc;
+      uint32_t off = 0;
+      for (uint32_t r = 0; r < G; ++r) {
+        if (sizes[r])
+          HIP_TRY(c, hipMemcpyAsync(g.d_all[k].p + off, g.d_gather.p + (size_t)r * max_n,
+                                    (size_t)sizes[r] * 4, hipMemcpyDeviceToDevice, c->stream));
+        off += sizes[r];
+      }
+    }
+    ydc_task_soa all{g.d_all[0].p, g.d_all[1].p, g.d_all[2].p};
+    if (int rc = ydc_dispatch_device(c, &all, total, flags, g.d_all_idx.p,
+                                     d_out_util ? g.d_all_util.p : nullptr, d_out_running))
+      return rc;
+    if (N && d_out_idx)
+      HIP_TRY(c, hipMemcpyAsync(d_out_idx, g.d_all_idx.p + my_off, (size_t)N * 4,
+                                hipMemcpyDeviceToDevice, c->stream));
+    if (N && d_out_util)
+      HIP_TRY(c, hipMemcpyAsync(d_out_util, g.d_all_util.p + my_off, (size_t)N * 8,
+                                hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // Stats describe the whole batch in this mode; report this rank's share of the grants.
+    c->stats.n_tasks = N;
+    g.passes = c->stats.rounds;
+    return YDC_OK;
+  }
   const uint32_t G = (uint32_t)g.n_ranks, C = p.C, S = p.S, K = p.K;
   const size_t rec = (size_t)C + 1;  // ClassStates a rank publishes per pass
   HIP_TRY(c, g.d_totals.reserve(G));
