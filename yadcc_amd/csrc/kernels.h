@@ -34,6 +34,9 @@ struct DeviceParams {
   uint32_t overflow;      // M exceeded the workspace
   uint32_t need_shared;   // some task's host runs several servants
   uint32_t n_changed[64]; // pass r (index r & 63) changed some chunk's end state: not final yet
+  // Sampled count of the end states pass r changed (chunks with index % 16 == 0 only: an
+  // estimate at a sixteenth of the same-address atomics), same indexing as the flags.
+  uint32_t n_sampled[64];
   uint32_t chunk_sims;    // chunk simulations executed (all rounds)
   uint32_t granted;       // requests that got a slot (k_running_out)
   uint32_t consuming;     // requests with at least one eligible class (k_chunk_prefix)
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->need_shared = 0;
-    for (int r = 0; r < 64; ++r) prm->n_changed[r] = 0;
+    for (int r = 0; r < 64; ++r) prm->n_changed[r] = prm->n_sampled[r] = 0;
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;

@@ -60,6 +60,10 @@ struct MatchBuffers {
   // entries, or NULL) is the end state of the predecessor's last chunk.
   const ClassState* boundary_in;
   uint32_t has_successor;  // multi-GPU: another rank continues after this rank's last chunk
+  // "pass r changed an end state" flags (index r & flag_mask): DeviceParams::n_changed.
+  uint32_t* flags;
+  uint32_t* sampled;  // sampled counts of changed end states, same indexing
+  uint32_t flag_mask;
 };
 
 // Everything a lane keeps about one of its classes.
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   // An earlier pass found every chunk consistent: nothing to do.
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
-  if (device_check && pass > 0 && prm->n_changed[(pass - 1) & (kPassSlots - 1)] == 0) return;
+  if (device_check && pass > 0 && B.flags[(pass - 1) & B.flag_mask] == 0) return;
   const uint32_t lane = threadIdx.x;
   uint32_t kc = blockIdx.x;  // chunk
   if (kc >= n_chunks) return;
@@ -417,11 +421,13 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     }
     if (pass != 0) {
       if (__ballot(differs) == 0) return;  // consistent
-      if (pass >= 2 && kc >= 1) {
-        // From the third pass on what is left are chains: chunks whose predecessor's end
-        // state keeps changing. A chunk whose predecessor is itself inconsistent would
-        // replay from a stale state; it leaves the work to the wave that follows the chain
-        // from its head (below), and says that the batch is not final yet.
+      if (pass >= 2 && kc >= 1 && B.sampled[(pass - 1) & B.flag_mask] < 4) {
+        // Few end states changed in the previous pass (sampled estimate < ~64): what is left
+        // are chains — chunks whose predecessor's end state keeps changing. A chunk whose
+        // predecessor is itself inconsistent would replay from a stale state; it leaves the
+        // work to the wave that follows the chain from its head (below), and says that the
+        // batch is not final yet. (With many changes everybody replays in parallel instead:
+        // most of them settle within their own chunk.)
         const ClassState* pstart = kc == 1 ? B.boundary_in : B.endst + (size_t)(kc - 2) * C;
         bool pdiff = false;
         if (pstart) {
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           }
         }
         if (__ballot(pdiff) != 0) {
-          if (lane == 0) prm->n_changed[pass & (kPassSlots - 1)] = 1;
+          if (lane == 0) B.flags[pass & B.flag_mask] = 1;
           return;
         }
       }
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 
   bool ring_ready = false;
   uint64_t holes[W] = {};
+  uint32_t followed = 0;  // chunks this wave has carried on into
 
   // Tops up the ring of class j of lane `cc`: one coalesced load of up to 64 entries.
   auto refill = [&](uint32_t cc, int bj) {
@@ -762,12 +769,16 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     // The first chunk of the next rank starts from a guess of its own in pass 0.
     if (pass == 0 && kc + 1 == n_chunks && B.has_successor) changed = true;
     // "Not final yet": everybody stores the same 1 (no same-address atomics).
-    if (changed && lane == 0) prm->n_changed[pass & (kPassSlots - 1)] = 1;
+    if (changed && lane == 0) {
+      B.flags[pass & B.flag_mask] = 1;
+      if ((kc & 15u) == 0) atomicAdd(&B.sampled[pass & B.flag_mask], 1u);
+    }
     if (pass == 0) return;
     if (!changed) return;  // nothing downstream is affected
     // The next chunk is now inconsistent. Follow the chain unless its own wave (or
     // another follower) has it in this pass; then the next pass picks it up.
     if (kc + 1 >= n_chunks) return;
+    if (++followed > 64) return;  // bound one wave's serial work; the next pass goes on
     ++kc;
     uint32_t taken = 0;
     if (lane == 0) taken = atomicMax(&B.claim[kc], stamp) == stamp;

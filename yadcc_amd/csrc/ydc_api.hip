@@ -652,6 +652,9 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.claim = c->d_claim.p;
     p.mb.slot_of = c->d_slot_of.p;
     p.mb.boundary_in = nullptr;
+    p.mb.flags = c->d_prm.p->n_changed;
+    p.mb.sampled = c->d_prm.p->n_sampled;
+    p.mb.flag_mask = 63;
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
     p.rshift = 3;
@@ -861,8 +864,10 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
     if (launched) {
       // Counter slots of the passes to come (the first group's were cleared by
       // k_servant_scan). The stream is idle here: the host has just synchronised.
-      for (uint32_t r = launched; r < launched + group; ++r)
+      for (uint32_t r = launched; r < launched + group; ++r) {
         HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->n_changed[r & 63], 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->n_sampled[r & 63], 0, 4, c->stream));
+      }
     }
     const uint32_t first = launched;
     for (uint32_t r = launched; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
@@ -1287,7 +1292,10 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   for (;;) {
     const uint32_t group = launched == 0 ? std::max(2u, std::min(g.pass_hint, 12u)) : 3u;
     for (uint32_t r = launched; r < launched + group; ++r) {
-      if (launched) HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
+      if (launched) {
+        HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
+        HIP_TRY(c, hipMemsetAsync(&prm->n_sampled[r & 63], 0, 4, st));
+      }
       if (p.wave_path) enqueue_pass(c, p, r, 1u);
       hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
                          c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, r, g.d_send.p);
