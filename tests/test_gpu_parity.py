@@ -216,3 +216,26 @@ def test_single_class_no_self(ctx):
     sv["version"][:] = 20
     st = check(ctx, sv, tk)
     assert st["n_classes"] == 1 and st["rounds"] <= 2
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
+    """<= 8 classes and room in the last key digit: the class partition rides on the last key
+    pass (k_radix_scatter_classed); YDC_FUSED_CLASS=0 keeps the separate pass. Same results."""
+    monkeypatch.setenv("YDC_FUSED_CLASS", str(fused))
+    c = binding.Context(device=0)
+    try:
+        for seed, envs in ((61, 2), (62, 3), (63, 1)):
+            sv, tk = cases.random_case(seed=seed, n_tasks=40_000, n_servants=700, n_envs=envs,
+                                       self_frac=0.2, unknown_env_frac=0.001)
+            st = check(c, sv, tk)
+            assert 2 <= st["n_classes"] <= 16
+        # fp64 keys (capacity >= 2^21): 64-bit sort keys in, 32-bit ranks out
+        sv, tk = cases.random_case(seed=64, n_tasks=5_000, n_servants=50, n_envs=2)
+        sv["num_processors"][:5] = 3_000_000
+        sv["max_tasks"][:5] = 3_000_000
+        sv["running_tasks"][:5] = 3_000_000 - 40
+        st = check(c, sv, tk)
+        assert st["key_bits"] == 64
+    finally:
+        c.close()

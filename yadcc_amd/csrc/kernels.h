@@ -208,12 +208,19 @@ struct SortIn {
   uint32_t shift;
   uint32_t bits;            // digit width of this pass
   uint32_t items;           // elements per thread (tile = 256 * items), <= kSortItems
+  // Last key pass with the class folded in (few classes, room left in the digit): the digit
+  // is (class << (bits - fused_cls_bits)) | key bits, see k_radix_scatter_classed. 0: off.
+  uint32_t fused_cls_bits;
 };
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t i, KeyT key,
                                                uint32_t val) {
   const uint32_t mask = (1u << in.bits) - 1;
+  if (in.fused_cls_bits) {
+    const uint32_t kbits = in.bits - in.fused_cls_bits;
+    return ((uint32_t)in.cls_by_g[val] << kbits) | ((uint32_t)(key >> in.shift) & ((1u << kbits) - 1));
+  }
   if (in.cls_by_g) return ((uint32_t)in.cls_by_g[val] >> in.shift) & mask;
   return (uint32_t)(key >> in.shift) & mask;
 }
@@ -351,6 +358,135 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       out_keys[pos] = (OutKeyT)key[j];
       out_vals[pos] = val[j];
+    }
+  }
+}
+
+// Last key pass and class partition in one (SortIn::fused_cls_bits != 0, a handful of classes).
+// The digit is (class, top key bits), so the elements land class-major and key-sorted within
+// the class: the per-class lists. What the separate class pass got for free — an element's
+// GLOBAL rank, i.e. its position in the key-only order — is computed beside it: the same
+// stable ranking on the key bits of the digit alone (digit start and earlier tiles: sums over
+// the classes of the scanned histogram; within the tile: a second ballot match). Writes
+// out_rank[pos] = global rank, out_vals[pos] = slot, rank_to_g[global rank] = slot.
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
+    SortIn<KeyT> in, const DeviceParams* prm, uint32_t n_tiles, const uint32_t* hist,
+    const uint32_t* row_total, uint32_t* out_rank, uint32_t* out_vals, uint32_t* rank_to_g) {
+  // cnt[kSortWaves][radix] | dstart[radix] | kcnt[kSortWaves][kradix] | kstart[kradix]
+  extern __shared__ uint32_t sm[];
+  __shared__ uint32_t lds[17];
+  const uint32_t radix = 1u << in.bits;
+  const uint32_t kbits = in.bits - in.fused_cls_bits;
+  const uint32_t kradix = 1u << kbits, n_cls = 1u << in.fused_cls_bits;
+  uint32_t* cnt = sm;
+  uint32_t* dstart = sm + kSortWaves * radix;
+  uint32_t* kcnt = dstart + radix;
+  uint32_t* kstart = kcnt + kSortWaves * kradix;
+  const uint32_t M = prm->n_slots;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t base = tile * (kSortThreads * in.items);
+  if (base >= M) return;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wave_span = in.items * 64;
+  {
+    const uint32_t per = (radix + kSortThreads - 1) / kSortThreads;
+    const uint32_t d0 = threadIdx.x * per, d1 = min(radix, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += row_total[d];
+    uint32_t total;
+    uint32_t acc = block_exclusive_scan(sum, lds, &total);
+    for (uint32_t d = d0; d < d1; ++d) {
+      dstart[d] = acc + hist[d * n_tiles + tile];
+      acc += row_total[d];
+    }
+    __syncthreads();  // lds[] is reused by the second scan
+    // Key-only digit starts: all classes' elements with a smaller key digit + the elements
+    // of earlier tiles with the same key digit.
+    const uint32_t kper = (kradix + kSortThreads - 1) / kSortThreads;
+    const uint32_t k0 = threadIdx.x * kper, k1 = min(kradix, k0 + kper);
+    sum = 0;
+    for (uint32_t d = k0; d < k1; ++d)
+      for (uint32_t c = 0; c < n_cls; ++c) sum += row_total[(c << kbits) | d];
+    acc = block_exclusive_scan(sum, lds, &total);
+    for (uint32_t d = k0; d < k1; ++d) {
+      uint32_t all = 0, earlier = 0;
+      for (uint32_t c = 0; c < n_cls; ++c) {
+        all += row_total[(c << kbits) | d];
+        earlier += hist[((c << kbits) | d) * n_tiles + tile];
+      }
+      kstart[d] = acc + earlier;
+      acc += all;
+    }
+    for (uint32_t d = threadIdx.x; d < kSortWaves * radix; d += kSortThreads) cnt[d] = 0;
+    for (uint32_t d = threadIdx.x; d < kSortWaves * kradix; d += kSortThreads) kcnt[d] = 0;
+  }
+  __syncthreads();
+  uint32_t val[kSortItems], dig[kSortItems], rank[kSortItems], krank[kSortItems];
+  const uint64_t lt_mask = (1ull << lane) - 1;
+  uint32_t* wcnt = cnt + wave * radix;
+  uint32_t* wkcnt = kcnt + wave * kradix;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = base + wave * wave_span + j * 64 + lane;
+    const bool valid = (uint32_t)j < in.items && i < M;
+    val[j] = 0;
+    uint32_t d = 0;
+    if (valid) {
+      val[j] = in.vals[i];
+      d = sort_digit(in, i, in.keys[i], val[j]);
+    }
+    dig[j] = d;
+    uint64_t kpeers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kMaxRadixBits; ++b) {
+      if ((uint32_t)b < kbits) {
+        const uint64_t m = __ballot((d >> b) & 1u);
+        kpeers &= ((d >> b) & 1u) ? m : ~m;
+      }
+    }
+    uint64_t peers = kpeers;  // same key digit; now the same class as well
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if ((uint32_t)b < in.fused_cls_bits) {
+        const uint64_t m = __ballot((d >> (kbits + b)) & 1u);
+        peers &= ((d >> (kbits + b)) & 1u) ? m : ~m;
+      }
+    }
+    const uint32_t kd = d & (kradix - 1);
+    uint32_t before = 0, kbefore = 0;
+    if (valid) {
+      before = wcnt[d];
+      kbefore = wkcnt[kd];
+    }
+    rank[j] = before + (uint32_t)__popcll(peers & lt_mask);
+    krank[j] = kbefore + (uint32_t)__popcll(kpeers & lt_mask);
+    if (valid && (peers & lt_mask) == 0) wcnt[d] = before + (uint32_t)__popcll(peers);
+    if (valid && (kpeers & lt_mask) == 0) wkcnt[kd] = kbefore + (uint32_t)__popcll(kpeers);
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < radix + kradix; d += kSortThreads) {
+    uint32_t* col = d < radix ? cnt + d : kcnt + (d - radix);
+    const uint32_t stride = d < radix ? radix : kradix;
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      uint32_t t = col[w * stride];
+      col[w * stride] = off;
+      off += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = base + wave * wave_span + j * 64 + lane;
+    if ((uint32_t)j < in.items && i < M) {
+      const uint32_t kd = dig[j] & (kradix - 1);
+      const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
+      const uint32_t grank = kstart[kd] + wkcnt[kd] + krank[j];
+      out_rank[pos] = grank;
+      out_vals[pos] = val[j];
+      rank_to_g[grank] = val[j];
     }
   }
 }

@@ -52,6 +52,7 @@ namespace {
 struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
   uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
+  uint32_t fused_cls_bits = 0;  // class partition folded into the last key pass (kernels.h)
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
   ServantTable sv{};
   ClassLists L{};
@@ -86,6 +87,7 @@ struct ydc_context {
   DevBuf<uint64_t> d_keys[2];  // viewed as u32 when the key fits
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
+  DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
   DevBuf<uint8_t> d_consumed;   // slot taken by a request of this batch
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
@@ -143,6 +145,7 @@ struct ydc_context {
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
+  bool opt_fused_class = true;
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -273,7 +276,12 @@ int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in, uint32_t n_tiles, v
   YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(radix), dim3(256), 0, c->stream, n_tiles,
              c->d_hist.p, c->d_row_total.p);
   const size_t lds = (size_t)(kSortWaves + 1) * radix * 4;
-  if (out_u32) {
+  if (in.fused_cls_bits) {
+    const size_t lds2 = lds + (size_t)(kSortWaves + 1) * (radix >> in.fused_cls_bits) * 4;
+    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter_classed<KeyT>), dim3(n_tiles),
+               dim3(kSortThreads), lds2, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
+               c->d_row_total.p, (uint32_t*)out_keys, out_vals, c->d_rank_to_g.p);
+  } else if (out_u32) {
     YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint32_t>), dim3(n_tiles),
                dim3(kSortThreads), lds, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint32_t*)out_keys, out_vals);
@@ -381,6 +389,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_DEBUG_SIM")) c->debug_sim = atoi(s) != 0;
   if (const char* s = getenv("YDC_CHUNK_SIZE")) c->opt_chunk_size = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_TARGET_CHUNKS")) c->opt_target_chunks = (uint32_t)atoi(s);
+  if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -403,6 +412,7 @@ int ydc_destroy(ydc_context* c) {
   for (auto* b : {&c->d_cls_env, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
   c->d_cls_by_g.release();
   c->d_owner.release();
+  c->d_rank_to_g.release();
   c->d_consumed.release();
   c->d_guess[0].release();
   c->d_endst.release();
@@ -604,6 +614,23 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_vals[1].reserve(slot_bound));
   HIP_TRY(c, c->d_hist.reserve(((size_t)1 << kMaxRadixBits) * p.n_tiles));
   if (C > 1) HIP_TRY(c, c->d_cls_by_g.reserve(slot_bound));
+  p.key_passes = c->kf.passes;
+  p.cls_passes = 0;
+  p.fused_cls_bits = 0;
+  if (C > 1 && slot_bound) {
+    uint32_t cls_bits = 1;
+    while ((1u << cls_bits) < C) ++cls_bits;
+    // A handful of classes and room left in the last key digit: one pass does both.
+    const uint32_t last_bits = c->kf.key_bits - (p.key_passes - 1) * c->kf.bits_per_pass;
+    if (C <= 8 && p.key_passes >= 1 && last_bits + cls_bits <= (uint32_t)kMaxRadixBits &&
+        c->opt_fused_class) {
+      p.fused_cls_bits = cls_bits;
+      HIP_TRY(c, c->d_rank_to_g.reserve(slot_bound));
+    } else {
+      p.cls_passes = ceil_div(cls_bits, kMaxRadixBits);
+      p.cls_bits = ceil_div(cls_bits, p.cls_passes);
+    }
+  }
   HIP_TRY(c, c->d_owner.reserve(slot_bound));
   HIP_TRY(c, c->d_consumed.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
@@ -628,20 +655,12 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
 
   p.sv = ServantTable{c->d_version.p, c->d_nproc.p,  c->d_load.p,     c->d_max_tasks.p,
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
-  p.key_passes = c->kf.passes;
-  p.cls_passes = 0;
-  if (C > 1 && slot_bound) {
-    uint32_t cls_bits = 1;
-    while ((1u << cls_bits) < C) ++cls_bits;
-    p.cls_passes = ceil_div(cls_bits, kMaxRadixBits);
-    p.cls_bits = ceil_div(cls_bits, p.cls_passes);
-  }
   // The sort ping-pongs between the two key/value buffers: where the lists end up.
   const int cur = (int)(((slot_bound ? p.key_passes : 0) + p.cls_passes) & 1);
-  p.rank_to_g = c->d_vals[(slot_bound ? p.key_passes : 0) & 1].p;
+  p.rank_to_g = p.fused_cls_bits ? c->d_rank_to_g.p : c->d_vals[(slot_bound ? p.key_passes : 0) & 1].p;
   p.L.n_classes = C;
   p.L.cls_begin = c->d_cls_begin.p;
-  p.L.list_p = p.cls_passes ? (const uint32_t*)c->d_keys[cur].p : nullptr;
+  p.L.list_p = p.cls_passes || p.fused_cls_bits ? (const uint32_t*)c->d_keys[cur].p : nullptr;
   p.L.list_g = c->d_vals[cur].p;
   p.T = TaskTable{c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p, W};
   p.mb = MatchBuffers{};
@@ -705,11 +724,16 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   auto bits_of = [&](uint32_t q) { return std::min(bpp, c->kf.key_bits - q * bpp); };
   if (p.slot_bound) {
     for (uint32_t q = 0; q < p.key_passes; ++q) {
+      // The last pass may carry the class above its key bits (k_radix_scatter_classed).
+      const uint32_t fused = q + 1 == p.key_passes ? p.fused_cls_bits : 0;
+      const uint16_t* cls = fused ? c->d_cls_by_g.p : nullptr;
       if (p.key32) {
-        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q), p.sort_items};
+        SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
+                            p.sort_items, fused};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
       } else {
-        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], nullptr, q * bpp, bits_of(q), p.sort_items};
+        SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
+                            p.sort_items, fused};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1]);
       }
       cur ^= 1;
@@ -720,7 +744,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   for (uint32_t q = 0; q < p.cls_passes; ++q) {
     // First pass: key == index (global rank). Later passes carry the rank along.
     SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
-                        q * p.cls_bits, p.cls_bits, p.sort_items};
+                        q * p.cls_bits, p.cls_bits, p.sort_items, 0u};
     launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
     cur ^= 1;
   }
