@@ -168,14 +168,125 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
 }
 
 // ---------------------------------------------------------------------------
+// Request classification: thread per request. Rides in k_slot_gen's launch (both only need
+// k_servant_scan's output, and a launch costs about what either of them does).
+// ---------------------------------------------------------------------------
+struct TaskColumns {
+  const uint32_t* env_id;
+  const uint32_t* min_version;
+  const uint32_t* requestor_ip;
+};
+
+struct ClassifyArgs {
+  TaskColumns tk;
+  uint32_t n_tasks;
+  const uint64_t* cls_env;
+  const uint32_t* cls_ver;
+  uint32_t n_classes, words;
+  const uint32_t* ip_sorted;
+  const uint32_t* ip_servant;
+  uint32_t n_servants;
+  const uint32_t* slot_base;
+  uint32_t chunk_size;
+  uint64_t* mask;
+  uint32_t* self_lo;
+  uint32_t* self_hi;
+  uint32_t* chunk_consuming;
+};
+
+__device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
+                                                    DeviceParams* prm) {
+  const uint32_t t = block * blockDim.x + threadIdx.x;
+  if (t >= a.n_tasks) return;
+  uint64_t any = 0;
+  {
+    const uint32_t env = a.tk.env_id[t], minv = a.tk.min_version[t];
+    for (uint32_t w = 0; w < a.words; ++w) {
+      uint64_t m = 0;
+      if (env < 64) {
+        const uint32_t c0 = w * 64, c1 = min(c0 + 64, a.n_classes);
+        for (uint32_t c = c0; c < c1; ++c) {
+          if (((a.cls_env[c] >> env) & 1u) && a.cls_ver[c] >= minv) m |= 1ull << (c - c0);
+        }
+      }
+      a.mask[(size_t)t * a.words + w] = m;
+      any |= m;
+    }
+  }
+  uint32_t lo = kNone, hi = kNone;
+  const uint32_t rip = a.tk.requestor_ip[t];
+  const uint32_t i = lower_bound_u32(a.ip_sorted, a.n_servants, rip);
+  if (i < a.n_servants && a.ip_sorted[i] == rip) {
+    if (i + 1 < a.n_servants && a.ip_sorted[i + 1] == rip) {
+      lo = i;
+      hi = kSelfShared;
+      if (any) prm->need_shared = 1;  // benign race: everybody writes 1
+    } else {
+      const uint32_t s = a.ip_servant[i];
+      const uint32_t b = a.slot_base[s], e = a.slot_base[s + 1];
+      if (e > b) {
+        lo = b;
+        hi = e;
+      }
+    }
+  }
+  a.self_lo[t] = lo;
+  a.self_hi[t] = hi;
+  // chunk_size is a multiple of 64 and waves start at multiples of 64, so all
+  // lanes of a wave fall into the same chunk: one atomic per wave.
+  const uint64_t consuming = __ballot(any != 0);
+  if (consuming && (threadIdx.x & 63) == __builtin_ctzll(__ballot(true)))
+    atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
+}
+
+// before[k] = number of consuming requests in the chunks before k; before[n_chunks] = their
+// total. ONE workgroup: an extra workgroup of the first histogram launch of the sort (which
+// runs after the classification anyway), or k_chunk_prefix when nothing is sorted.
+struct PrefixArgs {
+  const uint32_t* chunk_consuming;  // NULL: nothing to do
+  uint32_t n_chunks;
+  uint32_t* before;
+};
+
+__device__ __forceinline__ void chunk_prefix_block(const PrefixArgs& a, DeviceParams* prm) {
+  // Each thread owns a run of consecutive chunks (K is a few thousand at most: the chunk
+  // size grows with the batch): independent loads, one block scan, one barrier.
+  __shared__ uint32_t lds[17];
+  const uint32_t per = (a.n_chunks + blockDim.x - 1) / blockDim.x;
+  const uint32_t b = min(a.n_chunks, threadIdx.x * per), e = min(a.n_chunks, b + per);
+  uint32_t sum = 0;
+  for (uint32_t k = b; k < e; ++k) sum += a.chunk_consuming[k];
+  uint32_t total;
+  uint32_t acc = block_exclusive_scan(sum, lds, &total);
+  for (uint32_t k = b; k < e; ++k) {
+    a.before[k] = acc;
+    acc += a.chunk_consuming[k];
+  }
+  if (threadIdx.x == 0) {
+    a.before[a.n_chunks] = total;
+    prm->consuming = total;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_chunk_prefix(PrefixArgs a, DeviceParams* prm) {
+  chunk_prefix_block(a, prm);
+}
+
+// ---------------------------------------------------------------------------
 // k_slot_gen: thread per slot, generation order (servant-major, running ascending).
 // ---------------------------------------------------------------------------
+// Workgroups [gen_blocks, gridDim.x) classify requests instead (task_classify_block).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_t* slot_base,
-                                                  const DeviceParams* prm, uint32_t exact,
+                                                  DeviceParams* prm, uint32_t exact,
                                                   uint32_t cap_bits, KeyT* keys, uint32_t* vals,
                                                   uint16_t* cls_by_g, uint32_t* owner,
-                                                  uint8_t* consumed) {
+                                                  uint8_t* consumed, uint32_t gen_blocks,
+                                                  ClassifyArgs ca) {
+  if (blockIdx.x >= gen_blocks) {
+    task_classify_block(ca, blockIdx.x - gen_blocks, prm);
+    return;
+  }
   const uint32_t M = prm->n_slots;
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= M) return;
@@ -226,11 +337,16 @@ __device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t 
 }
 
 // hist[d * n_tiles + tile] = number of elements of the tile with digit d.
+// Workgroup n_tiles (if launched): the chunk prefix (chunk_prefix_block).
 template <typename KeyT>
-__global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in,
-                                                             const DeviceParams* prm,
-                                                             uint32_t n_tiles, uint32_t* hist) {
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, DeviceParams* prm,
+                                                             uint32_t n_tiles, uint32_t* hist,
+                                                             PrefixArgs pa) {
   extern __shared__ uint32_t h[];  // radix
+  if (blockIdx.x == n_tiles) {
+    chunk_prefix_block(pa, prm);
+    return;
+  }
   const uint32_t radix = 1u << in.bits;
   const uint32_t M = prm->n_slots;
   const uint32_t tile = blockIdx.x;
@@ -488,88 +604,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
       out_vals[pos] = val[j];
       rank_to_g[grank] = val[j];
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_task_classify: thread per task.
-// ---------------------------------------------------------------------------
-struct TaskColumns {
-  const uint32_t* env_id;
-  const uint32_t* min_version;
-  const uint32_t* requestor_ip;
-};
-
-__global__ __launch_bounds__(256) void k_task_classify(
-    TaskColumns tk, uint32_t n_tasks, const uint64_t* cls_env, const uint32_t* cls_ver,
-    uint32_t n_classes, uint32_t words, const uint32_t* ip_sorted, const uint32_t* ip_servant,
-    uint32_t n_servants, const uint32_t* slot_base, uint32_t chunk_size, uint64_t* mask,
-    uint32_t* self_lo, uint32_t* self_hi, uint32_t* chunk_consuming, DeviceParams* prm) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_tasks) return;
-  uint64_t any = 0;
-  {
-    uint32_t env = tk.env_id[t], minv = tk.min_version[t];
-    for (uint32_t w = 0; w < words; ++w) {
-      uint64_t m = 0;
-      if (env < 64) {
-        uint32_t c0 = w * 64, c1 = min(c0 + 64, n_classes);
-        for (uint32_t c = c0; c < c1; ++c) {
-          if (((cls_env[c] >> env) & 1u) && cls_ver[c] >= minv) m |= 1ull << (c - c0);
-        }
-      }
-      mask[(size_t)t * words + w] = m;
-      any |= m;
-    }
-  }
-  uint32_t lo = kNone, hi = kNone;
-  uint32_t rip = tk.requestor_ip[t];
-  uint32_t i = lower_bound_u32(ip_sorted, n_servants, rip);
-  if (i < n_servants && ip_sorted[i] == rip) {
-    if (i + 1 < n_servants && ip_sorted[i + 1] == rip) {
-      lo = i;
-      hi = kSelfShared;
-      if (any) prm->need_shared = 1;  // benign race: everybody writes 1
-    } else {
-      uint32_t s = ip_servant[i];
-      uint32_t b = slot_base[s], e = slot_base[s + 1];
-      if (e > b) {
-        lo = b;
-        hi = e;
-      }
-    }
-  }
-  self_lo[t] = lo;
-  self_hi[t] = hi;
-  // chunk_size is a multiple of 64 and waves start at multiples of 64, so all
-  // lanes of a wave fall into the same chunk: one atomic per wave.
-  const uint64_t consuming = __ballot(any != 0);
-  if (consuming && (threadIdx.x & 63) == __builtin_ctzll(__ballot(true)))
-    atomicAdd(&chunk_consuming[t / chunk_size], (uint32_t)__popcll(consuming));
-}
-
-// ONE workgroup: before[k] = number of consuming tasks in the chunks before k;
-// before[n_chunks] = their total.
-__global__ __launch_bounds__(1024) void k_chunk_prefix(const uint32_t* chunk_consuming,
-                                                       uint32_t n_chunks, uint32_t* before,
-                                                       DeviceParams* prm) {
-  __shared__ uint32_t lds[17];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t k0 = 0; k0 < n_chunks; k0 += blockDim.x) {
-    uint32_t k = k0 + threadIdx.x;
-    uint32_t v = k < n_chunks ? chunk_consuming[k] : 0;
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan(v, lds, &total);
-    if (k < n_chunks) before[k] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    before[n_chunks] = carry;
-    prm->consuming = carry;
   }
 }
 

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl is resolved with dlopen at ydc_group_init
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <cstdarg>
@@ -267,12 +268,13 @@ struct KernelTimer {
     hipLaunchKernelGGL(__VA_ARGS__);          \
   } while (0)
 
+// pa (nullable): the chunk prefix rides in the histogram launch as one more workgroup.
 template <typename KeyT>
 int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in, uint32_t n_tiles, void* out_keys,
-                     bool out_u32, uint32_t* out_vals) {
+                     bool out_u32, uint32_t* out_vals, const PrefixArgs* pa = nullptr) {
   const uint32_t radix = 1u << in.bits;
-  YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles), dim3(kSortThreads), radix * 4,
-             c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p);
+  YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles + (pa ? 1 : 0)), dim3(kSortThreads),
+             radix * 4, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p, pa ? *pa : PrefixArgs{});
   YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(radix), dim3(256), 0, c->stream, n_tiles,
              c->d_hist.p, c->d_row_total.p);
   const size_t lds = (size_t)(kSortWaves + 1) * radix * 4;
@@ -706,18 +708,32 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
   uint32_t* vals[2] = {c->d_vals[0].p, c->d_vals[1].p};
   int cur = 0;
-  if (p.slot_bound) {
-    const uint32_t gen_blocks = ceil_div(p.slot_bound, 256);
+  // The request classification (class masks, own-servant ranges, consuming counts per chunk)
+  // rides in the same launch: workgroups [gen_blocks, gen_blocks + cls_blocks).
+  ClassifyArgs ca{};
+  if (N) {
+    ca = ClassifyArgs{TaskColumns{tk->env_id, tk->min_version, tk->requestor_ip}, N,
+                      c->d_cls_env.p, c->d_cls_ver.p, C, W, c->d_ip_sorted.p, c->d_ip_servant.p, S,
+                      c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
+                      c->d_chunk_consuming.p};
+  }
+  const uint32_t gen_blocks = ceil_div(p.slot_bound, 256), cls_blocks = ceil_div(N, 256);
+  if (gen_blocks + cls_blocks) {
     if (p.key32) {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks), dim3(256), 0, st, p.sv,
-                 c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint32_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p);
+      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), 0, st,
+                 p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint32_t*)keys[0],
+                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p, gen_blocks,
+                 ca);
     } else {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks), dim3(256), 0, st, p.sv,
-                 c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint64_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p);
+      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), 0, st,
+                 p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint64_t*)keys[0],
+                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p, gen_blocks,
+                 ca);
     }
   }
+  // The chunk prefix of the consuming counts goes with the first histogram launch.
+  PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p};
+  const PrefixArgs* pending_prefix = N ? &pa : nullptr;
   mark(c, 2);
   // ---- sort by key
   const uint32_t bpp = c->kf.bits_per_pass;
@@ -730,12 +746,13 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
       if (p.key32) {
         SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
                             p.sort_items, fused};
-        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
+        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], pending_prefix);
       } else {
         SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
                             p.sort_items, fused};
-        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1]);
+        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1], pending_prefix);
       }
+      pending_prefix = nullptr;
       cur ^= 1;
     }
   }
@@ -745,20 +762,14 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
     // First pass: key == index (global rank). Later passes carry the rank along.
     SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
                         q * p.cls_bits, p.cls_bits, p.sort_items, 0u};
-    launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1]);
+    launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], pending_prefix);
+    pending_prefix = nullptr;
     cur ^= 1;
   }
   mark(c, 4);
-  // ---- request classification + level guesses
-  if (N) {
-    TaskColumns cols{tk->env_id, tk->min_version, tk->requestor_ip};
-    YDC_LAUNCH(c, "k_task_classify", k_task_classify, dim3(ceil_div(N, 256)), dim3(256), 0, st, cols, N,
-               c->d_cls_env.p, c->d_cls_ver.p, C, W, c->d_ip_sorted.p, c->d_ip_servant.p, S,
-               c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
-               c->d_chunk_consuming.p, prm);
-    YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, c->d_chunk_consuming.p, K,
-               c->d_before.p, prm);
-  }
+  // Nothing was sorted (no free slot anywhere): the prefix gets a launch of its own.
+  if (pending_prefix)
+    YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, pa, prm);
   return YDC_OK;
 }
 
