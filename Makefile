@@ -20,7 +20,10 @@ oracle:
 model:
 	$(MAKE) -s -C tests/model
 # Native (C++) drive of the dispatcher through the scheduler harness; plain g++, links libydc.so.
-native: tests/native/harness_test
+native: tests/native/harness_test tools/td_native_bench
+tools/td_native_bench: tools/td_native_bench.cc yadcc_amd/libydc.so $(HDRS)
+	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tools/td_native_bench.cc \
+	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../yadcc_amd' -lpthread
 tests/native/harness_test: tests/native/harness_test.cc yadcc_amd/libydc.so $(HDRS)
 	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tests/native/harness_test.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../../yadcc_amd' -lpthread
