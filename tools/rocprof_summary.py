@@ -60,9 +60,34 @@ def hbmjson(fetch_db, write_db):
                        "kernels": out}, indent=1)
 
 
+def hbmtable(specs):
+    """specs: tag=path/to/pmc_hbm.json ... -> the per-kernel HBM traffic / bandwidth table."""
+    import json
+    out = ["# HBM traffic per launch and bandwidth per kernel, from the rocprofv3 PMC passes in this directory",
+           "# (r01_<cfg>_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB per dispatch).",
+           "# 'corrected' doubles FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads,",
+           "# MI355X_MICROARCH.md HBM section); 'raw' takes both counters as reported. Durations are",
+           "# those of the profiled (counter-collecting) runs. Peak 8000 GB/s."]
+    for spec in specs:
+        tag, path = spec.split("=", 1)
+        ks = json.load(open(path))["kernels"]
+        out += ["", tag, "  %-26s %10s %10s %9s %16s %16s" % ("kernel", "fetch KB", "write KB", "avg us",
+                                                               "raw GB/s (%pk)", "corr. GB/s (%pk)")]
+        rows = [(k, v) for k, v in ks.items() if not k.startswith("__amd")]
+        rows.sort(key=lambda kv: -(2 * kv[1]["fetch_kb"] + kv[1]["write_kb"]))
+        for k, v in rows:
+            raw = (v["fetch_kb"] + v["write_kb"]) * 1024 / v["avg_ns"]
+            cor = (2 * v["fetch_kb"] + v["write_kb"]) * 1024 / v["avg_ns"]
+            out.append("  %-26s %10.0f %10.0f %9.1f %9.0f (%4.1f%%) %9.0f (%4.1f%%)" % (
+                k, v["fetch_kb"], v["write_kb"], v["avg_ns"] / 1e3, raw, raw / 80.0, cor, cor / 80.0))
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "hbmjson":
         print(hbmjson(sys.argv[2], sys.argv[3]))
+    elif mode == "hbmtable":
+        print(hbmtable(sys.argv[2:]))
     else:
         print(stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2]))
