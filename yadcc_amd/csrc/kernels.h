@@ -858,6 +858,32 @@ __global__ __launch_bounds__(256) void k_apply_rows(const uint32_t* idx, const S
   flags[s] = r.flags;
 }
 
+// One streaming tick's registry deltas in one launch: workgroups [0, upd_blocks) apply the
+// heartbeat rows (as k_apply_rows), the rest give released slots back (as k_release_slots).
+__global__ __launch_bounds__(256) void k_apply_tick(const uint32_t* idx, const ServantRowDev* rows,
+                                                    uint32_t n_upd, uint32_t upd_blocks,
+                                                    const uint32_t* released, uint32_t n_rel,
+                                                    uint32_t n_servants, uint32_t* version,
+                                                    uint32_t* nproc, uint32_t* load,
+                                                    uint32_t* max_tasks, uint32_t* flags,
+                                                    uint32_t* running) {
+  if (blockIdx.x < upd_blocks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_upd) return;
+    const uint32_t s = idx[i];
+    if (s >= n_servants) return;
+    const ServantRowDev r = rows[i];
+    version[s] = r.version;
+    nproc[s] = r.num_processors;
+    load[s] = r.current_load;
+    max_tasks[s] = r.max_tasks;
+    flags[s] = r.flags;
+  } else {
+    const uint32_t i = (blockIdx.x - upd_blocks) * blockDim.x + threadIdx.x;
+    if (i < n_rel && released[i] < n_servants) atomicSub(&running[released[i]], 1u);
+  }
+}
+
 }  // namespace ydc
 
 #include "match_kernel.h"

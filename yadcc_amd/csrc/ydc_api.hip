@@ -122,12 +122,18 @@ struct ydc_context {
   struct Stream {
     bool active = false, stale = true;
     uint32_t max_upd = 0, max_rel = 0, max_tasks = 0, passes = 0;
-    // pinned host staging
+    // One pinned staging arena for everything a tick brings (heartbeat indexes and rows,
+    // released slots, the three request columns) and its device mirror: one H2D copy per
+    // tick. The typed pointers below point into the two arenas.
+    uint8_t* h_in = nullptr;
+    DevBuf<uint8_t> d_in;
+    size_t in_bytes = 0;
     uint32_t *h_upd_idx = nullptr, *h_rel = nullptr, *h_env = nullptr, *h_minv = nullptr,
              *h_ip = nullptr, *h_out = nullptr;
     ydc_servant_row* h_upd_rows = nullptr;
-    DevBuf<uint32_t> d_upd_idx, d_rel;
-    DevBuf<ydc_servant_row> d_upd_rows;
+    uint32_t *d_upd_idx = nullptr, *d_rel = nullptr, *d_env = nullptr, *d_minv = nullptr,
+             *d_ip = nullptr;
+    ServantRowDev* d_upd_rows = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     BatchPlan plan;
@@ -1400,14 +1406,12 @@ void stream_release(ydc_context* c) {
   if (sm.graph) (void)hipGraphDestroy(sm.graph);
   sm.exec = nullptr;
   sm.graph = nullptr;
-  for (void* q : {(void*)sm.h_upd_idx, (void*)sm.h_rel, (void*)sm.h_env, (void*)sm.h_minv,
-                  (void*)sm.h_ip, (void*)sm.h_out, (void*)sm.h_upd_rows})
-    if (q) (void)hipHostFree(q);
+  if (sm.h_in) (void)hipHostFree(sm.h_in);
+  if (sm.h_out) (void)hipHostFree(sm.h_out);
+  sm.h_in = nullptr;
   sm.h_upd_idx = sm.h_rel = sm.h_env = sm.h_minv = sm.h_ip = sm.h_out = nullptr;
   sm.h_upd_rows = nullptr;
-  sm.d_upd_idx.release();
-  sm.d_rel.release();
-  sm.d_upd_rows.release();
+  sm.d_in.release();
   sm.active = false;
   sm.stale = true;
 }
@@ -1435,23 +1439,15 @@ int stream_capture(ydc_context* c) {
       rc = fail(c, YDC_ERR_HIP, "capture: %s", hipGetErrorString(e));
   };
   const size_t T = sm.max_tasks;
-  if (sm.max_upd) {
-    cap(hipMemcpyAsync(sm.d_upd_idx.p, sm.h_upd_idx, (size_t)sm.max_upd * 4, hipMemcpyHostToDevice, st));
-    cap(hipMemcpyAsync(sm.d_upd_rows.p, sm.h_upd_rows, (size_t)sm.max_upd * sizeof(ydc_servant_row),
-                       hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_apply_rows, dim3(ceil_div(sm.max_upd, 256)), dim3(256), 0, st, sm.d_upd_idx.p,
-                       (const ServantRowDev*)sm.d_upd_rows.p, sm.max_upd, c->n_servants,
-                       c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p, c->d_flags.p);
+  cap(hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, st));
+  if (sm.max_upd + sm.max_rel) {
+    const uint32_t upd_blocks = ceil_div(sm.max_upd, 256);
+    hipLaunchKernelGGL(k_apply_tick, dim3(upd_blocks + ceil_div(sm.max_rel, 256)), dim3(256), 0, st,
+                       sm.d_upd_idx, sm.d_upd_rows, sm.max_upd, upd_blocks, sm.d_rel, sm.max_rel,
+                       c->n_servants, c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p,
+                       c->d_flags.p, c->d_running.p);
   }
-  if (sm.max_rel) {
-    cap(hipMemcpyAsync(sm.d_rel.p, sm.h_rel, (size_t)sm.max_rel * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(sm.max_rel, 256)), dim3(256), 0, st, sm.d_rel.p,
-                       sm.max_rel, c->n_servants, c->d_running.p);
-  }
-  cap(hipMemcpyAsync(c->d_t_env.p, sm.h_env, T * 4, hipMemcpyHostToDevice, st));
-  cap(hipMemcpyAsync(c->d_t_minv.p, sm.h_minv, T * 4, hipMemcpyHostToDevice, st));
-  cap(hipMemcpyAsync(c->d_t_ip.p, sm.h_ip, T * 4, hipMemcpyHostToDevice, st));
-  ydc_task_soa d{c->d_t_env.p, c->d_t_minv.p, c->d_t_ip.p};
+  ydc_task_soa d{sm.d_env, sm.d_minv, sm.d_ip};
   if (rc == YDC_OK) rc = enqueue_front(c, sm.plan, &d);
   if (rc == YDC_OK && sm.plan.wave_path)
     for (uint32_t r = 0; r < sm.passes; ++r) enqueue_pass(c, sm.plan, r, 1u);
@@ -1488,20 +1484,35 @@ int ydc_stream_begin(ydc_context* c, uint32_t max_updates, uint32_t max_releases
   sm.max_upd = max_updates;
   sm.max_rel = max_releases;
   sm.max_tasks = max_tasks;
-  auto pin = [&](void** q, size_t bytes) { return hipHostMalloc(q, std::max<size_t>(bytes, 16)); };
-  HIP_TRY(c, pin((void**)&sm.h_upd_idx, (size_t)max_updates * 4));
-  HIP_TRY(c, pin((void**)&sm.h_upd_rows, (size_t)max_updates * sizeof(ydc_servant_row)));
-  HIP_TRY(c, pin((void**)&sm.h_rel, (size_t)max_releases * 4));
-  HIP_TRY(c, pin((void**)&sm.h_env, (size_t)max_tasks * 4));
-  HIP_TRY(c, pin((void**)&sm.h_minv, (size_t)max_tasks * 4));
-  HIP_TRY(c, pin((void**)&sm.h_ip, (size_t)max_tasks * 4));
-  HIP_TRY(c, pin((void**)&sm.h_out, (size_t)max_tasks * 4));
-  HIP_TRY(c, sm.d_upd_idx.reserve(max_updates));
-  HIP_TRY(c, sm.d_upd_rows.reserve(max_updates));
-  HIP_TRY(c, sm.d_rel.reserve(max_releases));
-  HIP_TRY(c, c->d_t_env.reserve(max_tasks));
-  HIP_TRY(c, c->d_t_minv.reserve(max_tasks));
-  HIP_TRY(c, c->d_t_ip.reserve(max_tasks));
+  // Arena layout (256 B aligned sections).
+  size_t off = 0;
+  auto section = [&](size_t bytes) {
+    const size_t at = off;
+    off += (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t o_idx = section((size_t)max_updates * 4);
+  const size_t o_rows = section((size_t)max_updates * sizeof(ydc_servant_row));
+  const size_t o_rel = section((size_t)max_releases * 4);
+  const size_t o_env = section((size_t)max_tasks * 4);
+  const size_t o_minv = section((size_t)max_tasks * 4);
+  const size_t o_ip = section((size_t)max_tasks * 4);
+  sm.in_bytes = off;
+  HIP_TRY(c, hipHostMalloc((void**)&sm.h_in, sm.in_bytes));
+  HIP_TRY(c, hipHostMalloc((void**)&sm.h_out, std::max<size_t>((size_t)max_tasks * 4, 16)));
+  HIP_TRY(c, sm.d_in.reserve(sm.in_bytes));
+  sm.h_upd_idx = (uint32_t*)(sm.h_in + o_idx);
+  sm.h_upd_rows = (ydc_servant_row*)(sm.h_in + o_rows);
+  sm.h_rel = (uint32_t*)(sm.h_in + o_rel);
+  sm.h_env = (uint32_t*)(sm.h_in + o_env);
+  sm.h_minv = (uint32_t*)(sm.h_in + o_minv);
+  sm.h_ip = (uint32_t*)(sm.h_in + o_ip);
+  sm.d_upd_idx = (uint32_t*)(sm.d_in.p + o_idx);
+  sm.d_upd_rows = (ServantRowDev*)(sm.d_in.p + o_rows);
+  sm.d_rel = (uint32_t*)(sm.d_in.p + o_rel);
+  sm.d_env = (uint32_t*)(sm.d_in.p + o_env);
+  sm.d_minv = (uint32_t*)(sm.d_in.p + o_minv);
+  sm.d_ip = (uint32_t*)(sm.d_in.p + o_ip);
   HIP_TRY(c, c->d_out_idx.reserve(max_tasks));
   sm.active = true;
   sm.stale = true;
