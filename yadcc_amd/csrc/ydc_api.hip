@@ -145,10 +145,20 @@ struct ydc_context {
   DevBuf<DeviceParams> d_prm;
   DeviceParams* h_prm = nullptr;  // pinned
 
-  // Staging for the host-pointer entry point.
-  DevBuf<uint32_t> d_t_env, d_t_minv, d_t_ip, d_out_idx, d_upd_idx;
+  // Staging for the host-pointer entry point (ydc_dispatch): the three request columns in
+  // one pinned arena and its device mirror (one H2D copy), the results (indexes |
+  // running_tasks | utilisation) in another pair (one D2H copy, enqueued right behind the
+  // finalise kernels so that the batch needs a single wait).
+  uint8_t *h_in = nullptr, *h_res = nullptr;
+  size_t h_in_cap = 0, h_res_cap = 0;
+  DevBuf<uint8_t> d_in, d_res;
+  struct {
+    void* dst = nullptr;
+    const void* src = nullptr;
+    size_t bytes = 0;
+  } post_copy;  // D2H copy to enqueue after every finalise of the current batch (bytes == 0: none)
+  DevBuf<uint32_t> d_out_idx, d_upd_idx;
   DevBuf<ydc_servant_row> d_upd_rows;
-  DevBuf<double> d_out_util;
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
@@ -414,8 +424,8 @@ int ydc_destroy(ydc_context* c) {
                   &c->d_flags, &c->d_class_of, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
                   &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist,
                   &c->d_row_total, &c->d_self_lo, &c->d_self_hi, &c->d_chunk_consuming,
-                  &c->d_before, &c->d_slot_of, &c->d_left, &c->d_running_out, &c->d_t_env,
-                  &c->d_t_minv, &c->d_t_ip, &c->d_out_idx, &c->d_upd_idx})
+                  &c->d_before, &c->d_slot_of, &c->d_left, &c->d_running_out, &c->d_out_idx,
+                  &c->d_upd_idx})
     b->release();
   for (auto* b : {&c->d_cls_env, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
   c->d_cls_by_g.release();
@@ -429,8 +439,11 @@ int ydc_destroy(ydc_context* c) {
   c->d_runs.release();
   c->d_dirty.release();
   c->d_prm.release();
-  c->d_out_util.release();
   if (c->h_prm) (void)hipHostFree(c->h_prm);
+  if (c->h_in) (void)hipHostFree(c->h_in);
+  if (c->h_res) (void)hipHostFree(c->h_res);
+  c->d_in.release();
+  c->d_res.release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& k : c->ksamples) {
@@ -917,6 +930,9 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
                                   (launched - 1) & 63))
       return rc;
     mark(c, 7);
+    if (c->post_copy.bytes)  // a finalise that was gated out is repeated, and so is the copy
+      HIP_TRY(c, hipMemcpyAsync(c->post_copy.dst, c->post_copy.src, c->post_copy.bytes,
+                                hipMemcpyDeviceToHost, c->stream));
     int done = read_outcome(c, p, first, launched, rounds);
     if (done < 0) return done;
     if (done) {
@@ -980,6 +996,9 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
     }
     if (int rc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running, kNone)) return rc;
     mark(c, 7);
+    if (c->post_copy.bytes)
+      HIP_TRY(c, hipMemcpyAsync(c->post_copy.dst, c->post_copy.src, c->post_copy.bytes,
+                                hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
@@ -1021,29 +1040,46 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
   if (!c || (N && (!tk || !out_idx))) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, c->d_t_env.reserve(N));
-  HIP_TRY(c, c->d_t_minv.reserve(N));
-  HIP_TRY(c, c->d_t_ip.reserve(N));
-  HIP_TRY(c, c->d_out_idx.reserve(N));
-  if (out_util) HIP_TRY(c, c->d_out_util.reserve(N));
+  const uint32_t S = c->n_servants;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // in: env | min_version | requestor_ip        out: idx | running_tasks | utilisation
+  const size_t col = pad((size_t)N * 4), in_bytes = 3 * col;
+  const size_t o_run = pad((size_t)N * 4), o_util = o_run + pad((size_t)(out_running ? S : 0) * 4);
+  const size_t res_bytes = o_util + (out_util ? (size_t)N * 8 : 0);
+  auto pinned = [&](uint8_t** q, size_t* cap, size_t want) -> hipError_t {
+    if (want <= *cap) return hipSuccess;
+    if (*q) (void)hipHostFree(*q);
+    *q = nullptr;
+    *cap = 0;
+    want = std::max<size_t>(want + want / 2, 4096);
+    hipError_t e = hipHostMalloc((void**)q, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+  };
+  HIP_TRY(c, pinned(&c->h_in, &c->h_in_cap, in_bytes));
+  HIP_TRY(c, pinned(&c->h_res, &c->h_res_cap, res_bytes));
+  HIP_TRY(c, c->d_in.reserve(std::max<size_t>(in_bytes, 256)));
+  HIP_TRY(c, c->d_res.reserve(std::max<size_t>(res_bytes, 256)));
   if (N) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_t_env.p, tk->env_id, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_t_minv.p, tk->min_version, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_t_ip.p, tk->requestor_ip, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->h_in, tk->env_id, (size_t)N * 4);
+    std::memcpy(c->h_in + col, tk->min_version, (size_t)N * 4);
+    std::memcpy(c->h_in + 2 * col, tk->requestor_ip, (size_t)N * 4);
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  ydc_task_soa d{c->d_t_env.p, c->d_t_minv.p, c->d_t_ip.p};
-  int rc = ydc_dispatch_device(c, &d, N, flags, c->d_out_idx.p, out_util ? c->d_out_util.p : nullptr,
-                               nullptr);
+  ydc_task_soa d{(const uint32_t*)c->d_in.p, (const uint32_t*)(c->d_in.p + col),
+                 (const uint32_t*)(c->d_in.p + 2 * col)};
+  c->post_copy.dst = c->h_res;
+  c->post_copy.src = c->d_res.p;
+  c->post_copy.bytes = res_bytes;
+  int rc = ydc_dispatch_device(c, &d, N, flags, (uint32_t*)c->d_res.p,
+                               out_util ? (double*)(c->d_res.p + o_util) : nullptr,
+                               out_running && S ? (uint32_t*)(c->d_res.p + o_run) : nullptr);
+  c->post_copy.bytes = 0;
   if (rc) return rc;
-  if (N) {
-    HIP_TRY(c, hipMemcpyAsync(out_idx, c->d_out_idx.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out_util)
-      HIP_TRY(c, hipMemcpyAsync(out_util, c->d_out_util.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
-  }
-  if (out_running && c->n_servants)
-    HIP_TRY(c, hipMemcpyAsync(out_running, c->d_running_out.p, (size_t)c->n_servants * 4,
-                              hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // ydc_dispatch_device has waited for the stream: the results are in the pinned arena.
+  if (N) std::memcpy(out_idx, c->h_res, (size_t)N * 4);
+  if (out_running && S) std::memcpy(out_running, c->h_res + o_run, (size_t)S * 4);
+  if (out_util && N) std::memcpy(out_util, c->h_res + o_util, (size_t)N * 8);
   return YDC_OK;
 }
 
