@@ -54,6 +54,10 @@ struct MatchBuffers {
   const ClassState* guess0;  // [K * C] level guesses (start states of pass 0)
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
+  // [K * C] state after the first kEarlyAt requests of every chunk (<= 64 classes only): a
+  // replay whose start was off by a slot or two is back on its previous track within a few
+  // requests, and stops there instead of at the end of the block.
+  ClassState* early;
   unsigned long long* claim; // [K] (batch, pass) stamp of the pass in which a wave took the chunk
   uint32_t* slot_of;         // [N] global rank of the slot each request takes (or kIdx*)
   // Multi-GPU: this rank's chunks continue the previous rank's. boundary_in (C
@@ -65,6 +69,8 @@ struct MatchBuffers {
   uint32_t* sampled;  // sampled counts of changed end states, same indexing
   uint32_t flag_mask;
 };
+
+constexpr uint32_t kEarlyAt = 16;  // requests into a chunk at which MatchBuffers::early is taken
 
 // Everything a lane keeps about one of its classes.
 struct LaneClass {
@@ -518,6 +524,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
     };
     stage(t0);
+    ClassState early_cp{};
+    if (W == 1 && pass != 0 && lane < C) early_cp = B.early[(size_t)kc * C + lane];
 
     for (uint32_t tb = t0; tb < t1; tb += 64) {
       // ---- checkpoint: stop if the previous replay was in the same state here ----
@@ -569,6 +577,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 
       const uint64_t has_self = __ballot(slo != kNone);
       uint32_t res = kIdxTimeout;
+      uint32_t keep = 64;  // results of this block to store (fewer after an early stop)
       const uint32_t cnt = min(64u, t1 - tb);
 
       // General step for request i: holes, own-servant heads, last-resort self pick. The
@@ -658,9 +667,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         const uint32_t rmask4 = (R << 2) - 1;
         const uint64_t my_mask = ((uint64_t)mhi[0] << 32) | mlo[0];
         uint32_t i = 0;
-        while (i < cnt) {
+        // The first block of a chunk pauses after kEarlyAt requests for the early checkpoint.
+        uint32_t lim = tb == t0 && cnt > kEarlyAt ? kEarlyAt : cnt;
+        for (;;) {
+        while (i < lim) {
           const uint32_t budget = top_up();
-          const uint32_t n = min(cnt - i, budget);
+          const uint32_t n = min(lim - i, budget);
           const uint32_t off = ((q.cursor + 1) & w.rmask) << 2;  // ring offset of `next`
           // Requests that need a look before the plain step.
           const uint64_t hole_hit = holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull;
@@ -673,6 +685,26 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             general_step(i);
             ++i;
           }
+        }
+        if (lim == cnt) break;
+        {
+          const ClassState sn = w.state(0);
+          bool differs = false;
+          if (lane < C) {
+            if (pass == 0) {
+              B.early[(size_t)kc * C + lane] = sn;
+            } else if (!class_state_equal(early_cp, sn)) {
+              differs = true;
+              B.early[(size_t)kc * C + lane] = sn;
+            }
+          }
+          if (pass != 0 && __ballot(differs) == 0) {
+            stopped_early = true;  // the rest of the previous replay stands
+            keep = kEarlyAt;
+            break;
+          }
+        }
+        lim = cnt;
         }
       } else {
         uint32_t budget = 0;
@@ -739,7 +771,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
       // No eligible class at all: EnvironmentNotFound (task_dispatcher.cc:105-108).
       if (many == 0) res = kIdxEnvNotFound;
-      if (tl < t1) B.slot_of[tl] = res;
+      if (tl < t1 && lane < keep) B.slot_of[tl] = res;
+      if (stopped_early) break;
     }
     if (count_sims && lane == 0) atomicAdd(&prm->chunk_sims, 1u);
     if (stopped_early) return;  // same remainder as last time: the end state stands

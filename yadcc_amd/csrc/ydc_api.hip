@@ -93,7 +93,7 @@ struct ydc_context {
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
   DevBuf<uint32_t> d_running_out;
-  DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint;
+  DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint, d_early;
   DevBuf<unsigned long long> d_claim;
   uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
 
@@ -435,6 +435,7 @@ int ydc_destroy(ydc_context* c) {
   c->d_guess[0].release();
   c->d_endst.release();
   c->d_checkpoint.release();
+  c->d_early.release();
   c->d_claim.release();
   c->d_runs.release();
   c->d_dirty.release();
@@ -665,6 +666,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_endst.reserve((size_t)K * C + 1));
   if (!p.use_generic) {
     HIP_TRY(c, c->d_checkpoint.reserve((size_t)ceil_div(std::max(N, 1u), 64) * C + 1));
+    HIP_TRY(c, c->d_early.reserve((size_t)K * C + 1));
     if ((size_t)K + 1 > c->d_claim.cap) {
       // Claims compare against ever-growing (batch, pass) stamps: a fresh array starts at 0.
       HIP_TRY(c, c->d_claim.reserve((size_t)K + 1));
@@ -689,6 +691,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.guess0 = c->d_guess[0].p;
     p.mb.endst = c->d_endst.p;
     p.mb.checkpoint = c->d_checkpoint.p;
+    p.mb.early = c->d_early.p;
     p.mb.claim = c->d_claim.p;
     p.mb.slot_of = c->d_slot_of.p;
     p.mb.boundary_in = nullptr;
