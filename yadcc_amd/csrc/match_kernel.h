@@ -52,6 +52,9 @@ constexpr uint32_t kPassSlots = 64;  // DeviceParams::n_changed is indexed by pa
 
 struct MatchBuffers {
   const ClassState* guess0;  // [K * C] level guesses (start states of pass 0)
+  // Non-NULL (<= 64 classes, single GPU): pass 0 works its level guesses out itself from the
+  // prefix of the chunks' consuming counts, and guess0 is not used.
+  const uint32_t* before;
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
   // [K * C] state after the first kEarlyAt requests of every chunk (<= 64 classes only): a
@@ -403,7 +406,96 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   while ((1u << steps) < C) ++steps;
 
   // ---- start state; is there anything to do? ----
-  {
+  ClassState next_guess{};  // pass 0 with own guesses: the level guess of the next chunk
+  const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
+  if (own_guess) {
+    // Level guesses of this chunk and the next: two lower bounds in the lane's class list,
+    // walked together (the loads of the two searches overlap).
+    ClassState st{};
+    if (lane < C) {
+      const uint32_t n0 = B.before[kc], n1 = B.before[kc + 1];
+      const uint32_t b = L.cls_begin[lane], e = L.cls_begin[lane + 1];
+      uint32_t c0 = 0, c1 = 0;
+      if (L.list_p && C <= 4) {
+        // (filled in below by the whole wave)
+      } else if (L.list_p) {
+        uint32_t lo0 = b, hi0 = e, lo1 = b, hi1 = e;
+        while (lo0 < hi0 || lo1 < hi1) {
+          const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+          const uint32_t v0 = lo0 < hi0 ? L.list_p[m0] : 0u, v1 = lo1 < hi1 ? L.list_p[m1] : 0u;
+          if (lo0 < hi0) {
+            if (v0 < n0) lo0 = m0 + 1; else hi0 = m0;
+          }
+          if (lo1 < hi1) {
+            if (v1 < n1) lo1 = m1 + 1; else hi1 = m1;
+          }
+        }
+        c0 = lo0;
+        c1 = lo1;
+      } else {
+        c0 = b + min(n0, e - b);
+        c1 = b + min(n1, e - b);
+      }
+      st.cursor = st.lo = c0;
+      st.hown_lo = st.hown_hi = kNone;
+      next_guess = st;
+      next_guess.cursor = next_guess.lo = c1;
+    }
+    if (L.list_p && C <= 4) {
+      // A handful of classes: the wave searches together, 64 probes per search and round
+      // (three rounds for a list of 2^18 entries instead of eighteen dependent loads), the
+      // 2 * C searches side by side.
+      const uint32_t n0 = B.before[kc], n1 = B.before[kc + 1];
+      uint32_t lo[8], hi[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t c = (uint32_t)q >> 1;
+        lo[q] = hi[q] = 0;
+        if (c < C) {
+          lo[q] = L.cls_begin[c];
+          hi[q] = L.cls_begin[c + 1];
+        }
+      }
+      for (;;) {
+        bool any = false;
+        uint32_t v[8], step[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          step[q] = (hi[q] - lo[q] + 63) / 64;
+          v[q] = 0xFFFFFFFFu;  // "not less": an empty segment
+          if (hi[q] > lo[q]) {
+            any = true;
+            const uint32_t first = lo[q] + lane * step[q];
+            if (first < hi[q]) v[q] = L.list_p[min(first + step[q] - 1, hi[q] - 1)];
+          }
+        }
+        if (!any) break;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (hi[q] > lo[q]) {
+            const uint32_t target = (q & 1) ? n1 : n0;
+            // Segments wholly below the target form a prefix (the list is sorted).
+            const uint32_t k = (uint32_t)__popcll(__ballot(v[q] < target));
+            const uint32_t nlo = lo[q] + k * step[q];
+            if (nlo >= hi[q] || step[q] == 1) {
+              lo[q] = hi[q] = min(nlo, hi[q]);  // found
+            } else {
+              lo[q] = nlo;  // the answer is in this segment, whose last entry is >= target
+              hi[q] = min(hi[q], nlo + step[q]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (lane == ((uint32_t)q >> 1) && lane < C) {
+          if (q & 1) next_guess.cursor = next_guess.lo = lo[q];
+          else st.cursor = st.lo = next_guess.cursor = next_guess.lo = lo[q];
+        }
+      }
+    }
+    w.set_state(0, st, lane, C);
+  } else {
     const ClassState* start;
     if (pass == 0) {
       start = B.guess0 + (size_t)kc * C;
@@ -788,7 +880,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         if (pass == 0) {
           *e = s;
           // Is the next chunk's level guess what this chunk really ends in?
-          if (kc + 1 < n_chunks) differs |= !class_state_equal(B.guess0[(size_t)(kc + 1) * C + c], s);
+          if (kc + 1 < n_chunks)
+            differs |= !class_state_equal(own_guess ? next_guess : B.guess0[(size_t)(kc + 1) * C + c], s);
         } else {
           const ClassState old = *e;
           if (!class_state_equal(old, s)) {

@@ -163,6 +163,7 @@ struct ydc_context {
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
   bool opt_fused_class = true;
+  bool opt_own_guess = true;
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -408,6 +409,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_CHUNK_SIZE")) c->opt_chunk_size = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_TARGET_CHUNKS")) c->opt_target_chunks = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
+  if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -691,6 +693,11 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.guess0 = c->d_guess[0].p;
     p.mb.endst = c->d_endst.p;
     p.mb.checkpoint = c->d_checkpoint.p;
+    // <= 64 classes on one GPU, one servant per host: pass 0 computes its level guesses
+    // itself (no k_guess_init; the shared-host path reads the guess array).
+    p.mb.before = p.W == 1 && !p.any_shared && c->group.n_ranks <= 1 && c->opt_own_guess
+                      ? c->d_before.p
+                      : nullptr;
     p.mb.early = c->d_early.p;
     p.mb.claim = c->d_claim.p;
     p.mb.slot_of = c->d_slot_of.p;
@@ -801,7 +808,7 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
   const uint32_t N = p.N, S = p.S, C = p.C, K = p.K;
   DeviceParams* prm = c->d_prm.p;
   hipStream_t st = c->stream;
-  if (N && C)
+  if (N && C && !(p.wave_path && p.mb.before && !d_base))
     YDC_LAUNCH(c, "k_guess_init", k_guess_init, dim3(ceil_div(K * C, 256)), dim3(256), 0, st, p.L,
                c->d_before.p, K, d_base, c->d_guess[0].p, c->d_dirty.p);
   mark(c, 5);
