@@ -279,8 +279,89 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_TAILFILL_1 "v_readlane_b32 s91, %[mhi], %[ip]\n"
 #define YDC_TAILFILL_N "s_nop 0\n"
 
-#define YDC_LOOP_BODY(K, RED, TAILFILL, LASTLANE)                                  \
-  "L" #K "_loop%=:\n"                                                              \
+// Two requests per iteration (>= 5 classes): the two selections and DPP chains are
+// independent until the winners are known, so they fill each other's wait states; when the
+// winners are different lanes (the usual case with many classes) both advance under one exec
+// mask, otherwise only the first request is committed and the second one starts the next
+// iteration. Plain requests only (neither of the two `special`), and both served.
+// s[92:93] = class mask of the second request, s[94:95] = its winner, s[96:97] scratch;
+// %[s0] / %[s1] double as the second request's maximum / result.
+#define YDC_MAX2(dst, first, ctrl) "v_max_u32_dpp " dst ", " first " " ctrl " bound_ctrl:0\n"
+#define YDC_P1                                                                        \
+  YDC_MAX2("%[t]", "%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")              \
+  "v_readlane_b32 s90, %[mlo], %[ip]\n"                                               \
+  YDC_MAX2("%[t1]", "%[c1], %[c1]", "row_shr:1 row_mask:0xf bank_mask:0xf")
+#define YDC_P2                                                                        \
+  YDC_MAX2("%[t]", "%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")              \
+  "v_readlane_b32 s91, %[mhi], %[ip]\n"                                               \
+  YDC_MAX2("%[t1]", "%[t1], %[t1]", "row_shr:2 row_mask:0xf bank_mask:0xf")
+#define YDC_PN(ctrl)                                                                  \
+  YDC_MAX2("%[t]", "%[t], %[t]", ctrl) "s_nop 0\n" YDC_MAX2("%[t1]", "%[t1], %[t1]", ctrl)
+#define YDC_PRED_3 YDC_P1 YDC_P2 YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf")
+#define YDC_PRED_4 YDC_PRED_3 YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf")
+#define YDC_PRED_5 YDC_PRED_4 YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf")
+#define YDC_PRED_6 YDC_PRED_5 YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define YDC_COMMIT                                                                    \
+  "s_waitcnt lgkmcnt(0)\n"                                                            \
+  "v_mov_b32 %[hq], %[nq]\n"                                                          \
+  "v_add_u32 %[off], 4, %[off]\n"                                                     \
+  "v_and_b32 %[off], %[rmask4], %[off]\n"                                             \
+  "v_add_u32 %[a], %[base], %[off]\n"                                                 \
+  "ds_read_b32 %[nq], %[a]\n"                                                         \
+  "v_add_u32 %[cur], 1, %[cur]\n"                                                     \
+  "s_mov_b64 exec, -1\n"
+#define YDC_PAIR(K, PRED, LASTLANE)                                                   \
+  "s_cmp_eq_u32 %[pair], 0\n"                                                         \
+  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
+  "s_cmp_eq_u32 %[n], 0\n"                                                            \
+  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
+  "s_lshr_b64 s[96:97], %[special], m0\n"                                             \
+  "s_and_b32 s96, s96, 3\n"                                                           \
+  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
+  "s_add_u32 %[ip], %[ip], 1\n"                                                       \
+  "v_readlane_b32 s92, %[mlo], %[ip]\n"                                               \
+  "v_readlane_b32 s93, %[mhi], %[ip]\n"                                               \
+  "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                          \
+  "s_add_u32 %[ip], %[ip], 1\n"                                                       \
+  "v_cndmask_b32 %[c1], 0, %[hq], s[92:93]\n" PRED                                    \
+  "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                        \
+  "v_readlane_b32 %[s0], %[t1], " LASTLANE "\n"                                       \
+  "s_cmp_eq_u32 %[mn], 0\n"                                                           \
+  "s_cbranch_scc1 L" #K "_bail%=\n"                                                   \
+  "s_cmp_eq_u32 %[s0], 0\n"                                                           \
+  "s_cbranch_scc1 L" #K "_bail%=\n"                                                   \
+  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
+  "v_cmp_eq_u32_e64 s[94:95], %[s0], %[c1]\n"                                         \
+  "s_not_b32 %[sp], %[mn]\n"                                                          \
+  "s_not_b32 %[s1], %[s0]\n"                                                          \
+  "s_and_b64 s[96:97], vcc, s[94:95]\n"                                               \
+  "s_cbranch_scc1 L" #K "_conflict%=\n"                                               \
+  "s_or_b64 exec, vcc, s[94:95]\n" YDC_COMMIT                                         \
+  "v_writelane_b32 %[res], %[sp], m0\n"                                               \
+  "s_add_u32 m0, m0, 1\n"                                                             \
+  "v_writelane_b32 %[res], %[s1], m0\n"                                               \
+  "s_add_u32 m0, m0, 1\n"                                                             \
+  "s_add_u32 %[n], %[n], -2\n"                                                        \
+  "s_cbranch_scc1 L" #K "_loop%=\n"                                                   \
+  "s_branch L_out%=\n"                                                                \
+  "L" #K "_conflict%=:\n"                                                             \
+  "s_mov_b64 exec, vcc\n" YDC_COMMIT                                                  \
+  "v_writelane_b32 %[res], %[sp], m0\n"                                               \
+  "s_mov_b64 s[90:91], s[92:93]\n"                                                    \
+  "s_add_u32 m0, m0, 1\n"                                                             \
+  "s_add_u32 %[ip], %[ip], -1\n"                                                      \
+  "s_add_u32 %[n], %[n], -1\n"                                                        \
+  "s_branch L" #K "_loop%=\n"                                                         \
+  "L" #K "_bail%=:\n"                                                                 \
+  "v_readlane_b32 s90, %[mlo], m0\n"                                                  \
+  "v_readlane_b32 s91, %[mhi], m0\n"                                                  \
+  "s_add_u32 %[ip], %[ip], -2\n"                                                      \
+  "s_nop 1\n"                                                                         \
+  "s_branch L" #K "_cont%=\n"
+
+#define YDC_LOOP_BODY(K, RED, TAILFILL, LASTLANE, PAIR)                            \
+  "L" #K "_loop%=:\n" PAIR                                                         \
+  "L" #K "_single%=:\n"                                                            \
   "s_bitcmp1_b64 %[special], m0\n"                                                 \
   "s_cbranch_scc1 L" #K "_special%=\n"                                             \
   "L" #K "_cont%=:\n"                                                              \
@@ -331,8 +412,9 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 __device__ __forceinline__ uint32_t match_fast_loop(
     uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
     uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& res, uint32_t& hq,
-    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4, uint32_t steps) {
-  uint32_t status, c, t, a, mn, sp, ip, s0, s1, m0save;
+    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4, uint32_t steps,
+    uint32_t pair) {
+  uint32_t status, c, t, c1, t1, a, mn, sp, ip, s0, s1, m0save;
   asm volatile(
       "s_mov_b32 %[m0s], m0\n"
       "s_mov_b32 %[st], 0\n"
@@ -353,12 +435,12 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_cmp_eq_u32 %[steps], 5\n"
       "s_cbranch_scc1 L5_loop%=\n"
       "s_branch L6_loop%=\n"
-      YDC_LOOP_BODY(1, YDC_RED_1(1), YDC_TAILFILL_1, "1")
-      YDC_LOOP_BODY(2, YDC_RED_2(2), YDC_TAILFILL_N, "3")
-      YDC_LOOP_BODY(3, YDC_RED_3(3), YDC_TAILFILL_N, "7")
-      YDC_LOOP_BODY(4, YDC_RED_4(4), YDC_TAILFILL_N, "15")
-      YDC_LOOP_BODY(5, YDC_RED_5(5), YDC_TAILFILL_N, "31")
-      YDC_LOOP_BODY(6, YDC_RED_6(6), YDC_TAILFILL_N, "63")
+      YDC_LOOP_BODY(1, YDC_RED_1(1), YDC_TAILFILL_1, "1", "")
+      YDC_LOOP_BODY(2, YDC_RED_2(2), YDC_TAILFILL_N, "3", "")
+      YDC_LOOP_BODY(3, YDC_RED_3(3), YDC_TAILFILL_N, "7", YDC_PAIR(3, YDC_PRED_3, "7"))
+      YDC_LOOP_BODY(4, YDC_RED_4(4), YDC_TAILFILL_N, "15", YDC_PAIR(4, YDC_PRED_4, "15"))
+      YDC_LOOP_BODY(5, YDC_RED_5(5), YDC_TAILFILL_N, "31", YDC_PAIR(5, YDC_PRED_5, "31"))
+      YDC_LOOP_BODY(6, YDC_RED_6(6), YDC_TAILFILL_N, "63", YDC_PAIR(6, YDC_PRED_6, "63"))
       "L_slow%=:\n"
       "s_mov_b32 %[st], 1\n"
       "L_out%=:\n"
@@ -366,12 +448,13 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b32 m0, %[m0s]\n"
       : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hq] "+v"(hq), [nq] "+v"(nq),
-        [cur] "+v"(cur), [off] "+v"(off), [c] "=&v"(c), [t] "=&v"(t), [a] "=&v"(a), [mn] "=&s"(mn),
+        [cur] "+v"(cur), [off] "+v"(off), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
+        [a] "=&v"(a), [mn] "=&s"(mn),
         [sp] "=&s"(sp), [ip] "=&s"(ip), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
       : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [special] "s"(special),
         [hh] "s"(hole_hit), [hs] "s"(has_self), [base] "v"(base), [rmask4] "s"(rmask4),
-        [steps] "s"(steps)
-      : "vcc", "scc", "memory", "s90", "s91", "s92", "s93");
+        [steps] "s"(steps), [pair] "s"(pair)
+      : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
   return status;
 }
 
@@ -404,6 +487,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   const uint32_t thresh = R / 4 < 4 ? 4 : (R / 4 > 12 ? 12 : R / 4);
   uint32_t steps = 1;  // DPP steps of the min over the class lanes
   while ((1u << steps) < C) ++steps;
+  // Two requests per iteration of the fast loop (match_fast_loop): with few classes the two
+  // winners are mostly the same lane and the pairing only costs.
+  const uint32_t pair_mode = (flags & 4u) && steps >= 3 ? 1u : 0u;
 
   // ---- start state; is there anything to do? ----
   ClassState next_guess{};  // pass 0 with own guesses: the level guess of the next chunk
@@ -770,7 +856,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           const uint64_t hole_hit = holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull;
           const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
                                               hole_hit, has_self, res, q.hq, q.nq, q.cursor, off,
-                                              base, rmask4, steps);
+                                              base, rmask4, steps,
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode));
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
           if (st == 1) {

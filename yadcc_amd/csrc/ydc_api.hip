@@ -164,6 +164,7 @@ struct ydc_context {
   uint32_t opt_target_chunks = 2048;
   bool opt_fused_class = true;
   bool opt_own_guess = true;
+  bool opt_pair = true;
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -410,6 +411,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_TARGET_CHUNKS")) c->opt_target_chunks = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
+  if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -841,6 +843,7 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
 void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t device_check) {
   const size_t lds = 16384;
   device_check |= c->debug_sim ? 2u : 0u;
+  device_check |= c->opt_pair ? 4u : 0u;
   DeviceParams* prm = c->d_prm.p;
   if (p.W == 1) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
