@@ -4,7 +4,7 @@
 Draws registries and batches from the seeded families of tests/cases.py with random shapes
 (1..8 digests, shared hosts, oversubscription, initial running_tasks, unknown digests, self
 requests, forced chunk sizes) for a given number of seconds and reports every mismatch.
-    python tools/fuzz_parity.py [seconds=60] [first_seed=1000]
+    python tests/tools/fuzz_parity.py [seconds=60] [first_seed=1000]
 Needs the GPU; the oracle is the checker (test infrastructure)."""
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oraclebind as O  # noqa: E402
 from tests import cases  # noqa: E402
 from yadcc_amd import binding, pack  # noqa: E402
