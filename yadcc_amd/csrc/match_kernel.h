@@ -465,19 +465,28 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
                                                    uint32_t flags, uint32_t rshift,
                                                    uint32_t init_fill, DeviceParams* prm) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
-  if (prm->need_shared) return;  // the batch went through the sequential path
-  // An earlier pass found every chunk consistent: nothing to do.
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
-  if (device_check && pass > 0 && B.flags[(pass - 1) & B.flag_mask] == 0) return;
-  const uint32_t lane = threadIdx.x;
   uint32_t kc = blockIdx.x;  // chunk
+  // Everything the wave needs to decide whether it has work, fetched in one round trip.
+  const uint32_t need_shared = prm->need_shared;
+  const uint32_t batch_seq = prm->batch_seq;
+  const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
+  const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
+  uint32_t before0 = 0, before1 = 0;
+  if (own_guess && kc < n_chunks) {
+    before0 = B.before[kc];
+    before1 = B.before[kc + 1];
+  }
+  if (need_shared) return;        // the batch went through the sequential path
+  if (prev_changed == 0) return;  // an earlier pass found every chunk consistent
+  const uint32_t lane = threadIdx.x;
   if (kc >= n_chunks) return;
   const uint32_t C = L.n_classes;
   const bool multi = B.boundary_in != nullptr;
   // Unique per pass launch and ever growing (the batch counter lives on the device, so a
   // replayed graph gets fresh stamps too).
-  const unsigned long long stamp = ((unsigned long long)prm->batch_seq << 16) | (pass + 1);
+  const unsigned long long stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
 
   // Fixed layout: ranks in the first 8 KB, generation indexes 8 KB further (the asm loop
   // addresses the second array with an immediate offset). C << rshift <= 2048.
@@ -493,13 +502,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 
   // ---- start state; is there anything to do? ----
   ClassState next_guess{};  // pass 0 with own guesses: the level guess of the next chunk
-  const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
   if (own_guess) {
     // Level guesses of this chunk and the next: two lower bounds in the lane's class list,
     // walked together (the loads of the two searches overlap).
     ClassState st{};
     if (lane < C) {
-      const uint32_t n0 = B.before[kc], n1 = B.before[kc + 1];
+      const uint32_t n0 = before0, n1 = before1;
       const uint32_t b = L.cls_begin[lane], e = L.cls_begin[lane + 1];
       uint32_t c0 = 0, c1 = 0;
       if (L.list_p && C <= 4) {
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       // A handful of classes: the wave searches together, 64 probes per search and round
       // (three rounds for a list of 2^18 entries instead of eighteen dependent loads), the
       // 2 * C searches side by side.
-      const uint32_t n0 = B.before[kc], n1 = B.before[kc + 1];
+      const uint32_t n0 = before0, n1 = before1;
       uint32_t lo[8], hi[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
