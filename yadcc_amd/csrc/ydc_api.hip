@@ -138,6 +138,10 @@ struct ydc_context {
     hipGraphExec_t exec = nullptr;
     BatchPlan plan;
     uint64_t ticks = 0, recaptures = 0, eager_fallbacks = 0;
+    // Passes to capture: one more than the last eager batch needed, to begin with; after 256
+    // ticks that all needed fewer, exactly the most any of them needed (a pre-launched pass
+    // that finds nothing to do still costs a launch); more again after a tick that ran out.
+    uint32_t want_passes = 0, window_max = 0, window_ticks = 0;
   } stream_mode;
   DevBuf<ClassRun> d_runs;
   DevBuf<uint8_t> d_dirty;
@@ -1479,7 +1483,8 @@ int stream_capture(ydc_context* c) {
     return fail(c, YDC_ERR_TOO_MANY_CLASSES, "streaming mode needs <= %u servant classes",
                 kMaxWaveClasses);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  sm.passes = std::max(2u, std::min(c->round_hint + 1, 12u));
+  sm.passes = sm.want_passes ? sm.want_passes : std::max(2u, std::min(c->round_hint + 1, 12u));
+  sm.window_max = sm.window_ticks = 0;
   hipStream_t st = c->stream;
   HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
   int rc = YDC_OK;
@@ -1563,6 +1568,7 @@ int ydc_stream_begin(ydc_context* c, uint32_t max_updates, uint32_t max_releases
   sm.d_minv = (uint32_t*)(sm.d_in.p + o_minv);
   sm.d_ip = (uint32_t*)(sm.d_in.p + o_ip);
   HIP_TRY(c, c->d_out_idx.reserve(max_tasks));
+  sm.want_passes = sm.window_max = sm.window_ticks = 0;
   sm.active = true;
   sm.stale = true;
   return YDC_OK;
@@ -1654,6 +1660,7 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
         return rc;
       HIP_TRY(c, hipMemcpy(sm.h_out, c->d_out_idx.p, (size_t)sm.max_tasks * 4, hipMemcpyDeviceToHost));
       c->round_hint = rounds;
+      sm.want_passes = std::min(rounds + 1, 12u);
       sm.stale = true;
     } else {
       for (uint32_t r = 0; r < sm.passes; ++r)
@@ -1661,6 +1668,14 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
           rounds = r + 1;
           break;
         }
+      sm.window_max = std::max(sm.window_max, rounds);
+      if (++sm.window_ticks >= 256) {
+        if (sm.window_max < sm.passes && sm.passes > 2) {
+          sm.want_passes = std::max(2u, sm.window_max);
+          sm.stale = true;
+        }
+        sm.window_max = sm.window_ticks = 0;
+      }
     }
   }
   fill_stats(c, p, rounds);
