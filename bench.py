@@ -274,13 +274,23 @@ def main():
             ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
             out["cpu_baseline"] = base
             out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if sharded:
         ctx.group_destroy()
     ctx.close()
+    # ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C
+    # stdio, which would otherwise be flushed behind it at exit. Every rank flushes before the
+    # last barrier; rank 0 prints after it.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if line:
+        print(line, flush=True)
 
 
 def pmc_traffic(kernel, config):

@@ -925,6 +925,32 @@ void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   s.timeouts = p.N - s.env_not_found - std::min(p.N - s.env_not_found, s.granted);
 }
 
+// Per-kernel totals of the dispatch just finished as JSON: {"name": [launches, total_ms], ...}
+// (profiling only: one event pair per YDC_LAUNCH).
+void collect_kernel_profile(ydc_context* c) {
+  std::vector<std::pair<std::string, std::pair<int, double>>> acc;
+  for (size_t i = 0; i < c->ksamples_used; ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ksamples[i].a, c->ksamples[i].b) != hipSuccess) continue;
+    bool found = false;
+    for (auto& e : acc)
+      if (e.first == c->ksamples[i].name) {
+        e.second.first++;
+        e.second.second += ms;
+        found = true;
+      }
+    if (!found) acc.push_back({c->ksamples[i].name, {1, ms}});
+  }
+  std::string j = "{";
+  for (size_t i = 0; i < acc.size(); ++i) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s\"%s\": [%d, %.6f]", i ? ", " : "", acc[i].first.c_str(),
+             acc[i].second.first, acc[i].second.second);
+    j += buf;
+  }
+  c->kprofile_json = j + "}";
+}
+
 // Passes [launched, ...) in groups until one finds every chunk consistent, each group
 // followed by the (gated) finalise and one look at the counters.
 int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t launched, uint32_t flags,
@@ -1027,28 +1053,7 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   if (c->profiling) {
     for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&s.stage_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&s.stage_ms[YDC_STAGE_TOTAL], c->ev[0], c->ev[7]);
-    // Per-kernel totals of this dispatch as JSON: {"name": [launches, total_ms], ...}
-    std::vector<std::pair<std::string, std::pair<int, double>>> acc;
-    for (size_t i = 0; i < c->ksamples_used; ++i) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, c->ksamples[i].a, c->ksamples[i].b) != hipSuccess) continue;
-      bool found = false;
-      for (auto& e : acc)
-        if (e.first == c->ksamples[i].name) {
-          e.second.first++;
-          e.second.second += ms;
-          found = true;
-        }
-      if (!found) acc.push_back({c->ksamples[i].name, {1, ms}});
-    }
-    std::string j = "{";
-    for (size_t i = 0; i < acc.size(); ++i) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "%s\"%s\": [%d, %.6f]", i ? ", " : "", acc[i].first.c_str(),
-               acc[i].second.first, acc[i].second.second);
-      j += buf;
-    }
-    c->kprofile_json = j + "}";
+    collect_kernel_profile(c);
   }
   return YDC_OK;
 }
@@ -1433,6 +1438,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   HIP_TRY(c, hipStreamSynchronize(st));
   HIP_TRY(c, hipGetLastError());
   fill_stats(c, p, rounds);
+  if (c->profiling) collect_kernel_profile(c);
   return YDC_OK;
 }
 
