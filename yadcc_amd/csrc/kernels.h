@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, co
                                                      const uint8_t* consumed, uint32_t n_servants,
                                                      uint32_t* running_out, uint32_t* out_a,
                                                      uint32_t* out_b, uint32_t check_slot,
-                                                     uint32_t count_all, DeviceParams* prm) {
+                                                     uint32_t count_all, DeviceParams* prm,
+                                                     uint32_t* taken_out) {
   __shared__ uint32_t lds[17];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t taken = 0;
@@ -746,6 +747,7 @@ __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, co
     running_out[s] = v;
     if (out_a) out_a[s] = v;
     if (out_b) out_b[s] = v;
+    if (taken_out) taken_out[s] = taken;  // (multi-GPU: this rank's slot delta)
   }
   // One counter update per workgroup (same-address atomics serialise at ~10 ns each).
   uint32_t total;
@@ -814,12 +816,6 @@ __global__ void k_global_flag(const ClassState* bounds, uint32_t rec, uint32_t n
     prm->n_changed[pass & 63] = any ? 1u : 0u;
     if (over) prm->overflow = 1;
   }
-}
-// delta[s] = grants of this rank's slice on servant s.
-__global__ __launch_bounds__(256) void k_slot_delta(const uint32_t* running, const uint32_t* running_out,
-                                                    uint32_t n, uint32_t* delta) {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n) delta[s] = running_out[s] - running[s];
 }
 // running_out[s] = running[s] + sum over ranks of delta[g][s].
 // out_a / out_b (nullable): the caller's copy and, when committing, the resident column.

@@ -55,6 +55,10 @@ struct MatchBuffers {
   // Non-NULL (<= 64 classes, single GPU): pass 0 works its level guesses out itself from the
   // prefix of the chunks' consuming counts, and guess0 is not used.
   const uint32_t* before;
+  // Multi-GPU with own guesses: the consuming-request counts of all ranks (gathered); the
+  // guesses of rank base_rank start behind those of the ranks before it. NULL on one GPU.
+  const uint32_t* base_totals;
+  uint32_t base_rank;
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
   // [K * C] state after the first kEarlyAt requests of every chunk (<= 64 classes only): a
@@ -477,6 +481,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   if (own_guess && kc < n_chunks) {
     before0 = B.before[kc];
     before1 = B.before[kc + 1];
+    if (B.base_totals) {
+      uint32_t base = 0;
+      for (uint32_t g = 0; g < B.base_rank; ++g) base += B.base_totals[g];
+      before0 += base;
+      before1 += base;
+    }
   }
   if (need_shared) return;        // the batch went through the sequential path
   if (prev_changed == 0) return;  // an earlier pass found every chunk consistent

@@ -864,7 +864,8 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
 // slot -> servant index, utilisation, running_tasks. check_slot != kNone: only runs when
 // the pass with that counter slot found every chunk consistent.
 int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_t* d_out_idx,
-                     double* d_out_util, uint32_t* d_out_running, uint32_t check_slot) {
+                     double* d_out_util, uint32_t* d_out_running, uint32_t check_slot,
+                     uint32_t* d_taken = nullptr) {
   hipStream_t st = c->stream;
   const uint32_t S = p.S, N = p.N;
   if (N) {
@@ -878,7 +879,7 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
     YDC_LAUNCH(c, "k_running_out", k_running_out, dim3(ceil_div(S, 256)), dim3(256), 0, st,
                c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p,
                d_out_running, (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr, check_slot,
-               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p);
+               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p, d_taken);
   }
   return YDC_OK;
 }
@@ -1379,8 +1380,16 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, 4, st));  // before[K == 0] = total = 0
   // Level guesses count the consuming requests of the ranks before this one.
   if (int rc = group_all_gather(c, c->d_before.p + K, g.d_totals.p, 4)) return rc;
-  hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, g.d_base.p);
-  if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
+  if (p.wave_path && p.W == 1 && c->opt_own_guess) {
+    // Pass 0 works the guesses out itself, from the gathered counts.
+    p.mb.before = c->d_before.p;
+    p.mb.base_totals = g.d_totals.p;
+    p.mb.base_rank = (uint32_t)g.rank;
+    if (int rc = enqueue_front_b(c, p, nullptr)) return rc;
+  } else {
+    hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, g.d_base.p);
+    if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
+  }
   mark(c, 6);
 
   // Matching passes, pre-launched in groups like on one GPU: after every pass the ranks
@@ -1404,6 +1413,19 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
     }
     const uint32_t first = launched;
     launched += group;
+    // The tail behind the group, gated on the device by the last pass's global flag (the same
+    // on every rank): placement of this rank's slice, then the global running_tasks from
+    // everybody's slot deltas. Not converged yet: the deltas are zero and nothing changes.
+    if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, (launched - 1) & 63,
+                                  g.d_delta.p))
+      return rc;
+    if (S) {
+      if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
+      hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
+                         g.d_deltas.p, S, G, c->d_running_out.p, d_out_running,
+                         (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr);
+    }
+    mark(c, 7);
     HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
@@ -1423,20 +1445,6 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   }
   g.passes = rounds;
 
-  // Placement of this rank's slice; then the global running_tasks from everybody's deltas.
-  if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, kNone)) return rc;
-  if (S) {
-    hipLaunchKernelGGL(k_slot_delta, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
-                       c->d_running_out.p, S, g.d_delta.p);
-    if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
-    hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
-                       g.d_deltas.p, S, G, c->d_running_out.p, d_out_running,
-                       (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr);
-  }
-  mark(c, 7);
-  HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
-  HIP_TRY(c, hipGetLastError());
   fill_stats(c, p, rounds);
   if (c->profiling) collect_kernel_profile(c);
   return YDC_OK;
