@@ -275,6 +275,10 @@ __global__ __launch_bounds__(1024) void k_chunk_prefix(PrefixArgs a, DeviceParam
 // ---------------------------------------------------------------------------
 // k_slot_gen: thread per slot, generation order (servant-major, running ascending).
 // ---------------------------------------------------------------------------
+// Workgroup t < gen_blocks generates the slots of sort tile t (256 x `items` slots, element
+// j * 256 + thread like the sort kernels) and, while it has their keys, the tile's histogram
+// of the FIRST sort pass (digit = the low `bits0` key bits, or with fused0 class bits above
+// bits0 - fused0 key bits when the sort has a single pass): hist[d * gen_blocks + t].
 // Workgroups [gen_blocks, gridDim.x) classify requests instead (task_classify_block).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_t* slot_base,
@@ -282,25 +286,39 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint32_t cap_bits, KeyT* keys, uint32_t* vals,
                                                   uint16_t* cls_by_g, uint32_t* owner,
                                                   uint8_t* consumed, uint32_t gen_blocks,
-                                                  ClassifyArgs ca) {
+                                                  uint32_t items, uint32_t bits0, uint32_t fused0,
+                                                  uint32_t* hist, ClassifyArgs ca) {
+  extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
     return;
   }
+  const uint32_t radix = 1u << bits0, kbits = bits0 - fused0;
+  for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) h0[d] = 0;
+  __syncthreads();
   const uint32_t M = prm->n_slots;
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= M) return;
-  uint32_t s = owner_of_slot(slot_base, sv.n, g);
-  owner[g] = s;
-  consumed[g] = 0;
-  uint32_t r = sv.running[s] + (g - slot_base[s]);
-  uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
-  uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
-  uint32_t tier = slot_tier(nproc, flags, r);
-  uint64_t key = exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap);
-  keys[g] = (KeyT)key;
-  vals[g] = g;
-  if (cls_by_g) cls_by_g[g] = (uint16_t)sv.class_of[s];
+  const uint32_t tile = blockIdx.x, base = tile * (blockDim.x * items);
+  for (uint32_t j = 0; j < items; ++j) {
+    const uint32_t g = base + j * blockDim.x + threadIdx.x;
+    if (g >= M) break;
+    uint32_t s = owner_of_slot(slot_base, sv.n, g);
+    owner[g] = s;
+    consumed[g] = 0;
+    uint32_t r = sv.running[s] + (g - slot_base[s]);
+    uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
+    uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
+    uint32_t tier = slot_tier(nproc, flags, r);
+    uint64_t key = exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap);
+    keys[g] = (KeyT)key;
+    vals[g] = g;
+    const uint32_t cls = sv.class_of[s];
+    if (cls_by_g) cls_by_g[g] = (uint16_t)cls;
+    uint32_t d = (uint32_t)key & ((1u << kbits) - 1);
+    if (fused0) d |= cls << kbits;
+    atomicAdd(&h0[d], 1u);
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) hist[d * gen_blocks + tile] = h0[d];
 }
 
 // ---------------------------------------------------------------------------

@@ -293,10 +293,12 @@ struct KernelTimer {
 // pa (nullable): the chunk prefix rides in the histogram launch as one more workgroup.
 template <typename KeyT>
 int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in, uint32_t n_tiles, void* out_keys,
-                     bool out_u32, uint32_t* out_vals, const PrefixArgs* pa = nullptr) {
+                     bool out_u32, uint32_t* out_vals, const PrefixArgs* pa = nullptr,
+                     bool have_hist = false) {
   const uint32_t radix = 1u << in.bits;
-  YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles + (pa ? 1 : 0)), dim3(kSortThreads),
-             radix * 4, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p, pa ? *pa : PrefixArgs{});
+  if (!have_hist)  // (the first pass's tile histograms come out of k_slot_gen)
+    YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles + (pa ? 1 : 0)), dim3(kSortThreads),
+               radix * 4, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p, pa ? *pa : PrefixArgs{});
   YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(radix), dim3(256), 0, c->stream, n_tiles,
              c->d_hist.p, c->d_row_total.p);
   const size_t lds = (size_t)(kSortWaves + 1) * radix * 4;
@@ -752,18 +754,24 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
                       c->d_chunk_consuming.p};
   }
-  const uint32_t gen_blocks = ceil_div(p.slot_bound, 256), cls_blocks = ceil_div(N, 256);
+  // One slot-generating workgroup per sort tile: it leaves the tile's histogram of the first
+  // sort pass behind as well (kernels.h).
+  const uint32_t bpp0 = c->kf.bits_per_pass;
+  const uint32_t fused0 = p.key_passes == 1 ? p.fused_cls_bits : 0;
+  const uint32_t bits0 = std::min(bpp0, c->kf.key_bits) + fused0;
+  const uint32_t gen_blocks = p.slot_bound ? p.n_tiles : 0, cls_blocks = ceil_div(N, 256);
   if (gen_blocks + cls_blocks) {
+    const size_t lds0 = ((size_t)4 << bits0);
     if (p.key32) {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), 0, st,
-                 p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint32_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p, gen_blocks,
-                 ca);
+      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+                 st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
+                 (uint32_t*)keys[0], vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, c->d_hist.p, ca);
     } else {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), 0, st,
-                 p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits, (uint64_t*)keys[0],
-                 vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p, c->d_consumed.p, gen_blocks,
-                 ca);
+      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+                 st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
+                 (uint64_t*)keys[0], vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, c->d_hist.p, ca);
     }
   }
   // The chunk prefix of the consuming counts goes with the first histogram launch.
@@ -781,13 +789,15 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
       if (p.key32) {
         SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
                             p.sort_items, fused};
-        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], pending_prefix);
+        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], q ? pending_prefix : nullptr,
+                         q == 0);
       } else {
         SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
                             p.sort_items, fused};
-        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1], pending_prefix);
+        launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1], q ? pending_prefix : nullptr,
+                         q == 0);
       }
-      pending_prefix = nullptr;
+      if (q) pending_prefix = nullptr;
       cur ^= 1;
     }
   }
