@@ -293,15 +293,42 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
     return;
   }
+  // Owners: slots are servant-major, so a tile's owners are one short run of servants. Two
+  // threads find its ends (the only long chains of dependent loads), the run's slot_base
+  // entries go to LDS, and every slot searches there.
+  constexpr uint32_t kWindow = 2048;
+  __shared__ uint32_t win[kWindow];
+  __shared__ uint32_t run_ends[2];
   const uint32_t radix = 1u << bits0, kbits = bits0 - fused0;
   for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) h0[d] = 0;
-  __syncthreads();
   const uint32_t M = prm->n_slots;
   const uint32_t tile = blockIdx.x, base = tile * (blockDim.x * items);
+  const uint32_t g_end = min(M, base + blockDim.x * items);  // (base >= M: nothing to generate)
+  if (base < M) {
+    if (threadIdx.x == 0) run_ends[0] = owner_of_slot(slot_base, sv.n, base);
+    if (threadIdx.x == 64) run_ends[1] = owner_of_slot(slot_base, sv.n, g_end - 1);
+  }
+  __syncthreads();
+  const uint32_t s_first = base < M ? run_ends[0] : 0;
+  const uint32_t n_run = base < M ? run_ends[1] - s_first + 1 : 0;
+  const bool windowed = n_run <= kWindow;  // (zero-slot servants in between can make it long)
+  if (windowed)
+    for (uint32_t i = threadIdx.x; i < n_run; i += blockDim.x) win[i] = slot_base[s_first + i];
+  __syncthreads();
   for (uint32_t j = 0; j < items; ++j) {
     const uint32_t g = base + j * blockDim.x + threadIdx.x;
     if (g >= M) break;
-    uint32_t s = owner_of_slot(slot_base, sv.n, g);
+    uint32_t s;
+    if (windowed) {
+      uint32_t lo = 0, hi = n_run;  // win[lo] <= g < win[hi] (hi == n_run: beyond the run)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (win[mid] <= g) lo = mid; else hi = mid;
+      }
+      s = s_first + lo;
+    } else {
+      s = owner_of_slot(slot_base, sv.n, g);
+    }
     owner[g] = s;
     consumed[g] = 0;
     uint32_t r = sv.running[s] + (g - slot_base[s]);
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, De
       uint32_t i = base + j * kSortThreads + threadIdx.x;
       if ((uint32_t)j < in.items && i < M) {
         KeyT key = in.keys ? in.keys[i] : (KeyT)i;
-        uint32_t d = sort_digit(in, i, key, in.vals[i]);
+        uint32_t d = sort_digit(in, i, key, in.cls_by_g ? in.vals[i] : 0u);  // (slot: class digits only)
         atomicAdd(&h[d], 1u);
       }
     }
