@@ -3,14 +3,16 @@
 // Pipeline of one batch (all on one stream, sizes that depend on device data
 // are read from DeviceParams, so the host never waits for them):
 //
-//   k_servant_scan   per-servant free-slot counts -> slot_base[], class sizes
-//   k_slot_gen       one (key, generation index) pair per free slot
-//   k_radix_*        stable LSD radix sort of the slots by key  (HBM-bound)
-//   k_radix_* (cls)  stable partition of the sorted ranks by servant class
-//   k_task_classify  per task: eligible-class mask, own-servant slot range
-//   k_chunk_prefix / k_guess_init   speculative start state of every task chunk
-//   k_match_round (rounds)          chunk-parallel replay of the greedy picks (match_kernel.h)
-//   k_finalize       slot -> servant index, utilisation, running_tasks
+//   k_servant_scan   per-servant free-slot counts -> slot_base[], class sizes, counter reset
+//   k_slot_gen       one (key, generation index) pair per free slot + the first sort pass's
+//                    tile histograms; extra workgroups classify the requests (eligible-class
+//                    mask, own-servant slot range, consuming count per chunk)
+//   k_radix_hist / _scan / _scatter   stable LSD radix sort of the slots by key (the chunk
+//                    prefix of the consuming counts rides in a histogram launch)
+//   k_radix_scatter_classed / class passes   per-class sorted lists (rank, slot)
+//   k_match_pass (match_kernel.h)     chunk-parallel speculative replay of the greedy picks;
+//                    pass 0 makes its own level guesses (k_guess_init: > 64 classes, sharded)
+//   k_finalize, k_running_out         rank -> slot -> servant index, utilisation, running_tasks
 //
 // The arithmetic (capacity, keys, class-state machine) lives in dispatch_core.h
 // and is shared with the CPU model in tests/model.

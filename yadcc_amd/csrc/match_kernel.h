@@ -4,9 +4,10 @@
 // One wave (= one workgroup) per chunk of requests, one lane per servant class
 // (W classes per lane above 64).
 //
-//   pass 0   every chunk is replayed from its level guess (k_guess_init) and
-//            leaves: the slot of every request, a checkpoint of the class states
-//            before every block of 64 requests, its end state.
+//   pass 0   every chunk is replayed from its level guess (worked out here, or by
+//            k_guess_init) and leaves: the slot of every request, a checkpoint of the
+//            class states before every block of 64 requests and 16 requests into
+//            the chunk, its end state.
 //   pass r   chunk k is *consistent* when the state it was last replayed from
 //            (its first checkpoint) equals the end state of chunk k-1. An
 //            inconsistent chunk is replayed from that end state; the replay
@@ -37,7 +38,8 @@
 // its slot's global rank (the reduced value itself; k_finalize maps rank -> slot ->
 // servant), and the winning lane advances from registers (head / next kept in
 // VGPRs, the LDS read of the entry after next is only waited for when the lane wins
-// again). About 34 instructions per request at 32 classes.
+// again). About 34 instructions per request at 32 classes; with >= 5 classes two
+// requests share an iteration when their winners are different lanes.
 #ifndef YADCC_AMD_MATCH_KERNEL_H_
 #define YADCC_AMD_MATCH_KERNEL_H_
 
