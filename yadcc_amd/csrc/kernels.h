@@ -401,14 +401,19 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, De
   __syncthreads();
   const uint32_t base = tile * (kSortThreads * in.items);
   if (base < M) {
+    // All loads first (clamped, unconditional), so that they are in flight together.
+    KeyT key[kSortItems];
+    uint32_t val[kSortItems];
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
-      uint32_t i = base + j * kSortThreads + threadIdx.x;
-      if ((uint32_t)j < in.items && i < M) {
-        KeyT key = in.keys ? in.keys[i] : (KeyT)i;
-        uint32_t d = sort_digit(in, i, key, in.cls_by_g ? in.vals[i] : 0u);  // (slot: class digits only)
-        atomicAdd(&h[d], 1u);
-      }
+      const uint32_t i = min(base + j * kSortThreads + threadIdx.x, M - 1);
+      key[j] = in.keys ? in.keys[i] : (KeyT)i;
+      val[j] = in.cls_by_g ? in.vals[i] : 0u;  // (the slot: class digits only)
+    }
+#pragma unroll
+    for (int j = 0; j < kSortItems; ++j) {
+      const uint32_t i = base + j * kSortThreads + threadIdx.x;
+      if ((uint32_t)j < in.items && i < M) atomicAdd(&h[sort_digit(in, i, key[j], val[j])], 1u);
     }
   }
   __syncthreads();
