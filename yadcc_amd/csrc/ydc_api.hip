@@ -154,6 +154,9 @@ struct ydc_context {
   // running_tasks | utilisation) in another pair (one D2H copy, enqueued right behind the
   // finalise kernels so that the batch needs a single wait).
   uint8_t *h_in = nullptr, *h_res = nullptr;
+  uint32_t* h_rel = nullptr;  // pinned staging of ydc_release_slots
+  size_t h_rel_cap = 0;
+  hipEvent_t h_rel_ev = nullptr;
   size_t h_in_cap = 0, h_res_cap = 0;
   DevBuf<uint8_t> d_in, d_res;
   struct {
@@ -452,6 +455,8 @@ int ydc_destroy(ydc_context* c) {
   c->d_prm.release();
   if (c->h_prm) (void)hipHostFree(c->h_prm);
   if (c->h_in) (void)hipHostFree(c->h_in);
+  if (c->h_rel) (void)hipHostFree(c->h_rel);
+  if (c->h_rel_ev) (void)hipEventDestroy(c->h_rel_ev);
   if (c->h_res) (void)hipHostFree(c->h_res);
   c->d_in.release();
   c->d_res.release();
@@ -471,6 +476,7 @@ int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   if (c->max_servants && n > c->max_servants)
     return fail(c, YDC_ERR_CAPACITY, "%u servants > max_servants %u", n, c->max_servants);
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   if (int rc = reserve_registry(c, n)) return rc;
   c->n_servants = n;
   c->h_version.assign(sv ? sv->version : nullptr, sv ? sv->version + n : nullptr);
@@ -575,17 +581,31 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
   if (!n) return YDC_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->d_upd_idx.reserve(n));
-  HIP_TRY(c, hipMemcpyAsync(c->d_upd_idx.p, servant_idx, n * 4, hipMemcpyHostToDevice, c->stream));
+  // Through a pinned staging buffer, stream-ordered: no wait here (the next batch follows on
+  // the same stream). The buffer is reused only after its previous copy has run.
+  if (c->h_rel_ev) HIP_TRY(c, hipEventSynchronize(c->h_rel_ev));
+  if ((size_t)n * 4 > c->h_rel_cap) {
+    if (c->h_rel) (void)hipHostFree(c->h_rel);
+    c->h_rel = nullptr;
+    c->h_rel_cap = 0;
+    const size_t want = std::max<size_t>((size_t)n * 6, 4096);
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_rel, want));
+    c->h_rel_cap = want;
+  }
+  if (!c->h_rel_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->h_rel_ev, hipEventDisableTiming));
+  std::memcpy(c->h_rel, servant_idx, (size_t)n * 4);
+  HIP_TRY(c, hipMemcpyAsync(c->d_upd_idx.p, c->h_rel, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->h_rel_ev, c->stream));
   hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream,
                      c->d_upd_idx.p, n, c->n_servants, c->d_running.p);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // servant_idx is pageable host memory
   return YDC_OK;
 }
 
 int ydc_set_running(ydc_context* c, const uint32_t* running, uint32_t n) {
   if (!c || n != c->n_servants || (n && !running)) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   if (n) HIP_TRY(c, hipMemcpy(c->d_running.p, running, n * 4, hipMemcpyHostToDevice));
   return YDC_OK;
 }
@@ -593,6 +613,7 @@ int ydc_set_running(ydc_context* c, const uint32_t* running, uint32_t n) {
 int ydc_get_running(ydc_context* c, uint32_t* out, uint32_t n) {
   if (!c || n != c->n_servants || (n && !out)) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (n) HIP_TRY(c, hipMemcpy(out, c->d_running.p, n * 4, hipMemcpyDeviceToHost));
   return YDC_OK;
