@@ -129,15 +129,28 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
   for (uint32_t c = threadIdx.x; c <= n_classes; c += blockDim.x) cls_cnt[c] = 0;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
+  // A servant's six columns are fetched together, one slab of servants ahead of the scan
+  // that uses them (unconditional loads at a clamped index: one round trip per slab, and it
+  // overlaps the previous slab's scan).
+  struct Row {
+    uint32_t cls, nproc, load, max_tasks, running, flags;
+  };
+  auto fetch = [&](uint32_t s) {
+    const uint32_t i = min(s, sv.n ? sv.n - 1 : 0u);
+    Row r{kNone, 0, 0, 0, 0, 0};
+    if (sv.n) r = Row{sv.class_of[i], sv.nproc[i], sv.load[i], sv.max_tasks[i], sv.running[i], sv.flags[i]};
+    if (s >= sv.n) r.cls = kNone;
+    return r;
+  };
+  Row next = fetch(threadIdx.x);
   for (uint32_t s0 = 0; s0 < sv.n; s0 += blockDim.x) {
-    uint32_t s = s0 + threadIdx.x;
-    uint32_t k = 0, cls = kNone;
-    if (s < sv.n) {
-      cls = sv.class_of[s];
-      if (cls != kNone)
-        k = servant_slot_count(sv.nproc[s], sv.load[s], sv.max_tasks[s], sv.running[s],
-                               sv.flags[s]);
-    }
+    const uint32_t s = s0 + threadIdx.x;
+    const Row row = next;
+    next = fetch(s + blockDim.x);
+    const uint32_t cls = row.cls;
+    const uint32_t k = cls == kNone ? 0u
+                                    : servant_slot_count(row.nproc, row.load, row.max_tasks,
+                                                         row.running, row.flags);
     uint32_t total;
     uint32_t ex = block_exclusive_scan(k, lds, &total);
     uint32_t base = carry + ex;
