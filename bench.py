@@ -112,8 +112,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # A step is ~0.1 ms: enough of them that one scheduling hiccup of the host does not move
     # the mean, and that p99 means something.
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -220,16 +220,20 @@ def main():
     # Per-kernel durations: HIP events on the dispatch stream, separate profiled steps so
     # the events do not perturb the timed region.
     ctx.set_profiling(True)
-    prof = {}
-    n_prof = max(3, min(20, args.steps))
+    per_step = {}
+    n_prof = max(3, min(40, args.steps))
     for _ in range(n_prof):
         step()
         for k, (cnt, ms) in ctx.kernel_profile().items():
-            a = prof.setdefault(k, [0, 0.0])
-            a[0] += cnt
-            a[1] += ms
+            per_step.setdefault(k, []).append((cnt, ms))
     stage_ms = ctx.stats()["stage_ms"]
     ctx.set_profiling(False)
+    # Median over the profiled steps (a stalled step must not pass for a slow kernel), scaled
+    # back to totals so that the arithmetic below stays "total / count".
+    prof = {}
+    for k, v in per_step.items():
+        cnt = int(np.median([c for c, _ in v]))
+        prof[k] = [cnt * n_prof, float(np.median([m for _, m in v])) * n_prof]
 
     if rank == 0:
         host_idx = d_out.numpy()
