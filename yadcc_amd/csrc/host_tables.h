@@ -28,6 +28,13 @@ struct HostTables {
   std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant)
   std::vector<uint32_t> ip_servant;
   bool any_shared_ip = false;       // some host runs more than one servant
+  // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
+  // class versions and <= 256 classes: ver_sorted = the distinct class versions ascending,
+  // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` whose
+  // version is >= ver_sorted[vi] (vi == V: none). A request (env, min_version) looks up
+  // vi = number of entries of ver_sorted below min_version. Empty when not built.
+  std::vector<uint32_t> ver_sorted;
+  std::vector<uint64_t> env_ver_mask;
   uint32_t cap_bits = 1;            // max over servants of bits(min(max_tasks, nproc))
   uint64_t max_slots = 0;           // sum over servants of min(max_tasks, nproc): bound on slots
 
@@ -61,6 +68,22 @@ struct HostTables {
     }
     cap_bits = 1;
     while (cap_bits < 32 && (max_cap >> cap_bits)) ++cap_bits;
+    ver_sorted.assign(cls_ver.begin(), cls_ver.end());
+    std::sort(ver_sorted.begin(), ver_sorted.end());
+    ver_sorted.erase(std::unique(ver_sorted.begin(), ver_sorted.end()), ver_sorted.end());
+    env_ver_mask.clear();
+    const uint32_t C = (uint32_t)cls_env.size(), V = (uint32_t)ver_sorted.size();
+    if (C && C <= 256 && V <= 16) {
+      const uint32_t words = (C + 63) / 64;
+      env_ver_mask.assign((size_t)64 * (V + 1) * words, 0);
+      for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t env = 0; env < 64; ++env)
+          if ((cls_env[c] >> env) & 1u)
+            for (uint32_t vi = 0; vi < V && ver_sorted[vi] <= cls_ver[c]; ++vi)
+              env_ver_mask[((size_t)env * (V + 1) + vi) * words + c / 64] |= 1ull << (c % 64);
+    } else {
+      ver_sorted.clear();
+    }
 
     std::vector<std::pair<uint32_t, uint32_t>> byip(n);
     for (uint32_t s = 0; s < n; ++s) byip[s] = {ip_id[s], s};

@@ -198,6 +198,10 @@ struct ClassifyArgs {
   const uint64_t* cls_env;
   const uint32_t* cls_ver;
   uint32_t n_classes, words;
+  // Lookup form of the same test (host_tables.h; NULL: loop over the classes instead).
+  const uint32_t* ver_sorted;
+  const uint64_t* env_ver_mask;
+  uint32_t n_versions;
   const uint32_t* ip_sorted;
   const uint32_t* ip_servant;
   uint32_t n_servants;
@@ -216,6 +220,16 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   uint64_t any = 0;
   {
     const uint32_t env = a.tk.env_id[t], minv = a.tk.min_version[t];
+    if (a.env_ver_mask) {
+      uint32_t vi = 0;  // class versions below min_version
+      for (uint32_t j = 0; j < a.n_versions; ++j) vi += a.ver_sorted[j] < minv;
+      const uint64_t* row = a.env_ver_mask + ((size_t)min(env, 63u) * (a.n_versions + 1) + vi) * a.words;
+      for (uint32_t w = 0; w < a.words; ++w) {
+        const uint64_t m = env < 64 ? row[w] : 0;
+        a.mask[(size_t)t * a.words + w] = m;
+        any |= m;
+      }
+    } else
     for (uint32_t w = 0; w < a.words; ++w) {
       uint64_t m = 0;
       if (env < 64) {

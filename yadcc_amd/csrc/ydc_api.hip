@@ -80,8 +80,8 @@ struct ydc_context {
 
   // Resident registry.
   DevBuf<uint32_t> d_version, d_nproc, d_load, d_max_tasks, d_running, d_flags, d_class_of;
-  DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver;
-  DevBuf<uint64_t> d_cls_env;
+  DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted;
+  DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
 
   // Per-batch workspace.
   DevBuf<uint32_t> d_slot_base, d_cls_begin, d_vals[2], d_hist, d_row_total;
@@ -242,6 +242,14 @@ int rebuild_tables(ydc_context* c) {
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_cls_ver.p, c->tables.cls_ver.data(), C * 4,
                               hipMemcpyHostToDevice, c->stream));
+  }
+  if (!c->tables.env_ver_mask.empty()) {
+    HIP_TRY(c, c->d_ver_sorted.reserve(c->tables.ver_sorted.size()));
+    HIP_TRY(c, c->d_env_ver_mask.reserve(c->tables.env_ver_mask.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ver_sorted.p, c->tables.ver_sorted.data(),
+                              c->tables.ver_sorted.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_env_ver_mask.p, c->tables.env_ver_mask.data(),
+                              c->tables.env_ver_mask.size() * 8, hipMemcpyHostToDevice, c->stream));
   }
   // The host vectors are pageable: the copies above are complete on return only
   // after a sync (the tables may be rebuilt before the next launch otherwise).
@@ -440,7 +448,8 @@ int ydc_destroy(ydc_context* c) {
                   &c->d_before, &c->d_slot_of, &c->d_left, &c->d_running_out, &c->d_out_idx,
                   &c->d_upd_idx})
     b->release();
-  for (auto* b : {&c->d_cls_env, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
+  for (auto* b : {&c->d_cls_env, &c->d_env_ver_mask, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
+  c->d_ver_sorted.release();
   c->d_cls_by_g.release();
   c->d_owner.release();
   c->d_rank_to_g.release();
@@ -771,7 +780,10 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   ClassifyArgs ca{};
   if (N) {
     ca = ClassifyArgs{TaskColumns{tk->env_id, tk->min_version, tk->requestor_ip}, N,
-                      c->d_cls_env.p, c->d_cls_ver.p, C, W, c->d_ip_sorted.p, c->d_ip_servant.p, S,
+                      c->d_cls_env.p, c->d_cls_ver.p, C, W,
+                      c->tables.env_ver_mask.empty() ? nullptr : c->d_ver_sorted.p,
+                      c->tables.env_ver_mask.empty() ? nullptr : c->d_env_ver_mask.p,
+                      (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
                       c->d_chunk_consuming.p};
   }
