@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint16_t* cls_by_g, uint32_t* owner,
                                                   uint8_t* consumed, uint32_t gen_blocks,
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
-                                                  uint32_t* hist, ClassifyArgs ca) {
+                                                  uint32_t gbits, uint32_t* hist, ClassifyArgs ca) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
@@ -366,8 +366,10 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     uint32_t tier = slot_tier(nproc, flags, r);
     uint64_t key = exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap);
     keys[g] = (KeyT)key;
-    vals[g] = g;
     const uint32_t cls = sv.class_of[s];
+    // The sort's value is the slot; with room above its bits (gbits != 0) the class rides
+    // there, so that class digits need no gather (SortIn::gbits).
+    vals[g] = gbits ? (cls << gbits) | g : g;
     if (cls_by_g) cls_by_g[g] = (uint16_t)cls;
     uint32_t d = (uint32_t)key & ((1u << kbits) - 1);
     if (fused0) d |= cls << kbits;
@@ -396,7 +398,16 @@ struct SortIn {
   // Last key pass with the class folded in (few classes, room left in the digit): the digit
   // is (class << (bits - fused_cls_bits)) | key bits, see k_radix_scatter_classed. 0: off.
   uint32_t fused_cls_bits;
+  // gbits != 0: vals carry the class above gbits slot bits (class digits come from there and
+  // cls_by_g is only the "class digit needed" flag). out_mask: applied to the values this pass
+  // writes — the last pass of the sort strips the class again.
+  uint32_t gbits, out_mask;
 };
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t sort_class(const SortIn<KeyT>& in, uint32_t val) {
+  return in.gbits ? val >> in.gbits : (uint32_t)in.cls_by_g[val];
+}
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t i, KeyT key,
@@ -404,9 +415,9 @@ __device__ __forceinline__ uint32_t sort_digit(const SortIn<KeyT>& in, uint32_t 
   const uint32_t mask = (1u << in.bits) - 1;
   if (in.fused_cls_bits) {
     const uint32_t kbits = in.bits - in.fused_cls_bits;
-    return ((uint32_t)in.cls_by_g[val] << kbits) | ((uint32_t)(key >> in.shift) & ((1u << kbits) - 1));
+    return (sort_class(in, val) << kbits) | ((uint32_t)(key >> in.shift) & ((1u << kbits) - 1));
   }
-  if (in.cls_by_g) return ((uint32_t)in.cls_by_g[val] >> in.shift) & mask;
+  if (in.cls_by_g) return (sort_class(in, val) >> in.shift) & mask;
   return (uint32_t)(key >> in.shift) & mask;
 }
 
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     if ((uint32_t)j < in.items && i < M) {
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       out_keys[pos] = (OutKeyT)key[j];
-      out_vals[pos] = val[j];
+      out_vals[pos] = val[j] & in.out_mask;
     }
   }
 }
@@ -680,8 +691,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       const uint32_t grank = kstart[kd] + wkcnt[kd] + krank[j];
       out_rank[pos] = grank;
-      out_vals[pos] = val[j];
-      rank_to_g[grank] = val[j];
+      out_vals[pos] = val[j] & in.out_mask;
+      rank_to_g[grank] = val[j] & in.out_mask;
     }
   }
 }
@@ -770,7 +781,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
                                                   const uint32_t* slot_of, uint32_t n_tasks,
                                                   uint32_t slot_is_rank, uint32_t* out_idx,
                                                   double* out_util, uint8_t* consumed,
-                                                  uint32_t check_slot, const DeviceParams* prm) {
+                                                  uint32_t check_slot, const DeviceParams* prm,
+                                                  uint32_t g_mask) {
   // Pre-launched behind the matching passes: only runs once they have converged.
   if (check_slot != kNone && prm->n_changed[check_slot] != 0) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -780,7 +792,7 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
       if (out_idx) out_idx[t] = g;
       if (out_util) out_util[t] = -1.0;
     } else {
-      if (slot_is_rank && !prm->need_shared) g = rank_to_g[g];
+      if (slot_is_rank && !prm->need_shared) g = rank_to_g[g] & g_mask;  // (class bits above)
       const uint32_t s = owner[g];
       if (out_idx) out_idx[t] = s;
       if (out_util) {

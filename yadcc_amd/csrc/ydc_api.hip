@@ -54,6 +54,7 @@ struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
   uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
   uint32_t fused_cls_bits = 0;  // class partition folded into the last key pass (kernels.h)
+  uint32_t gbits = 0;  // != 0: the sort's values carry the class above gbits slot bits (SortIn)
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
   ServantTable sv{};
   ClassLists L{};
@@ -172,6 +173,7 @@ struct ydc_context {
   bool opt_fused_class = true;
   bool opt_own_guess = true;
   bool opt_pair = true;
+  bool opt_packed_class = true;
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -429,6 +431,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
   if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
+  if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -679,9 +682,13 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   p.key_passes = c->kf.passes;
   p.cls_passes = 0;
   p.fused_cls_bits = 0;
+  p.gbits = 0;
   if (C > 1 && slot_bound) {
     uint32_t cls_bits = 1;
     while ((1u << cls_bits) < C) ++cls_bits;
+    uint32_t gb = 1;
+    while (gb < 32 && (slot_bound >> gb)) ++gb;
+    if (gb + cls_bits <= 32 && c->opt_packed_class) p.gbits = gb;  // the class rides above the slot index
     // A handful of classes and room left in the last key digit: one pass does both.
     const uint32_t last_bits = c->kf.key_bits - (p.key_passes - 1) * c->kf.bits_per_pass;
     if (C <= 8 && p.key_passes >= 1 && last_bits + cls_bits <= (uint32_t)kMaxRadixBits &&
@@ -798,13 +805,13 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
     if (p.key32) {
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                  st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
-                 (uint32_t*)keys[0], vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, c->d_hist.p, ca);
+                 (uint32_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca);
     } else {
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                  st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
-                 (uint64_t*)keys[0], vals[0], C > 1 ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, c->d_hist.p, ca);
+                 (uint64_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca);
     }
   }
   // The chunk prefix of the consuming counts goes with the first histogram launch.
@@ -812,6 +819,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   const PrefixArgs* pending_prefix = N ? &pa : nullptr;
   mark(c, 2);
   // ---- sort by key
+  const uint32_t g_mask = p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu;  // strips the class again
   const uint32_t bpp = c->kf.bits_per_pass;
   auto bits_of = [&](uint32_t q) { return std::min(bpp, c->kf.key_bits - q * bpp); };
   if (p.slot_bound) {
@@ -821,12 +829,12 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
       const uint16_t* cls = fused ? c->d_cls_by_g.p : nullptr;
       if (p.key32) {
         SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
-                            p.sort_items, fused};
+                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], q ? pending_prefix : nullptr,
                          q == 0);
       } else {
         SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
-                            p.sort_items, fused};
+                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1], q ? pending_prefix : nullptr,
                          q == 0);
       }
@@ -839,7 +847,8 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   for (uint32_t q = 0; q < p.cls_passes; ++q) {
     // First pass: key == index (global rank). Later passes carry the rank along.
     SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
-                        q * p.cls_bits, p.cls_bits, p.sort_items, 0u};
+                        q * p.cls_bits, p.cls_bits, p.sort_items, 0u, p.gbits,
+                        q + 1 == p.cls_passes ? g_mask : 0xFFFFFFFFu};
     launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], pending_prefix);
     pending_prefix = nullptr;
     cur ^= 1;
@@ -914,7 +923,8 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   if (N) {
     YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(ceil_div(N, 256)), dim3(256), 0, st, p.sv,
                c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N,
-               p.wave_path ? 1u : 0u, d_out_idx, d_out_util, c->d_consumed.p, check_slot, c->d_prm.p);
+               p.wave_path ? 1u : 0u, d_out_idx, d_out_util, c->d_consumed.p, check_slot, c->d_prm.p,
+               p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu);
   }
   if (S) {
     // Also writes the caller's copy and (COMMIT) the resident column; when the passes have not
