@@ -239,3 +239,18 @@ def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
         assert st["key_bits"] == 64
     finally:
         c.close()
+
+
+def test_switchable_fast_paths_off(monkeypatch):
+    """The A/B switches select older, slower forms of the same steps (separate class pass,
+    class gather, k_guess_init, one request per loop iteration): same results."""
+    for k in ("YDC_PACKED_CLASS", "YDC_FUSED_CLASS", "YDC_OWN_GUESS", "YDC_PAIR"):
+        monkeypatch.setenv(k, "0")
+    c = binding.Context(device=0)
+    try:
+        for seed, envs, n in ((71, 1, 20_000), (72, 2, 30_000), (73, 4, 60_000)):
+            sv, tk = cases.random_case(seed=seed, n_tasks=n, n_servants=800, n_envs=envs,
+                                       self_frac=0.2, unknown_env_frac=0.001)
+            check(c, sv, tk)
+    finally:
+        c.close()
