@@ -21,13 +21,18 @@ model:
 	$(MAKE) -s -C tests/model
 # Native (C++) drive of the dispatcher through the scheduler harness; plain g++, links libydc.so.
 native: tests/native/harness_test tools/td_native_bench
+	$(MAKE) -s -C tests/native all
 tools/td_native_bench: tools/td_native_bench.cc yadcc_amd/libydc.so $(HDRS)
 	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tools/td_native_bench.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../yadcc_amd' -lpthread
-tests/native/harness_test: tests/native/harness_test.cc yadcc_amd/libydc.so $(HDRS)
-	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tests/native/harness_test.cc \
+tests/native/harness_test: tests/native/harness_test.cc tests/native/scheduler_harness.cc tests/native/scheduler_harness.h yadcc_amd/libydc.so $(HDRS)
+	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -Itests/native -o $@ tests/native/harness_test.cc tests/native/scheduler_harness.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../../yadcc_amd' -lpthread
+# Sanitizer builds of the host class against the CPU stand-in of the device API (no GPU).
+tsan asan:
+	$(MAKE) -s -C tests/native $@
 clean:
 	rm -f yadcc_amd/libydc.so tests/model/libmodel.so
+	$(MAKE) -C tests/native clean
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle model native clean
+.PHONY: all lib oracle model native tsan asan clean

@@ -42,7 +42,12 @@ extern "C" {
  * dispatch take up to 256. */
 #define YDC_MAX_CLASSES 65535u
 #define YDC_MAX_FAST_CLASSES 256u
-#define YDC_MAX_ENVS 64u
+/* Interned compiler digests per 64-bit word of an environment mask. The number of words per
+ * servant (env_words) is the caller's choice: the reference keeps an unbounded
+ * std::vector<EnvironmentDesc> per servant (task_dispatcher.h:93-94, .cc:55-63), so there
+ * is no limit on the number of distinct live digests here either. */
+#define YDC_ENVS_PER_WORD 64u
+#define YDC_MAX_ENV_WORDS 1024u
 
 /* ---- servant flags --------------------------------------------------------- */
 /* ServantPersonality::priority == SERVANT_PRIORITY_DEDICATED (task_dispatcher.cc:405) */
@@ -61,21 +66,25 @@ typedef struct ydc_servant_soa {
   const uint32_t* max_tasks;      /* 0 => never eligible, task_dispatcher.cc:330-332 */
   const uint32_t* running_tasks;  /* ServantDesc::running_tasks */
   const uint32_t* flags;          /* YDC_SERVANT_* */
-  const uint64_t* env_mask;       /* bit j <=> advertises interned compiler digest j */
+  const uint64_t* env_mask;       /* env_words words per servant: bit j of word w of servant s
+                                     (env_mask[s * env_words + w]) <=> advertises interned
+                                     compiler digest 64 * w + j */
   const uint32_t* ip_id;          /* interned text before ':' of observed_location;
                                      equal ids <=> IsNetworkAddressEqual, task_dispatcher.cc:66-69 */
+  uint32_t env_words;             /* 64-bit words per servant in env_mask; 0 is read as 1 */
 } ydc_servant_soa;
 
 /* One heartbeat's worth of a servant row (KeepServantAlive replaces the
  * personality but keeps running_tasks, task_dispatcher.cc:195-201). */
 typedef struct ydc_servant_row {
   uint32_t version, num_processors, current_load, max_tasks, flags, ip_id;
-  uint64_t env_mask;
+  uint64_t env_mask; /* word 0 of the servant's mask (ydc_update_servants: the whole mask) */
 } ydc_servant_row;
 
 /* Pending requests in arrival order (TaskPersonality, task_dispatcher.h:48-66). */
 typedef struct ydc_task_soa {
-  const uint32_t* env_id;       /* interned compiler digest; >= YDC_MAX_ENVS: nobody has it */
+  const uint32_t* env_id;       /* interned compiler digest (bit number in the servants' masks);
+                                   >= 64 * env_words of the resident table: nobody has it */
   const uint32_t* min_version;
   const uint32_t* requestor_ip; /* same interning as ydc_servant_soa::ip_id */
 } ydc_task_soa;
@@ -129,6 +138,15 @@ int ydc_upload_servants(ydc_context* ctx, const ydc_servant_soa* servants, uint3
  * with running_tasks = 0, task_dispatcher.cc:205-210). */
 int ydc_update_servants(ydc_context* ctx, const uint32_t* idx, const ydc_servant_row* rows,
                         uint32_t n);
+/* Same for registries with more than 64 interned digests: the masks come in env_masks
+ * (env_words words per row, env_masks[i * env_words + w]) and rows[i].env_mask is ignored.
+ * A table that was uploaded with fewer words is widened (the missing words are zero). */
+int ydc_update_servants_wide(ydc_context* ctx, const uint32_t* idx, const ydc_servant_row* rows,
+                             const uint64_t* env_masks, uint32_t env_words, uint32_t n);
+/* OnExpirationTimer's erase (task_dispatcher.cc:503-516): removes the rows idx[0..n) (strictly
+ * ascending) from the resident table; the servants behind them move up, keeping their order
+ * (registry order decides ties) and their running_tasks. Done on the device: no table upload. */
+int ydc_remove_servants(ydc_context* ctx, const uint32_t* idx, uint32_t n);
 /* FreeTask / zombie / orphan sweeps: running_tasks[servant_idx[i]] -= 1
  * (task_dispatcher.cc:181). */
 int ydc_release_slots(ydc_context* ctx, const uint32_t* servant_idx, uint32_t n);
@@ -159,7 +177,9 @@ int ydc_dispatch_device(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t 
  * step is captured into a hipGraph once and replayed per tick; counts may vary up to the
  * capacities given here. Host buffers in, host results out, synchronous.
  * Heartbeats that add a servant or change its environments / version / host / capacity
- * bound are applied eagerly (ydc_update_servants) and the step is captured again. */
+ * bound are applied eagerly (ydc_update_servants) and the step is captured again. With
+ * env_words > 1 a tick's rows cannot carry a mask: upd_rows[i].env_mask is ignored and the
+ * servant keeps its environments (change them with ydc_update_servants_wide). */
 int ydc_stream_begin(ydc_context* ctx, uint32_t max_updates, uint32_t max_releases,
                      uint32_t max_tasks);
 int ydc_stream_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
@@ -251,7 +271,8 @@ int ydc_td_set_clock_ns(ydc_td* td, int64_t now_ns);
 /* KeepServantAlive, task_dispatcher.h:167-168. */
 int ydc_td_keep_servant_alive(ydc_td* td, const ydc_td_servant* servant, int64_t expires_in_ns);
 /* WaitForStartingNewTask, task_dispatcher.h:139-141. timeout_in_ns is relative to now
- * (0: do not block). out_location receives TaskAllocation::servant_location. */
+ * (0: do not block). out_location receives TaskAllocation::servant_location; if it does not
+ * fit in location_cap bytes the grant is given back and YDC_ERR_CAPACITY returned. */
 int ydc_td_wait_for_starting_new_task(ydc_td* td, const char* requestor_ip, uint32_t min_version,
                                       const char* compiler_digest, int64_t expires_in_ns,
                                       int64_t timeout_in_ns, int prefetching,

@@ -49,7 +49,8 @@ int oracle_try_parse_size(const char* s, uint64_t* out) {
 
 static int servant_has_env(const oracle_servants* sv, size_t s, uint32_t env_id) {
   /* ContainsEnvironmentSlow, :55-63, on interned digests. */
-  return env_id < 64 && ((sv->env_mask[s] >> env_id) & 1u);
+  uint32_t words = sv->env_words ? sv->env_words : 1;
+  return env_id < 64 * words && ((sv->env_mask[s * words + (env_id >> 6)] >> (env_id & 63)) & 1u);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -158,6 +159,7 @@ static int ipent_cmp(const void* a, const void* b) {
 size_t oracle_dispatch_sorted(const oracle_servants* sv, uint64_t min_mem, const oracle_tasks* tk,
                               uint32_t* running, uint32_t* out_idx, double* out_util) {
   size_t S = sv->n, N = tk->n;
+  if (sv->env_words > 1) return oracle_dispatch_scan(sv, min_mem, tk, running, out_idx, out_util);
   /* 1. Per-servant slot runs. A servant is free at r iff r < cap(r); cap grows
    * by at most one per extra running task, so "not free" is absorbing and a
    * servant's slots are r0, r0+1, ... until the first r with r >= cap(r). */

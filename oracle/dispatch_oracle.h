@@ -40,11 +40,12 @@ typedef struct oracle_servants {
   const uint32_t* priority;
   const uint64_t* total_memory;
   const uint64_t* memory_available;
-  const uint64_t* env_mask;
+  const uint64_t* env_mask; /* env_words words per servant: digest j = bit j % 64 of word j / 64 */
   const uint32_t* ip;
+  uint32_t env_words;       /* 0 is read as 1 */
 } oracle_servants;
 
-/* TaskPersonality (task_dispatcher.h:48-66) in arrival order. env_id >= 64
+/* TaskPersonality (task_dispatcher.h:48-66) in arrival order. env_id >= 64 * env_words
  * stands for a digest nobody advertises. */
 typedef struct oracle_tasks {
   size_t n;
@@ -67,7 +68,8 @@ size_t oracle_dispatch_scan(const oracle_servants* sv, uint64_t min_memory_for_n
  * servants grouped into (env_mask, version) classes, per-class cursors, self
  * skipped per task_dispatcher.cc:372-396. O(slots log slots + N*classes).
  * Used for full-size parity where the literal scan would take minutes; itself
- * checked against oracle_dispatch_scan and the verbatim reference in tests/. */
+ * checked against oracle_dispatch_scan and the verbatim reference in tests/.
+ * Masks of more than one word are handed to oracle_dispatch_scan. */
 size_t oracle_dispatch_sorted(const oracle_servants* sv, uint64_t min_memory_for_new_task,
                               const oracle_tasks* tk, uint32_t* running,
                               uint32_t* out_servant_idx, double* out_util);

@@ -19,7 +19,7 @@ MIN_MEMORY_DEFAULT = 10 << 30  # --servant_min_memory_for_accepting_new_task=10G
 class _Servants(C.Structure):
     _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in (
         "version", "num_processors", "current_load", "max_tasks", "priority", "total_memory",
-        "memory_available", "env_mask", "ip")]
+        "memory_available", "env_mask", "ip")] + [("env_words", C.c_uint32)]
 
 
 class _Tasks(C.Structure):
@@ -64,6 +64,8 @@ def dispatch(sv, tk, method="sorted", min_memory=MIN_MEMORY_DEFAULT, want_util=T
         a = _col(sv[k], dt)
         keep.append(a)
         setattr(S, k, a.ctypes.data)
+        if k == "env_mask":
+            S.env_words = a.shape[1] if a.ndim == 2 else 1  # (n,) or (n, env_words)
     T = _Tasks()
     T.n = len(tk["env_id"])
     for k in ("env_id", "min_version", "requestor_ip"):

@@ -24,6 +24,7 @@ struct ref_dispatcher {
   // location -> registry index, valid while no servant has expired.
   std::unordered_map<std::string, std::uint32_t> index_of;
   std::vector<std::string> digest_names;
+  std::uint32_t env_bits = 64;  // digests the loaded masks can name (64 * env_words)
 };
 
 namespace {
@@ -162,6 +163,17 @@ void ref_load_servants(ref_dispatcher* d, size_t n, const uint32_t* version,
                        const uint32_t* priority, const uint64_t* total_memory,
                        const uint64_t* memory_available, const uint64_t* env_mask,
                        const uint32_t* ip, const uint32_t* port) {
+  ref_load_servants_wide(d, n, version, num_processors, current_load, max_tasks, running_tasks,
+                         priority, total_memory, memory_available, env_mask, 1, ip, port);
+}
+
+void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version,
+                            const uint32_t* num_processors, const uint32_t* current_load,
+                            const uint32_t* max_tasks, const uint32_t* running_tasks,
+                            const uint32_t* priority, const uint64_t* total_memory,
+                            const uint64_t* memory_available, const uint64_t* env_mask,
+                            uint32_t env_words, const uint32_t* ip, const uint32_t* port) {
+  d->env_bits = 64 * (env_words ? env_words : 1);
   for (size_t i = 0; i != n; ++i) {
     auto location = Dotted(ip[i], port[i], true);
     bool is_new = d->index_of.count(location) == 0;
@@ -190,8 +202,8 @@ void ref_load_servants(ref_dispatcher* d, size_t n, const uint32_t* version,
     ServantPersonality s{};
     s.version = static_cast<int>(version[i]);
     s.observed_location = s.reported_location = location;
-    for (std::uint32_t j = 0; j != 64; ++j) {
-      if (env_mask[i] >> j & 1) {
+    for (std::uint32_t j = 0; j != d->env_bits; ++j) {
+      if (env_mask[i * (d->env_bits / 64) + j / 64] >> (j % 64) & 1) {
         s.environments.emplace_back().set_compiler_digest(CachedDigest(d, j));
       }
     }
@@ -217,8 +229,8 @@ double ref_dispatch_batch(ref_dispatcher* d, size_t n, const uint32_t* env_id,
   for (size_t i = 0; i != n; ++i) {
     tasks[i].requestor_ip = Dotted(requestor_ip[i], 0, false);
     tasks[i].min_version = min_version[i];
-    tasks[i].env_desc.set_compiler_digest(env_id[i] < 64 ? CachedDigest(d, env_id[i])
-                                                         : std::string("unknown-digest"));
+    tasks[i].env_desc.set_compiler_digest(env_id[i] < d->env_bits ? CachedDigest(d, env_id[i])
+                                                                  : std::string("unknown-digest"));
   }
   std::vector<const std::string*> granted(n, nullptr);
   std::vector<int> status(n, 0);

@@ -75,9 +75,17 @@ void ref_load_servants(ref_dispatcher* d, size_t n, const uint32_t* version,
                        const uint64_t* memory_available, const uint64_t* env_mask,
                        const uint32_t* ip, const uint32_t* port);
 
+/* Same with env_words 64-bit words per servant (digest j = bit j % 64 of word j / 64). */
+void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version,
+                            const uint32_t* num_processors, const uint32_t* current_load,
+                            const uint32_t* max_tasks, const uint32_t* running_tasks,
+                            const uint32_t* priority, const uint64_t* total_memory,
+                            const uint64_t* memory_available, const uint64_t* env_mask,
+                            uint32_t env_words, const uint32_t* ip, const uint32_t* port);
+
 /* N sequential WaitForStartingNewTask(timeout = now). out_servant_idx[i] is the
  * registry index of the granted servant, or REF_IDX_TIMEOUT / REF_IDX_ENV_NOT_FOUND.
- * env_id >= 64 denotes a digest no servant has. out_latency_ns may be NULL.
+ * env_id >= 64 * env_words of the loaded masks denotes a digest no servant has. out_latency_ns may be NULL.
  * Returns wall seconds spent inside the N calls. */
 double ref_dispatch_batch(ref_dispatcher* d, size_t n, const uint32_t* env_id,
                           const uint32_t* min_version, const uint32_t* requestor_ip,

@@ -49,6 +49,8 @@ def lib():
         L.ref_get_running_tasks.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t]
         L.ref_get_running_tasks.restype = C.c_size_t
         L.ref_load_servants.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 11
+        L.ref_load_servants_wide.argtypes = ([C.c_void_p, C.c_size_t] + [C.c_void_p] * 9 +
+                                             [C.c_uint32] + [C.c_void_p] * 2)
         L.ref_dispatch_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.ref_dispatch_batch.restype = C.c_double
         L.ref_digest_name.argtypes = [C.c_uint32, C.c_char_p]
@@ -128,7 +130,9 @@ class RefDispatcher:
             ("max_tasks", np.uint32), ("running_tasks", np.uint32), ("priority", np.uint32),
             ("total_memory", np.uint64), ("memory_available", np.uint64),
             ("env_mask", np.uint64), ("ip", np.uint32), ("port", np.uint32))]
-        lib().ref_load_servants(self._h, n, *[_p(c) for c in cols])
+        words = cols[8].shape[1] if cols[8].ndim == 2 else 1  # env_mask: (n,) or (n, env_words)
+        lib().ref_load_servants_wide(self._h, n, *[_p(c) for c in cols[:9]], words,
+                                     _p(cols[9]), _p(cols[10]))
 
     def dispatch_batch(self, tk, want_latency=False):
         n = len(tk["env_id"])

@@ -38,6 +38,9 @@ SMALL_CASES = [
     ("tiny_pool_self_fallback", dict(seed=9, n_tasks=200, n_servants=5, self_frac=0.8)),
     ("one_servant", dict(seed=10, n_tasks=50, n_servants=1, self_frac=1.0)),
     ("many_envs", dict(seed=11, n_tasks=6000, n_servants=400, n_envs=6, unknown_env_frac=0.01)),
+    # > 64 distinct digests: multi-word environment masks (no limit in the reference)
+    ("wide_envs_150", dict(seed=12, n_tasks=4000, n_servants=300, n_envs=150,
+                           unknown_env_frac=0.01, self_frac=0.2)),
 ]
 
 

@@ -24,16 +24,16 @@ struct model_stats {
   uint32_t n_slots, n_classes, key_bits, n_chunks, rounds, chunk_sims, force_fp64;
 };
 
-// Returns 0, or -5 if there are more than 64 classes.
-int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
-                   const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
-                   const uint64_t* env_mask, const uint32_t* ip_id, uint32_t N,
-                   const uint32_t* env_id, const uint32_t* min_version,
-                   const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
-                   uint32_t* out_idx, double* out_util, uint32_t* out_running,
-                   model_stats* stats) {
+// env_mask: env_words words per servant. Returns 0, or -6 if the rounds do not converge.
+int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
+                        const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
+                        const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id, uint32_t N,
+                        const uint32_t* env_id, const uint32_t* min_version,
+                        const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
+                        uint32_t* out_idx, double* out_util, uint32_t* out_running,
+                        model_stats* stats) {
   HostTables T;
-  T.build(S, env_mask, version, max_tasks, nproc, ip_id);
+  T.build(S, env_mask, version, max_tasks, nproc, ip_id, env_words);
   const uint32_t C = T.n_classes();
   KeyFormat kf = choose_key_format(force_fp64 ? 32 : T.cap_bits);
 
@@ -93,7 +93,7 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
   bool need_shared = false;
   for (uint32_t t = 0; t < N; ++t) {
     task_class_mask(env_id[t], min_version[t], T.cls_env.data(), T.cls_ver.data(), C, W,
-                    &tmask[(size_t)t * W]);
+                    &tmask[(size_t)t * W], T.env_words);
     uint32_t i = lower_bound_u32(T.ip_sorted.data(), S, requestor_ip[t]);
     if (i < S && T.ip_sorted[i] == requestor_ip[t]) {
       if (i + 1 < S && T.ip_sorted[i + 1] == requestor_ip[t]) {
@@ -195,6 +195,18 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
   return 0;
 }
 
+
+int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
+                   const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
+                   const uint64_t* env_mask, const uint32_t* ip_id, uint32_t N,
+                   const uint32_t* env_id, const uint32_t* min_version,
+                   const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
+                   uint32_t* out_idx, double* out_util, uint32_t* out_running,
+                   model_stats* stats) {
+  return model_dispatch_wide(S, version, nproc, load, max_tasks, running, flags, env_mask, 1, ip_id, N,
+                             env_id, min_version, requestor_ip, chunk_size, force_fp64, out_idx,
+                             out_util, out_running, stats);
+}
 
 // ---------------------------------------------------------------------------
 // One rank of the multi-GPU sharding protocol, replayed on the CPU so that

@@ -19,7 +19,7 @@ def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(os.path.join(_HERE, "libmodel.so"))
-        _lib.model_dispatch.restype = C.c_int
+        _lib.model_dispatch_wide.restype = C.c_int
     return _lib
 
 
@@ -34,9 +34,11 @@ def dispatch(sv, tk, chunk_size=256, force_fp64=False, min_memory=pack.MIN_MEMOR
     run = np.empty(S, np.uint32)
     st = Stats()
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    rc = lib().model_dispatch(
+    words = a["env_mask"].shape[1] if a["env_mask"].ndim == 2 else 1
+    rc = lib().model_dispatch_wide(
         C.c_uint32(S), p(a["version"]), p(a["num_processors"]), p(a["current_load"]),
-        p(a["max_tasks"]), p(a["running_tasks"]), p(a["flags"]), p(a["env_mask"]), p(a["ip_id"]),
+        p(a["max_tasks"]), p(a["running_tasks"]), p(a["flags"]), p(a["env_mask"]),
+        C.c_uint32(words), p(a["ip_id"]),
         C.c_uint32(N), p(t["env_id"]), p(t["min_version"]), p(t["requestor_ip"]),
         C.c_uint32(chunk_size), C.c_int(int(force_fp64)), p(out), p(util), p(run), C.byref(st))
     if rc:

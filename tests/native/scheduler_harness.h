@@ -1,4 +1,5 @@
-// scheduler_harness.h — flare-free stand-in for the reference's RPC layer.
+// scheduler_harness.h — TEST SCAFFOLDING (not in libydc.so): flare-free stand-in for the
+// reference's RPC layer.
 //
 // SchedulerServiceImpl (reference yadcc/scheduler/scheduler_service_impl.cc) is the only
 // caller of TaskDispatcher. It is NOT rebuilt here (flare RPC, protobuf and token roll-out

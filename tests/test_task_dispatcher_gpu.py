@@ -1,240 +1,75 @@
-"""GpuTaskDispatcher on the MI355X against the reference class itself.
-
-(1) The reference's own gtest cases (yadcc/scheduler/task_dispatcher_test.cc:29-144 `All`,
-    :146-186 `PreferDedicated`, :216-298 `LoadBalanceCase`) re-expressed call for call, real
-    sleeps replaced by the injected clock + OnExpirationTimer.
-(2) A seeded random event stream (heartbeats, grant batches, frees, lease renewals, servant
-    reports, clock + timer) applied to our class and to the reference's translation units
-    compiled verbatim (oracle/_ref); every observable answer must be identical."""
-import numpy as np
+"""GpuTaskDispatcher on the MI355X (libydc.so) against the reference class itself: the
+scenarios of tests/td_scenarios.py — the reference's own gtest cases call for call, wake-up
+order, and seeded random event streams (3 digests; 150 digests = multi-word environment
+masks) compared answer for answer with the reference's translation units compiled verbatim."""
 import pytest
 
 from oracle import refbind as R
+from tests import td_scenarios as S
 from yadcc_amd import dispatcher as D
 
 pytestmark = pytest.mark.gpu
 needs_ref = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
-G50 = 50 << 30
+
+
+def make(**kw):
+    d = D.GpuTaskDispatcher(device=0, **kw)
+    assert d.device_status == 0
+    return d
 
 
 @pytest.fixture
 def td():
-    d = D.GpuTaskDispatcher(device=0)
-    assert d.device_status == 0
+    d = make()
     yield d
     d.close()
 
 
 def test_golden_all(td):
-    """task_dispatcher_test.cc:29-144."""
-    td.keep_servant_alive("127.0.0.1:1234", ["digest"], 10, 10, 0, memory_available=G50)
-    st, _, _ = td.wait_for_starting_new_task("127.0.0.1", "not found", timeout_in_ms=1000)
-    assert st == D.ENV_NOT_FOUND
-    tasks = []
-    for _ in range(10):
-        st, tid, loc = td.wait_for_starting_new_task("127.0.0.1", "digest", expires_in_ms=5000,
-                                                     timeout_in_ms=1000)
-        assert st == D.GRANTED and loc == "127.0.0.1:1234"
-        tasks.append(tid)
-    assert tasks == list(range(10))  # next_task_id starts at 0 (task_dispatcher.h:218)
-    st, _, _ = td.wait_for_starting_new_task("127.0.0.1", "digest", timeout_in_ms=0)
-    assert st == D.TIMEOUT
-    assert not td.keep_task_alive(12345678, 1000)
-    for t in tasks:
-        assert td.keep_task_alive(t, 1000)
-    assert td.notify_servant_running_tasks("127.0.0.1:1234", [tasks[0], 1000002, 1000003]) == [
-        1000002, 1000003]
-    td.clock_advance_ms(2000)
-    td.on_expiration_timer()  # leases (1 s) expired -> zombies
-    for t in tasks:
-        assert not td.keep_task_alive(t, 1000)
-    assert td.notify_servant_running_tasks("127.0.0.1:1234", tasks) == tasks
-    td.keep_servant_alive("127.0.0.1:1234", ["digest"], 10, 10, 0, memory_available=G50,
-                          expires_in_ms=1000)
-    td.clock_advance_ms(2000)
-    td.on_expiration_timer()  # servant expired
-    st, _, _ = td.wait_for_starting_new_task("127.0.0.1", "digest", timeout_in_ms=0)
-    assert st != D.GRANTED
+    S.golden_all(td)
 
 
 def test_golden_prefer_dedicated(td):
-    """task_dispatcher_test.cc:146-186."""
-    td.keep_servant_alive("127.0.0.1:1234", ["digest"], 10, 10, 0, priority=D.PRIORITY_USER,
-                          memory_available=G50)
-    st, tid, loc = td.wait_for_starting_new_task("127.0.0.1", "digest")
-    assert (st, loc) == (D.GRANTED, "127.0.0.1:1234")  # self allowed when alone
-    td.free_task(tid)
-    td.keep_servant_alive("192.168.0.1:1234", ["digest"], 10, 10, 2,
-                          priority=D.PRIORITY_DEDICATED, memory_available=G50)
-    st, tid, loc = td.wait_for_starting_new_task("127.0.0.1", "digest")
-    assert (st, loc) == (D.GRANTED, "192.168.0.1:1234")
+    S.golden_prefer_dedicated(td)
 
 
 def test_golden_load_balance(td):
-    """task_dispatcher_test.cc:216-298: expected picks 1,2,3,2,1,2,3."""
-    from tests.test_oracle_golden import LB, LB_EXPECT
-    loads = {}
-    loc0, mt, npz, ld = LB[0]
-    td.keep_servant_alive(loc0, ["Load Balance"], mt, npz, ld, memory_available=G50)
-    st, _, _ = td.wait_for_starting_new_task("127.0.0.3", "Load Balance", timeout_in_ms=0)
-    assert st == D.TIMEOUT  # overloaded servant: Timeout, not EnvironmentNotFound (:217-228)
-    for loc, mt, npz, ld in LB[1:]:
-        td.keep_servant_alive(loc, ["Load Balance"], mt, npz, ld, memory_available=G50)
-        loads[loc] = [mt, npz, ld]
-    got = []
-    for _ in LB_EXPECT:
-        st, _, loc = td.wait_for_starting_new_task("127.0.0.3", "Load Balance")
-        assert st == D.GRANTED
-        got.append([x[0] for x in LB].index(loc))
-        loads[loc][2] += 1
-        td.keep_servant_alive(loc, ["Load Balance"], *loads[loc], memory_available=G50)
-    assert got == LB_EXPECT
+    S.golden_load_balance(td)
 
 
 def test_blocking_wait_is_woken_by_free_task():
-    """A request that finds no free servant waits until FreeTask's notify_all
-    (task_dispatcher.cc:116-118,187) — real clock, second thread."""
-    import threading
-    import time
-    td = D.GpuTaskDispatcher(device=0, fake_clock=False)
-    td.keep_servant_alive("10.0.0.1:1", ["d"], 1, 8, 0, memory_available=G50)
-    st, tid, _ = td.wait_for_starting_new_task("9.9.9.9", "d", expires_in_ms=60000)
-    assert st == D.GRANTED
-    t0 = time.time()
-    st2, _, _ = td.wait_for_starting_new_task("9.9.9.9", "d", timeout_in_ms=200)
-    assert st2 == D.TIMEOUT and time.time() - t0 >= 0.19
-    out = {}
+    S.blocking_wait_is_woken_by_free_task(make)
 
-    def waiter():
-        out["r"] = td.wait_for_starting_new_task("9.9.9.9", "d", timeout_in_ms=5000)
 
-    th = threading.Thread(target=waiter)
-    th.start()
-    time.sleep(0.2)
-    td.free_task(tid)
-    th.join(5)
-    assert out["r"][0] == D.GRANTED and out["r"][2] == "10.0.0.1:1"
-    td.close()
+def test_heartbeat_wakes_nobody():
+    S.heartbeat_wakes_nobody(make)
 
 
 def test_concurrent_callers_are_combined():
-    """Many threads calling WaitForStartingNewTask at once: every grant is distinct, the pool
-    fills exactly, the rest time out — whatever the interleaving."""
-    import threading
-    td = D.GpuTaskDispatcher(device=0, fake_clock=False)
-    for i in range(8):
-        td.keep_servant_alive("10.0.0.%d:1" % i, ["d"], 5, 16, 0, memory_available=G50)
-    res = []
-    lock = threading.Lock()
-
-    def worker(k):
-        for _ in range(10):
-            r = td.wait_for_starting_new_task("9.9.9.%d" % k, "d", expires_in_ms=60000)
-            with lock:
-                res.append(r)
-
-    ths = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
-    granted = [r for r in res if r[0] == D.GRANTED]
-    assert len(granted) == 40 and len(res) == 80
-    assert sorted(r[1] for r in granted) == list(range(40))
-    per = {}
-    for r in granted:
-        per[r[2]] = per.get(r[2], 0) + 1
-    assert all(v == 5 for v in per.values()) and len(per) == 8
-    td.close()
+    S.concurrent_callers_are_combined(make)
 
 
-DIGESTS = ["c0ffee%02d" % i + "0" * 56 for i in range(3)]
+def test_location_that_does_not_fit_is_an_error():
+    S.location_that_does_not_fit_is_an_error(make)
 
 
-def _random_personality(rng, i):
-    envs = [d for d in DIGESTS if rng.random() < 0.6] or [DIGESTS[int(rng.integers(3))]]
-    nproc = int(rng.choice([8, 16, 32, 64]))
-    ded = rng.random() < 0.3
-    return dict(
-        location="10.1.%d.%d:%d" % (i // 200, i % 200, 8335 + (i % 3 == 0) * (i % 7)),
-        envs=envs, max_tasks=0 if rng.random() < 0.05 else (nproc * (95 if ded else 40)) // 100,
-        num_processors=nproc, current_load=int(rng.integers(0, int(nproc * 1.25))),
-        priority=1 if ded else 2, version=int(rng.choice([19, 20, 20, 20])),
-        total_memory=0 if rng.random() < 0.2 else 64 << 30,
-        memory_available=(1 << 30) if rng.random() < 0.07 else (32 << 30),
-        expires_in_ms=int(rng.integers(1500, 8000)))
+def test_address_forms():
+    S.address_forms(make)
 
 
 @needs_ref
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_event_stream_matches_reference(seed):
-    rng = np.random.default_rng(seed)
-    ref = R.RefDispatcher()
-    td = D.GpuTaskDispatcher(device=0)
-    n_pool = 60
-    # some servants share a host (same ip, different port) to exercise the `self` rule
-    hosts = ["10.1.0.%d" % (i if i % 5 else max(i - 1, 0)) for i in range(n_pool)]
-    live = {}          # task id -> location
-    by_servant = {}    # location -> list of task ids ever granted there
+    S.event_stream_matches_reference(make, seed)
 
-    def heartbeat(i):
-        p = _random_personality(rng, i)
-        p["location"] = "%s:%d" % (hosts[i], 9000 + i)
-        for d in (ref, td):
-            d.keep_servant_alive(**p)
 
-    for i in range(0, n_pool, 2):
-        heartbeat(i)
-    for step in range(400):
-        ev = rng.random()
-        if ev < 0.25:
-            heartbeat(int(rng.integers(n_pool)))
-        elif ev < 0.55:
-            n = int(rng.integers(1, 40))
-            ips = [hosts[int(rng.integers(n_pool))] if rng.random() < 0.3 else "172.16.0.%d" % rng.integers(250)
-                   for _ in range(n)]
-            dg = [("unknown" if rng.random() < 0.03 else DIGESTS[int(rng.integers(3))]) for _ in range(n)]
-            mv = [int(rng.choice([0, 20])) for _ in range(n)]
-            lease = int(rng.integers(500, 6000))
-            st, ids, locs = td.wait_for_starting_new_tasks(ips, dg, mv, expires_in_ms=lease)
-            for k in range(n):
-                rst, rid, rloc = ref.wait_for_starting_new_task(ips[k], dg[k], min_version=mv[k],
-                                                                expires_in_ms=lease)
-                assert (int(st[k]), locs[k] or None) == (rst, rloc), (seed, step, k)
-                if rst == R.OK:
-                    assert int(ids[k]) == rid
-                    live[rid] = rloc
-                    by_servant.setdefault(rloc, []).append(rid)
-        elif ev < 0.70 and live:
-            tid = int(rng.choice(list(live))) if rng.random() < 0.9 else 10 ** 9
-            for d in (ref, td):
-                d.free_task(tid)
-            live.pop(tid, None)
-        elif ev < 0.78 and live:
-            tid = int(rng.choice(list(live))) if rng.random() < 0.9 else 10 ** 9
-            ms = int(rng.integers(500, 6000))
-            assert ref.keep_task_alive(tid, ms) == td.keep_task_alive(tid, ms)
-        elif ev < 0.90 and by_servant:
-            loc = str(rng.choice(list(by_servant)))
-            ids = [t for t in by_servant[loc] if rng.random() < 0.7][-30:] + (
-                [10 ** 9 + step] if rng.random() < 0.3 else [])
-            a = ref.notify_servant_running_tasks(loc, ids)
-            b = td.notify_servant_running_tasks(loc, ids)
-            assert a == b, (seed, step)
-            assert sorted(ref.get_running_tasks()) == sorted(td.get_running_tasks())
-        else:
-            ms = int(rng.integers(200, 2500))
-            R.clock_advance_ms(ms)
-            td.clock_advance_ms(ms)
-            R.fire_timers()
-            td.on_expiration_timer()
-    # drain: everything that is still placeable must go to the same servants
-    ips = ["172.16.9.9"] * 300
-    dg = [DIGESTS[i % 3] for i in range(300)]
-    st, ids, locs = td.wait_for_starting_new_tasks(ips, dg, [0] * 300)
-    for k in range(300):
-        rst, rid, rloc = ref.wait_for_starting_new_task(ips[k], dg[k], min_version=0)
-        assert (int(st[k]), locs[k] or None) == (rst, rloc), (seed, "drain", k)
-    ref.close()
-    td.close()
+@needs_ref
+@pytest.mark.parametrize("seed", [11, 12])
+def test_event_stream_150_digests(seed):
+    """More than 64 distinct live compiler digests (the reference has no limit,
+    task_dispatcher.h:93-94, .cc:55-63): multi-word environment masks on the device."""
+    dump = S.event_stream_matches_reference(make, seed, n_digests=150, n_pool=120, steps=500)
+    assert dump["gpu"]["environment_mask_words"] >= 2
 
 
 def test_native_scheduler_harness():

@@ -21,7 +21,8 @@ STAGES = ("servant_scan", "slot_gen", "sort", "class_lists", "task_classify", "m
 # Every symbol include/yadcc_dispatch.h declares (tests check they are all exported).
 ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
-    "ydc_upload_servants", "ydc_update_servants", "ydc_release_slots", "ydc_set_running",
+    "ydc_upload_servants", "ydc_update_servants", "ydc_update_servants_wide",
+    "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
@@ -40,7 +41,7 @@ ABI_SYMBOLS = (
 class ServantSoA(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("version", "num_processors", "current_load",
                                            "max_tasks", "running_tasks", "flags", "env_mask",
-                                           "ip_id")]
+                                           "ip_id")] + [("env_words", C.c_uint32)]
 
 
 # numpy view of ydc_servant_row (32 bytes)
@@ -96,6 +97,9 @@ def lib():
         L.ydc_upload_servants.argtypes = [C.c_void_p, C.POINTER(ServantSoA), C.c_uint32]
         L.ydc_update_servants.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ServantRow),
                                           C.c_uint32]
+        L.ydc_update_servants_wide.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ServantRow),
+                                               C.c_void_p, C.c_uint32, C.c_uint32]
+        L.ydc_remove_servants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_release_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_set_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_get_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -234,7 +238,8 @@ class Context:
                                             lib().ydc_last_error(self._h).decode()))
 
     def upload_servants(self, cols):
-        """cols: dict of numpy columns named like ydc_servant_soa (see pack.to_abi_columns)."""
+        """cols: dict of numpy columns named like ydc_servant_soa (see pack.to_abi_columns).
+        env_mask: (n,) for up to 64 interned digests, or (n, env_words)."""
         keep = {}
         soa = ServantSoA()
         for k, dt in (("version", np.uint32), ("num_processors", np.uint32),
@@ -244,20 +249,37 @@ class Context:
             keep[k] = np.ascontiguousarray(cols[k], dtype=dt)
             setattr(soa, k, keep[k].ctypes.data)
         n = len(keep["version"])
+        soa.env_words = keep["env_mask"].shape[1] if keep["env_mask"].ndim == 2 else 1
         self._check(lib().ydc_upload_servants(self._h, C.byref(soa), n), "ydc_upload_servants")
         self.n_servants = n
 
-    def update_servants(self, idx, rows):
+    def update_servants(self, idx, rows, env_masks=None):
+        """rows: dicts named like ydc_servant_row. env_masks: optional (len(rows), env_words)
+        uint64 array for registries with more than 64 interned digests (rows' env_mask is
+        ignored then)."""
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         arr = (ServantRow * len(rows))()
         for i, r in enumerate(rows):
             for k in ("version", "num_processors", "current_load", "max_tasks", "flags", "ip_id",
                       "env_mask"):
-                setattr(arr[i], k, int(r[k]))
-        self._check(lib().ydc_update_servants(self._h, idx.ctypes.data, arr, len(rows)),
-                    "ydc_update_servants")
+                setattr(arr[i], k, int(r.get(k, 0)) if isinstance(r, dict) else int(r[k]))
+        if env_masks is None:
+            self._check(lib().ydc_update_servants(self._h, idx.ctypes.data, arr, len(rows)),
+                        "ydc_update_servants")
+        else:
+            em = np.ascontiguousarray(env_masks, dtype=np.uint64).reshape(len(rows), -1)
+            self._check(lib().ydc_update_servants_wide(self._h, idx.ctypes.data, arr,
+                                                       em.ctypes.data, em.shape[1], len(rows)),
+                        "ydc_update_servants_wide")
         if len(idx):
             self.n_servants = max(self.n_servants, int(idx.max()) + 1)
+
+    def remove_servants(self, idx):
+        """Servant expiry: rows idx (ascending) leave, the rest keeps its order."""
+        a = np.ascontiguousarray(idx, dtype=np.uint32)
+        self._check(lib().ydc_remove_servants(self._h, a.ctypes.data, len(a)),
+                    "ydc_remove_servants")
+        self.n_servants -= len(a)
 
     def release_slots(self, servant_idx):
         a = np.ascontiguousarray(servant_idx, dtype=np.uint32)

@@ -120,16 +120,19 @@ YDC_HD bool task_mask_empty(const TaskTable& T, uint32_t t) {
 
 // UnsafeEnumerateEligibleServants (:316-344) per class: the class advertises the
 // digest and its version is not below min_version. Classes only contain servants
-// with max_tasks != 0. Writes `words` mask words.
+// with max_tasks != 0. cls_env holds env_words words per class (digest j = bit j % 64
+// of word j / 64). Writes `words` mask words.
 YDC_HD void task_class_mask(uint32_t env_id, uint32_t min_version, const uint64_t* cls_env,
                             const uint32_t* cls_ver, uint32_t n_classes, uint32_t words,
-                            uint64_t* out) {
+                            uint64_t* out, uint32_t env_words = 1) {
   for (uint32_t w = 0; w < words; ++w) {
     uint64_t m = 0;
-    if (env_id < 64) {
+    if (env_id < 64 * env_words) {
       uint32_t c0 = w * 64, c1 = c0 + 64 < n_classes ? c0 + 64 : n_classes;
       for (uint32_t c = c0; c < c1; ++c) {
-        if (((cls_env[c] >> env_id) & 1u) && cls_ver[c] >= min_version) m |= 1ull << (c - c0);
+        if (((cls_env[(size_t)c * env_words + (env_id >> 6)] >> (env_id & 63)) & 1u) &&
+            cls_ver[c] >= min_version)
+          m |= 1ull << (c - c0);
       }
     }
     out[w] = m;

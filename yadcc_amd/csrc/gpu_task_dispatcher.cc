@@ -41,12 +41,18 @@ bool ParseSize(const std::string& s, std::size_t* out) {
 
 // Host part of a location for the requestor-is-the-servant test
 // (IsNetworkAddressEqual, task_dispatcher.cc:66-69: `location` starts with
-// `requestor_ip` followed by ':'). Exact for "a.b.c.d:port" endpoints (what
-// scheduler_service_impl.cc:102-103 produces for IPv4); bracketed IPv6
-// locations never equal a requestor address in the reference either.
-std::string HostOf(const std::string& location) {
+// `requestor_ip` followed by ':'). The servant is keyed by the text before its
+// FIRST ':': exact for "a.b.c.d:port" endpoints (what scheduler_service_impl.cc:102-103
+// produces for IPv4) and for bracketed IPv6 locations "[..]:port" against address
+// literals (which never match in the reference either). A requestor string that
+// itself contains ':' and equals a longer prefix of a location would match in the
+// reference and does not here ("address forms").
+// A location without any ':' equals no requestor address in the reference
+// (`ip_port[ip2.size()] == ':'` can never hold); *has_host is false then.
+std::string HostOf(const std::string& location, bool* has_host) {
   auto p = location.find(':');
-  return p == std::string::npos ? std::string() : location.substr(0, p);
+  *has_host = p != std::string::npos;
+  return *has_host ? location.substr(0, p) : std::string();
 }
 
 std::uint32_t Clamp32(std::size_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (std::uint32_t)v; }
@@ -157,7 +163,11 @@ GpuTaskDispatcher::~GpuTaskDispatcher() {
 void GpuTaskDispatcher::TimerLoop() {
   std::unique_lock lk(timer_lock_);
   while (!stopping_) {
+#if defined(__SANITIZE_THREAD__)
+    if (timer_cv_.wait_until(lk, std::chrono::system_clock::now() + 1s, [this] { return stopping_; })) break;
+#else
     if (timer_cv_.wait_for(lk, 1s, [this] { return stopping_; })) break;
+#endif
     lk.unlock();
     OnExpirationTimer();
     lk.lock();
@@ -186,11 +196,17 @@ std::uint32_t GpuTaskDispatcher::InternIp(const std::string& ip, bool create) {
 
 std::uint32_t GpuTaskDispatcher::LookupEnv(const std::string& digest) const {
   auto it = env_ids_.find(digest);
-  return it == env_ids_.end() ? 0xFFFFu : it->second.first;
+  return it == env_ids_.end() ? 0xFFFFFFFFu : it->second.first;  // unknown: nobody has it
 }
 
-std::uint64_t GpuTaskDispatcher::AcquireEnvMask(const std::vector<std::string>& digests) {
-  std::uint64_t mask = 0;
+// Interns the digests a servant advertises: one bit number per digest, as many 64-bit mask
+// words as the live digests need (the reference keeps an unbounded vector of
+// EnvironmentDesc per servant, task_dispatcher.h:93-94 — no limit here either). Returns
+// the bit numbers in listing order; a digest listed twice holds two references, and
+// ReleaseEnvBits walks the same list.
+std::vector<std::uint32_t> GpuTaskDispatcher::AcquireEnvBits(const std::vector<std::string>& digests) {
+  std::vector<std::uint32_t> bits;
+  bits.reserve(digests.size());
   for (auto&& d : digests) {
     auto it = env_ids_.find(d);
     if (it == env_ids_.end()) {
@@ -198,23 +214,18 @@ std::uint64_t GpuTaskDispatcher::AcquireEnvMask(const std::vector<std::string>& 
       if (!free_env_bits_.empty()) {
         bit = free_env_bits_.back();
         free_env_bits_.pop_back();
-      } else if (env_ids_.size() < YDC_MAX_ENVS) {
-        bit = (std::uint32_t)env_ids_.size();
       } else {
-        ++env_overflow_;  // more than 64 distinct live digests: not representable
-        continue;
+        bit = next_env_bit_++;
       }
       it = env_ids_.emplace(d, std::make_pair(bit, 0u)).first;
     }
-    // A servant listing a digest twice still holds one reference per listing;
-    // ReleaseEnvMask walks the same list.
     ++it->second.second;
-    mask |= 1ull << it->second.first;
+    bits.push_back(it->second.first);
   }
-  return mask;
+  return bits;
 }
 
-void GpuTaskDispatcher::ReleaseEnvMask(const std::vector<std::string>& digests) {
+void GpuTaskDispatcher::ReleaseEnvBits(const std::vector<std::string>& digests) {
   for (auto&& d : digests) {
     auto it = env_ids_.find(d);
     if (it == env_ids_.end()) continue;
@@ -240,10 +251,10 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
     // (task_dispatcher.cc:195-201).
     idx = it->second;
     Servant* e = servants_[idx].get();
-    std::uint64_t mask = AcquireEnvMask(servant.environments);
-    ReleaseEnvMask(e->personality.environments);
+    auto bits = AcquireEnvBits(servant.environments);
+    ReleaseEnvBits(e->personality.environments);
     e->personality = servant;
-    e->env_mask = mask;
+    e->env_bits = std::move(bits);
     e->expires_at = now + expires_in;
   } else {
     idx = (std::uint32_t)servants_.size();
@@ -253,8 +264,12 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
     added->discovered_at = now;
     added->expires_at = now + expires_in;
     added->running_tasks = 0;  // :210
-    added->env_mask = AcquireEnvMask(servant.environments);
-    added->ip_id = InternIp(HostOf(servant.observed_location), true);
+    added->env_bits = AcquireEnvBits(servant.environments);
+    bool has_host = false;
+    const std::string host = HostOf(servant.observed_location, &has_host);
+    // No ':' in the location: an id of its own that no requestor address can map to.
+    added->ip_id = has_host ? InternIp(host, true)
+                            : InternIp(std::string("\0nohost#", 8) + std::to_string(added->uid), true);
     index_of_location_.emplace(servant.observed_location, idx);
     index_of_uid_.emplace(added->uid, idx);
     servants_.push_back(std::move(added));
@@ -264,10 +279,9 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
     row_is_dirty_[idx] = 1;
     dirty_rows_.push_back(idx);
   }
-  // The reference does not signal the condition variable here
-  // (task_dispatcher.cc:190-220); waiters see the new capacity on their next
-  // attempt, which the epoch makes possible.
-  ++registry_epoch_;
+  // The reference does not signal the condition variable here (task_dispatcher.cc:190-220):
+  // a heartbeat wakes nobody. Parked waiters are retried when FreeTask wakes them
+  // (UnsafeFreeTasks bumps wake_epoch_); a NEW caller sees the new capacity at once.
 }
 
 std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(
@@ -339,7 +353,7 @@ void GpuTaskDispatcher::UnsafeFreeTasks(const std::vector<std::uint64_t>& task_i
     }
     tasks_.erase(it);
   }
-  ++registry_epoch_;
+  ++wake_epoch_;
   allocation_cv_.notify_all();  // :187
 }
 
@@ -359,34 +373,42 @@ void GpuTaskDispatcher::OnExpirationTimer() {
 
   // Expired servants leave the registry; the order of the others is kept
   // because it decides ties (:503-516).
+  std::vector<std::uint32_t> expired;
+  for (std::uint32_t i = 0; i != servants_.size(); ++i)
+    if (servants_[i]->expires_at < now) expired.push_back(i);
   std::vector<std::uint64_t> orphans;
-  bool removed = false;
-  std::size_t w = 0;
-  for (std::size_t i = 0; i != servants_.size(); ++i) {
-    if (servants_[i]->expires_at < now) {
-      Servant* s = servants_[i].get();
-      running_task_bookkeeper_.DropServant(s->personality.observed_location);
-      ReleaseEnvMask(s->personality.environments);
-      orphans.insert(orphans.end(), s->grants.begin(), s->grants.end());
-      index_of_location_.erase(s->personality.observed_location);
-      index_of_uid_.erase(s->uid);
-      removed = true;
-    } else {
-      if (w != i) servants_[w] = std::move(servants_[i]);
-      ++w;
+  if (!expired.empty()) {
+    // Device first, while the host rows still have their old positions: the deltas recorded
+    // against those positions, then an order-preserving compaction of the resident columns on
+    // the device (running_tasks of the survivors stays where it is; no table upload).
+    if (ctx_ && !need_full_upload_) {
+      int rc = UnsafeSyncDevice();
+      if (rc == YDC_OK) rc = ydc_remove_servants(ctx_, expired.data(), (std::uint32_t)expired.size());
+      if (rc != YDC_OK) need_full_upload_ = true;
     }
-  }
-  if (removed) {
+    std::size_t w = 0, next = 0;
+    for (std::size_t i = 0; i != servants_.size(); ++i) {
+      if (next < expired.size() && expired[next] == i) {
+        ++next;
+        Servant* s = servants_[i].get();
+        running_task_bookkeeper_.DropServant(s->personality.observed_location);
+        ReleaseEnvBits(s->personality.environments);
+        orphans.insert(orphans.end(), s->grants.begin(), s->grants.end());
+        index_of_location_.erase(s->personality.observed_location);
+        index_of_uid_.erase(s->uid);
+      } else {
+        if (w != i) servants_[w] = std::move(servants_[i]);
+        ++w;
+      }
+    }
     servants_.resize(w);
     for (std::uint32_t i = 0; i != servants_.size(); ++i) {
       index_of_location_[servants_[i]->personality.observed_location] = i;
       index_of_uid_[servants_[i]->uid] = i;
     }
-    need_full_upload_ = true;
     dirty_rows_.clear();
     pending_release_.clear();
     row_is_dirty_.assign(servants_.size(), 0);
-    ++registry_epoch_;
   }
   // UnsafeSweepOrphans (:478-496): tasks of vanished servants are forgotten at
   // once. Their ids are exactly the grant sets of the servants removed above.
@@ -415,7 +437,8 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
   if (need_full_upload_) {
     const std::size_t n = servants_.size();
     std::vector<std::uint32_t> version(n), nproc(n), load(n), max_tasks(n), running(n), flags(n), ip(n);
-    std::vector<std::uint64_t> env(n);
+    const std::uint32_t ew = EnvWords();
+    std::vector<std::uint64_t> env(n * ew, 0);
     for (std::size_t i = 0; i != n; ++i) {
       const Servant& s = *servants_[i];
       version[i] = (std::uint32_t)s.personality.version;  // compared as unsigned, :333
@@ -424,11 +447,11 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
       max_tasks[i] = Clamp32(s.personality.max_tasks);
       running[i] = Clamp32(s.running_tasks);
       flags[i] = flags_of(s);
-      env[i] = s.env_mask;
+      for (auto b : s.env_bits) env[i * ew + b / 64] |= 1ull << (b % 64);
       ip[i] = s.ip_id;
     }
     ydc_servant_soa soa{version.data(), nproc.data(), load.data(), max_tasks.data(),
-                        running.data(), flags.data(),  env.data(),  ip.data()};
+                        running.data(), flags.data(),  env.data(),  ip.data(), ew};
     int rc = ydc_upload_servants(ctx_, &soa, (std::uint32_t)n);
     if (rc != YDC_OK) return rc;
     need_full_upload_ = false;
@@ -440,6 +463,8 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
   if (!dirty_rows_.empty()) {
     std::sort(dirty_rows_.begin(), dirty_rows_.end());  // appended rows in index order
     std::vector<ydc_servant_row> rows(dirty_rows_.size());
+    const std::uint32_t ew = EnvWords();
+    std::vector<std::uint64_t> env(rows.size() * ew, 0);
     for (std::size_t k = 0; k != dirty_rows_.size(); ++k) {
       const Servant& s = *servants_[dirty_rows_[k]];
       rows[k].version = (std::uint32_t)s.personality.version;
@@ -448,9 +473,11 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
       rows[k].max_tasks = Clamp32(s.personality.max_tasks);
       rows[k].flags = flags_of(s);
       rows[k].ip_id = s.ip_id;
-      rows[k].env_mask = s.env_mask;
+      for (auto b : s.env_bits) env[k * ew + b / 64] |= 1ull << (b % 64);
+      rows[k].env_mask = env[k * ew];
     }
-    int rc = ydc_update_servants(ctx_, dirty_rows_.data(), rows.data(), (std::uint32_t)rows.size());
+    int rc = ydc_update_servants_wide(ctx_, dirty_rows_.data(), rows.data(), env.data(), ew,
+                                      (std::uint32_t)rows.size());
     if (rc != YDC_OK) return rc;
     for (auto i : dirty_rows_) row_is_dirty_[i] = 0;
     dirty_rows_.clear();
@@ -498,7 +525,7 @@ void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
       r->result.ok = false;
       r->result.status = WaitStatus::EnvironmentNotFound;
     } else if (out[i] == YDC_IDX_TIMEOUT) {
-      r->tried_epoch = registry_epoch_;  // stays pending until its deadline (:116-118)
+      r->tried_epoch = wake_epoch_;  // stays pending until its deadline (:116-118)
     } else {
       Servant* pick = servants_[out[i]].get();
       ++pick->running_tasks;  // :123-124 (the device did the same on its column: COMMIT)
@@ -526,14 +553,19 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
     waiting_.insert(waiting_.end(), queue_.begin(), queue_.end());
     queue_.clear();
   }
-  // One device batch, arrival order; requests that already failed against this
-  // very registry state are not retried.
+  // One device batch, arrival order. A parked request is only retried after FreeTask has
+  // woken the waiters (wake_epoch_): in the reference a waiter sleeps until notify_all or
+  // its deadline, and a heartbeat wakes nobody (task_dispatcher.cc:116-118,187,190-220).
   std::vector<Pending*> batch;
   for (auto* r : waiting_)
-    if (!r->done && r->tried_epoch != registry_epoch_) batch.push_back(r);
+    if (!r->done && r->tried_epoch != wake_epoch_) batch.push_back(r);
   UnsafeDispatch(batch);
+  const std::size_t before = waiting_.size();
   waiting_.erase(std::remove_if(waiting_.begin(), waiting_.end(), [](Pending* r) { return r->done; }),
                  waiting_.end());
+  // Requests of other threads may just have been completed by this one: wake their owners
+  // (they sleep on the condition variable until their deadline otherwise).
+  if (waiting_.size() != before) allocation_cv_.notify_all();
 }
 
 WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& personality,
@@ -558,9 +590,21 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
     if (options_.clock) {
       // Injected (test) clock: poll it, do not sleep on the real one.
       timed_out = Now() >= req.deadline;
+#if defined(__SANITIZE_THREAD__)
+      if (!timed_out) allocation_cv_.wait_until(lk, std::chrono::system_clock::now() + 1ms);
+#else
       if (!timed_out) allocation_cv_.wait_for(lk, 1ms);
+#endif
     } else {
+#if defined(__SANITIZE_THREAD__)
+      // GCC 11's libtsan does not intercept pthread_cond_clockwait (what a steady_clock
+      // wait compiles to) and then reports the lock as held across the wait; the sanitizer
+      // build waits on the system clock (pthread_cond_timedwait) instead.
+      timed_out = allocation_cv_.wait_until(lk, std::chrono::system_clock::now() +
+                                                    (req.deadline - Clock::now())) == std::cv_status::timeout;
+#else
       timed_out = allocation_cv_.wait_until(lk, req.deadline) == std::cv_status::timeout;
+#endif
     }
     if (req.done) return req.result;  // a concurrent drain served us meanwhile
     if (timed_out) {
@@ -691,7 +735,7 @@ std::string GpuTaskDispatcher::DumpInternals() {
   j += ",\"gpu\":{\"device\":" + std::to_string(options_.device) +
        ",\"device_status\":" + std::to_string(device_status_) +
        ",\"environments_interned\":" + std::to_string(env_ids_.size()) +
-       ",\"environments_overflowed\":" + std::to_string(env_overflow_) + "}";
+       ",\"environment_mask_words\":" + std::to_string(EnvWords()) + "}";
   j += "}";
   return j;
 }

@@ -166,7 +166,7 @@ class GpuTaskDispatcher {
     Clock::time_point discovered_at, expires_at;
     std::size_t running_tasks = 0;
     std::size_t ever_assigned_tasks = 0;
-    std::uint64_t env_mask = 0;  // interned digests
+    std::vector<std::uint32_t> env_bits;  // interned digests (bit numbers), listing order
     std::uint32_t ip_id = 0;     // interned host part of observed_location
     std::unordered_set<std::uint64_t> grants;  // live task ids (incl. zombies) on this servant
   };
@@ -184,15 +184,17 @@ class GpuTaskDispatcher {
     Clock::time_point deadline;
     bool prefetching;
     bool done = false;
-    std::uint64_t tried_epoch = ~0ull;  // registry epoch of the last failed attempt
+    std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     WaitResult result;
   };
 
   std::size_t CapacityAvailable(const Servant& s) const;  // task_dispatcher.cc:283-313
   std::uint32_t InternIp(const std::string& ip, bool create);
   std::uint32_t LookupEnv(const std::string& digest) const;
-  std::uint64_t AcquireEnvMask(const std::vector<std::string>& digests);
-  void ReleaseEnvMask(const std::vector<std::string>& digests);
+  std::vector<std::uint32_t> AcquireEnvBits(const std::vector<std::string>& digests);
+  void ReleaseEnvBits(const std::vector<std::string>& digests);
+  // 64-bit words an environment mask needs for every bit number handed out so far.
+  std::uint32_t EnvWords() const { return next_env_bit_ ? (next_env_bit_ + 63) / 64 : 1; }
   void UnsafeFreeTasks(const std::vector<std::uint64_t>& task_ids);  // :167-188
   void UnsafeSweepZombiesOf(Servant* servant, const std::unordered_set<std::uint64_t>& running);
   void UnsafeSweepOrphans();
@@ -216,13 +218,13 @@ class GpuTaskDispatcher {
   std::uint64_t next_servant_uid_ = 1;
   std::unordered_map<std::uint64_t, Task> tasks_;
   std::uint64_t next_task_id_ = 0;  // task_dispatcher.h:218
-  std::uint64_t registry_epoch_ = 0;  // bumped by anything that can make a waiter succeed
+  std::uint64_t wake_epoch_ = 0;  // bumped where the reference notifies its waiters (:187)
 
   // interning
   std::unordered_map<std::string, std::uint32_t> ip_ids_;
   std::unordered_map<std::string, std::pair<std::uint32_t, std::uint32_t>> env_ids_;  // digest -> (bit, refs)
   std::vector<std::uint32_t> free_env_bits_;
-  std::uint64_t env_overflow_ = 0;
+  std::uint32_t next_env_bit_ = 0;  // bit numbers handed out so far (freed ones are reused)
 
   // device mirror bookkeeping (deltas applied before the next dispatch)
   bool need_full_upload_ = true;

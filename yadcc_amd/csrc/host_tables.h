@@ -23,45 +23,64 @@ namespace ydc {
 
 struct HostTables {
   std::vector<uint32_t> class_of;   // per servant, kNone when max_tasks == 0
-  std::vector<uint64_t> cls_env;    // per class
+  std::vector<uint64_t> cls_env;    // per class, env_words words each
+  uint32_t env_words = 1;           // 64-bit words of an environment mask
   std::vector<uint32_t> cls_ver;    // per class
   std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant)
   std::vector<uint32_t> ip_servant;
   bool any_shared_ip = false;       // some host runs more than one servant
   // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
   // class versions and <= 256 classes: ver_sorted = the distinct class versions ascending,
-  // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` whose
-  // version is >= ver_sorted[vi] (vi == V: none). A request (env, min_version) looks up
-  // vi = number of entries of ver_sorted below min_version. Empty when not built.
+  // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` (one of
+  // the 64 * env_words bit numbers) whose version is >= ver_sorted[vi] (vi == V: none). A
+  // request (env, min_version) looks up vi = number of entries of ver_sorted below
+  // min_version. Empty when not built.
   std::vector<uint32_t> ver_sorted;
   std::vector<uint64_t> env_ver_mask;
   uint32_t cap_bits = 1;            // max over servants of bits(min(max_tasks, nproc))
   uint64_t max_slots = 0;           // sum over servants of min(max_tasks, nproc): bound on slots
 
-  struct SigHash {
-    size_t operator()(const std::pair<uint64_t, uint32_t>& k) const {
-      return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ull ^ k.second);
-    }
-  };
-
+  // env_mask: words_per_servant words per servant (word w of servant s at
+  // env_mask[s * words_per_servant + w]).
   void build(uint32_t n, const uint64_t* env_mask, const uint32_t* version,
-             const uint32_t* max_tasks, const uint32_t* nproc, const uint32_t* ip_id) {
+             const uint32_t* max_tasks, const uint32_t* nproc, const uint32_t* ip_id,
+             uint32_t words_per_servant = 1) {
+    env_words = std::max<uint32_t>(1, words_per_servant);
+    const uint32_t EW = env_words;
     class_of.assign(n, kNone);
     cls_env.clear();
     cls_ver.clear();
-    std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, SigHash> ids;
+    // Signature (environment set, version) -> class. Buckets by hash, exact compare inside.
+    auto sig_hash = [&](uint32_t s) {
+      uint64_t h = 0x9E3779B97F4A7C15ull ^ version[s];
+      for (uint32_t w = 0; w < EW; ++w)
+        h = (h ^ env_mask[(size_t)s * EW + w]) * 0x100000001B3ull + (h >> 29);
+      return h;
+    };
+    std::unordered_multimap<uint64_t, uint32_t> ids;  // hash -> class
     uint32_t max_cap = 1;
     max_slots = 0;
     for (uint32_t s = 0; s < n; ++s) {
       if (max_tasks[s] == 0) continue;
-      auto key = std::make_pair(env_mask[s], version[s]);
-      auto it = ids.find(key);
-      if (it == ids.end()) {
-        it = ids.emplace(key, (uint32_t)cls_env.size()).first;
-        cls_env.push_back(env_mask[s]);
+      const uint64_t h = sig_hash(s);
+      uint32_t cls = kNone;
+      auto range = ids.equal_range(h);
+      for (auto it = range.first; it != range.second; ++it) {
+        const uint32_t c = it->second;
+        if (cls_ver[c] == version[s] &&
+            std::equal(&cls_env[(size_t)c * EW], &cls_env[(size_t)c * EW] + EW,
+                       &env_mask[(size_t)s * EW])) {
+          cls = c;
+          break;
+        }
+      }
+      if (cls == kNone) {
+        cls = (uint32_t)cls_ver.size();
+        ids.emplace(h, cls);
+        cls_env.insert(cls_env.end(), &env_mask[(size_t)s * EW], &env_mask[(size_t)s * EW] + EW);
         cls_ver.push_back(version[s]);
       }
-      class_of[s] = it->second;
+      class_of[s] = cls;
       uint32_t top = std::min(max_tasks[s], nproc[s]);
       max_cap = std::max(max_cap, top);
       max_slots += top;
@@ -72,13 +91,13 @@ struct HostTables {
     std::sort(ver_sorted.begin(), ver_sorted.end());
     ver_sorted.erase(std::unique(ver_sorted.begin(), ver_sorted.end()), ver_sorted.end());
     env_ver_mask.clear();
-    const uint32_t C = (uint32_t)cls_env.size(), V = (uint32_t)ver_sorted.size();
+    const uint32_t C = (uint32_t)cls_ver.size(), V = (uint32_t)ver_sorted.size();
     if (C && C <= 256 && V <= 16) {
       const uint32_t words = (C + 63) / 64;
-      env_ver_mask.assign((size_t)64 * (V + 1) * words, 0);
+      env_ver_mask.assign((size_t)64 * EW * (V + 1) * words, 0);
       for (uint32_t c = 0; c < C; ++c)
-        for (uint32_t env = 0; env < 64; ++env)
-          if ((cls_env[c] >> env) & 1u)
+        for (uint32_t env = 0; env < 64 * EW; ++env)
+          if ((cls_env[(size_t)c * EW + env / 64] >> (env % 64)) & 1u)
             for (uint32_t vi = 0; vi < V && ver_sorted[vi] <= cls_ver[c]; ++vi)
               env_ver_mask[((size_t)env * (V + 1) + vi) * words + c / 64] |= 1ull << (c % 64);
     } else {
@@ -98,7 +117,7 @@ struct HostTables {
     }
   }
 
-  uint32_t n_classes() const { return (uint32_t)cls_env.size(); }
+  uint32_t n_classes() const { return (uint32_t)cls_ver.size(); }
 };
 
 // Sort-key format for a registry.

@@ -198,6 +198,7 @@ struct ClassifyArgs {
   const uint64_t* cls_env;
   const uint32_t* cls_ver;
   uint32_t n_classes, words;
+  uint32_t env_words;  // words of a class's environment mask (cls_env: env_words per class)
   // Lookup form of the same test (host_tables.h; NULL: loop over the classes instead).
   const uint32_t* ver_sorted;
   const uint64_t* env_ver_mask;
@@ -223,19 +224,22 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
     if (a.env_ver_mask) {
       uint32_t vi = 0;  // class versions below min_version
       for (uint32_t j = 0; j < a.n_versions; ++j) vi += a.ver_sorted[j] < minv;
-      const uint64_t* row = a.env_ver_mask + ((size_t)min(env, 63u) * (a.n_versions + 1) + vi) * a.words;
+      const uint32_t n_env = 64 * a.env_words;  // digests >= n_env: nobody has them
+      const uint64_t* row = a.env_ver_mask + ((size_t)min(env, n_env - 1) * (a.n_versions + 1) + vi) * a.words;
       for (uint32_t w = 0; w < a.words; ++w) {
-        const uint64_t m = env < 64 ? row[w] : 0;
+        const uint64_t m = env < n_env ? row[w] : 0;
         a.mask[(size_t)t * a.words + w] = m;
         any |= m;
       }
     } else
     for (uint32_t w = 0; w < a.words; ++w) {
       uint64_t m = 0;
-      if (env < 64) {
+      if (env < 64 * a.env_words) {
         const uint32_t c0 = w * 64, c1 = min(c0 + 64, a.n_classes);
         for (uint32_t c = c0; c < c1; ++c) {
-          if (((a.cls_env[c] >> env) & 1u) && a.cls_ver[c] >= minv) m |= 1ull << (c - c0);
+          if (((a.cls_env[(size_t)c * a.env_words + (env >> 6)] >> (env & 63)) & 1u) &&
+              a.cls_ver[c] >= minv)
+            m |= 1ull << (c - c0);
         }
       }
       a.mask[(size_t)t * a.words + w] = m;
@@ -847,6 +851,22 @@ __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, co
 }
 
 // Registry maintenance.
+// Servant expiry (task_dispatcher.cc:503-516): rows removed[0..n_removed) (ascending) vanish,
+// the others move up in order. Thread per old row, all six columns.
+struct CompactCols {
+  uint32_t* col[6];
+};
+__global__ __launch_bounds__(256) void k_compact_rows(CompactCols in, CompactCols out,
+                                                      const uint32_t* removed, uint32_t n_removed,
+                                                      uint32_t n) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t before = lower_bound_u32(removed, n_removed, s);  // removed rows below s
+  if (before < n_removed && removed[before] == s) return;         // s itself goes
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out.col[k][s - before] = in.col[k][s];
+}
+
 __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_idx, uint32_t n,
                                                        uint32_t n_servants, uint32_t* running) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -20,9 +20,11 @@ struct ydc_td {
 
 namespace {
 
-void CopyString(const std::string& s, char* out, size_t cap) {
-  if (!out || !cap) return;
+// false: `s` does not fit (the buffer gets the truncated text; the caller reports it).
+bool CopyString(const std::string& s, char* out, size_t cap) {
+  if (!out || !cap) return true;
   std::snprintf(out, cap, "%s", s.c_str());
+  return s.size() < cap;
 }
 
 int StatusOf(const ydc::WaitResult& r) {
@@ -101,7 +103,12 @@ int ydc_td_wait_for_starting_new_task(ydc_td* td, const char* requestor_ip, uint
                                             prefetching != 0);
   if (r.ok) {
     if (out_task_id) *out_task_id = r.allocation.task_id;
-    CopyString(r.allocation.servant_location, out_location, location_cap);
+    if (!CopyString(r.allocation.servant_location, out_location, location_cap)) {
+      // A grant whose servant the caller cannot name is useless: give it back at once
+      // instead of leaking the slot until the lease runs out.
+      td->impl->FreeTask(r.allocation.task_id);
+      return YDC_ERR_CAPACITY;
+    }
   }
   return StatusOf(r);
 }
@@ -128,9 +135,13 @@ int ydc_td_wait_for_starting_new_tasks(ydc_td* td, size_t n, const char* const* 
     out_status[i] = StatusOf(rs[i]);
     if (out_status[i] < 0) worst = out_status[i];
     if (out_task_ids) out_task_ids[i] = rs[i].ok ? rs[i].allocation.task_id : ~0ull;
-    if (out_locations && location_stride)
-      CopyString(rs[i].ok ? rs[i].allocation.servant_location : std::string(),
-                 out_locations + i * location_stride, location_stride);
+    if (out_locations && location_stride &&
+        !CopyString(rs[i].ok ? rs[i].allocation.servant_location : std::string(),
+                    out_locations + i * location_stride, location_stride)) {
+      td->impl->FreeTask(rs[i].allocation.task_id);  // (see the single-request wrapper)
+      if (out_task_ids) out_task_ids[i] = ~0ull;
+      out_status[i] = worst = YDC_ERR_CAPACITY;
+    }
   }
   return worst;
 }

@@ -74,13 +74,15 @@ struct ydc_context {
   // Host mirror of the registry columns the derived tables need.
   uint32_t n_servants = 0;
   std::vector<uint32_t> h_version, h_nproc, h_load, h_max_tasks, h_flags, h_ip;
-  std::vector<uint64_t> h_env;
+  std::vector<uint64_t> h_env;  // env_words words per servant
+  uint32_t env_words = 1;
   HostTables tables;
   KeyFormat kf{};
   bool tables_dirty = true;
 
   // Resident registry.
   DevBuf<uint32_t> d_version, d_nproc, d_load, d_max_tasks, d_running, d_flags, d_class_of;
+  DevBuf<uint32_t> d_spare[6];  // ydc_remove_servants compacts into these, then swaps
   DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted;
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
 
@@ -221,14 +223,14 @@ inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 int rebuild_tables(ydc_context* c) {
   const uint32_t n = c->n_servants;
   c->tables.build(n, c->h_env.data(), c->h_version.data(), c->h_max_tasks.data(),
-                  c->h_nproc.data(), c->h_ip.data());
+                  c->h_nproc.data(), c->h_ip.data(), c->env_words);
   c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits);
   const uint32_t C = c->tables.n_classes();
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
   HIP_TRY(c, c->d_ip_sorted.reserve(n));
   HIP_TRY(c, c->d_ip_servant.reserve(n));
-  HIP_TRY(c, c->d_cls_env.reserve(C));
+  HIP_TRY(c, c->d_cls_env.reserve((size_t)C * c->env_words));
   HIP_TRY(c, c->d_cls_ver.reserve(C));
   HIP_TRY(c, c->d_cls_begin.reserve(C + 1));
   if (n) {
@@ -240,7 +242,7 @@ int rebuild_tables(ydc_context* c) {
                               hipMemcpyHostToDevice, c->stream));
   }
   if (C) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_cls_env.p, c->tables.cls_env.data(), C * 8,
+    HIP_TRY(c, hipMemcpyAsync(c->d_cls_env.p, c->tables.cls_env.data(), (size_t)C * c->env_words * 8,
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_cls_ver.p, c->tables.cls_ver.data(), C * 4,
                               hipMemcpyHostToDevice, c->stream));
@@ -384,7 +386,7 @@ int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
 }
-uint32_t ydc_abi_version(void) { return 1; }
+uint32_t ydc_abi_version(void) { return 2; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
                void* stream, ydc_context** out) {
@@ -453,6 +455,7 @@ int ydc_destroy(ydc_context* c) {
     b->release();
   for (auto* b : {&c->d_cls_env, &c->d_env_ver_mask, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
   c->d_ver_sorted.release();
+  for (auto& b : c->d_spare) b.release();
   c->d_cls_by_g.release();
   c->d_owner.release();
   c->d_rank_to_g.release();
@@ -485,6 +488,8 @@ int ydc_destroy(ydc_context* c) {
 
 int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   if (!c || (n && !sv)) return YDC_ERR_INVALID_ARGUMENT;
+  if (sv && sv->env_words > YDC_MAX_ENV_WORDS)
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "env_words %u > %u", sv->env_words, YDC_MAX_ENV_WORDS);
   if (c->max_servants && n > c->max_servants)
     return fail(c, YDC_ERR_CAPACITY, "%u servants > max_servants %u", n, c->max_servants);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -497,7 +502,8 @@ int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   c->h_max_tasks.assign(sv ? sv->max_tasks : nullptr, sv ? sv->max_tasks + n : nullptr);
   c->h_flags.assign(sv ? sv->flags : nullptr, sv ? sv->flags + n : nullptr);
   c->h_ip.assign(sv ? sv->ip_id : nullptr, sv ? sv->ip_id + n : nullptr);
-  c->h_env.assign(sv ? sv->env_mask : nullptr, sv ? sv->env_mask + n : nullptr);
+  c->env_words = sv && sv->env_words ? sv->env_words : 1;
+  c->h_env.assign(sv ? sv->env_mask : nullptr, sv ? sv->env_mask + (size_t)n * c->env_words : nullptr);
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->d_version.p, sv->version, n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_nproc.p, sv->num_processors, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -510,9 +516,26 @@ int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   return rebuild_tables(c);
 }
 
-int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_row* rows,
-                        uint32_t n) {
+namespace {
+// Re-lays the host copy of the environment masks out for `words` words per servant (the
+// device only holds per-class masks, which rebuild_tables derives from this copy).
+void widen_env(ydc_context* c, uint32_t words) {
+  if (words <= c->env_words) return;
+  std::vector<uint64_t> wide((size_t)c->n_servants * words, 0);
+  for (uint32_t s = 0; s < c->n_servants; ++s)
+    for (uint32_t w = 0; w < c->env_words; ++w)
+      wide[(size_t)s * words + w] = c->h_env[(size_t)s * c->env_words + w];
+  c->h_env.swap(wide);
+  c->env_words = words;
+  c->tables_dirty = true;
+}
+}  // namespace
+
+int ydc_update_servants_wide(ydc_context* c, const uint32_t* idx, const ydc_servant_row* rows,
+                             const uint64_t* env_masks, uint32_t env_words, uint32_t n) {
   if (!c || (n && (!idx || !rows))) return YDC_ERR_INVALID_ARGUMENT;
+  if (env_masks && (env_words == 0 || env_words > YDC_MAX_ENV_WORDS))
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "env_words %u out of range", env_words);
   HIP_TRY(c, hipSetDevice(c->device));
   // Appends first (they may need bigger buffers).
   uint32_t new_n = c->n_servants;
@@ -522,22 +545,27 @@ int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_r
   }
   if (c->max_servants && new_n > c->max_servants)
     return fail(c, YDC_ERR_CAPACITY, "%u servants > max_servants %u", new_n, c->max_servants);
+  if (env_masks) widen_env(c, env_words);
+  const uint32_t EW = c->env_words;
+  auto resize_host = [&](uint32_t m) {
+    c->h_version.resize(m);
+    c->h_nproc.resize(m);
+    c->h_load.resize(m);
+    c->h_max_tasks.resize(m);
+    c->h_flags.resize(m);
+    c->h_ip.resize(m);
+    c->h_env.resize((size_t)m * EW);
+  };
   if (new_n > c->d_version.cap) {
-    // Grow: read the running column back, reallocate, re-upload everything.
+    // Grow: read the running column back, reallocate, re-upload everything. Released slots
+    // (ydc_release_slots only enqueues) must have reached the column first.
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<uint32_t> run(c->n_servants);
     if (c->n_servants)
       HIP_TRY(c, hipMemcpy(run.data(), c->d_running.p, c->n_servants * 4, hipMemcpyDeviceToHost));
     run.resize(new_n, 0);
-    uint32_t old_n = c->n_servants;
-    (void)old_n;
     if (int rc = reserve_registry(c, std::max<uint32_t>(new_n, new_n + new_n / 2))) return rc;
-    c->h_version.resize(new_n);
-    c->h_nproc.resize(new_n);
-    c->h_load.resize(new_n);
-    c->h_max_tasks.resize(new_n);
-    c->h_flags.resize(new_n);
-    c->h_ip.resize(new_n);
-    c->h_env.resize(new_n);
+    resize_host(new_n);
     HIP_TRY(c, hipMemcpy(c->d_running.p, run.data(), new_n * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_version.p, c->h_version.data(), new_n * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_nproc.p, c->h_nproc.data(), new_n * 4, hipMemcpyHostToDevice));
@@ -545,21 +573,23 @@ int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_r
     HIP_TRY(c, hipMemcpy(c->d_max_tasks.p, c->h_max_tasks.data(), new_n * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_flags.p, c->h_flags.data(), new_n * 4, hipMemcpyHostToDevice));
   } else if (new_n > c->n_servants) {
-    c->h_version.resize(new_n);
-    c->h_nproc.resize(new_n);
-    c->h_load.resize(new_n);
-    c->h_max_tasks.resize(new_n);
-    c->h_flags.resize(new_n);
-    c->h_ip.resize(new_n);
-    c->h_env.resize(new_n);
+    resize_host(new_n);
     HIP_TRY(c, hipMemsetAsync(c->d_running.p + c->n_servants, 0, (new_n - c->n_servants) * 4, c->stream));
   }
+  bool structural = new_n != c->n_servants;
   c->n_servants = new_n;
-  bool structural = false;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t s = idx[i];
     const ydc_servant_row& r = rows[i];
-    structural |= c->h_version[s] != r.version || c->h_env[s] != r.env_mask ||
+    uint64_t* env = &c->h_env[(size_t)s * EW];
+    bool env_changed = false;
+    for (uint32_t w = 0; w < EW; ++w) {
+      const uint64_t m = env_masks ? (w < env_words ? env_masks[(size_t)i * env_words + w] : 0)
+                                   : (w == 0 ? r.env_mask : 0);
+      env_changed |= env[w] != m;
+      env[w] = m;
+    }
+    structural |= env_changed || c->h_version[s] != r.version ||
                   c->h_ip[s] != r.ip_id || (c->h_max_tasks[s] == 0) != (r.max_tasks == 0) ||
                   std::min(c->h_max_tasks[s], c->h_nproc[s]) != std::min(r.max_tasks, r.num_processors);
     c->h_version[s] = r.version;
@@ -568,7 +598,6 @@ int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_r
     c->h_max_tasks[s] = r.max_tasks;
     c->h_flags[s] = r.flags;
     c->h_ip[s] = r.ip_id;
-    c->h_env[s] = r.env_mask;
   }
   if (n) {
     // One staged copy of the update list + one scatter kernel (rows are SoA on the device).
@@ -586,6 +615,63 @@ int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_r
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (structural || c->tables_dirty) return rebuild_tables(c);
   return YDC_OK;
+}
+
+int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_row* rows,
+                        uint32_t n) {
+  return ydc_update_servants_wide(c, idx, rows, nullptr, 1, n);
+}
+
+int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
+  if (!c || (n && !idx)) return YDC_ERR_INVALID_ARGUMENT;
+  if (!n) return YDC_OK;
+  for (uint32_t i = 0; i < n; ++i)
+    if (idx[i] >= c->n_servants || (i && idx[i] <= idx[i - 1]))
+      return fail(c, YDC_ERR_INVALID_ARGUMENT, "removed rows must be ascending and < %u", c->n_servants);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t S = c->n_servants, kept = S - n, EW = c->env_words;
+  // Device: order-preserving compaction of the six resident columns into spare buffers,
+  // which then take their place (running_tasks of the survivors never leaves the device).
+  HIP_TRY(c, c->d_upd_idx.reserve(n));
+  for (auto& b : c->d_spare) HIP_TRY(c, b.reserve(c->d_version.cap));
+  HIP_TRY(c, hipMemcpyAsync(c->d_upd_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  CompactCols in{{c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p, c->d_running.p, c->d_flags.p}};
+  CompactCols out{{c->d_spare[0].p, c->d_spare[1].p, c->d_spare[2].p, c->d_spare[3].p, c->d_spare[4].p,
+                   c->d_spare[5].p}};
+  hipLaunchKernelGGL(k_compact_rows, dim3(ceil_div(S, 256)), dim3(256), 0, c->stream, in, out,
+                     c->d_upd_idx.p, n, S);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (idx is pageable; the swap below retires the old columns)
+  DevBuf<uint32_t>* cols[6] = {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
+                               &c->d_flags};
+  for (int k = 0; k < 6; ++k) std::swap(*cols[k], c->d_spare[k]);
+  // Host mirror.
+  uint32_t w = 0, next = 0;
+  for (uint32_t s = 0; s < S; ++s) {
+    if (next < n && idx[next] == s) {
+      ++next;
+      continue;
+    }
+    if (w != s) {
+      c->h_version[w] = c->h_version[s];
+      c->h_nproc[w] = c->h_nproc[s];
+      c->h_load[w] = c->h_load[s];
+      c->h_max_tasks[w] = c->h_max_tasks[s];
+      c->h_flags[w] = c->h_flags[s];
+      c->h_ip[w] = c->h_ip[s];
+      for (uint32_t e = 0; e < EW; ++e) c->h_env[(size_t)w * EW + e] = c->h_env[(size_t)s * EW + e];
+    }
+    ++w;
+  }
+  c->n_servants = kept;
+  c->h_version.resize(kept);
+  c->h_nproc.resize(kept);
+  c->h_load.resize(kept);
+  c->h_max_tasks.resize(kept);
+  c->h_flags.resize(kept);
+  c->h_ip.resize(kept);
+  c->h_env.resize((size_t)kept * EW);
+  return rebuild_tables(c);  // classes, the ip table and the slot bound follow the registry
 }
 
 int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
@@ -787,7 +873,7 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   ClassifyArgs ca{};
   if (N) {
     ca = ClassifyArgs{TaskColumns{tk->env_id, tk->min_version, tk->requestor_ip}, N,
-                      c->d_cls_env.p, c->d_cls_ver.p, C, W,
+                      c->d_cls_env.p, c->d_cls_ver.p, C, W, c->env_words,
                       c->tables.env_ver_mask.empty() ? nullptr : c->d_ver_sorted.p,
                       c->tables.env_ver_mask.empty() ? nullptr : c->d_env_ver_mask.p,
                       (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
@@ -1671,13 +1757,24 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
       break;
     }
     const ydc_servant_row& r = upd_rows[i];
-    structural = c->h_version[s] != r.version || c->h_env[s] != r.env_mask ||
+    structural = c->h_version[s] != r.version || (c->env_words == 1 && c->h_env[s] != r.env_mask) ||
                  c->h_ip[s] != r.ip_id || (c->h_max_tasks[s] == 0) != (r.max_tasks == 0) ||
                  std::min(c->h_max_tasks[s], c->h_nproc[s]) != std::min(r.max_tasks, r.num_processors);
   }
   uint32_t graph_upd = n_upd;
   if (structural) {
-    if (int rc = ydc_update_servants(c, upd_idx, upd_rows, n_upd)) return rc;
+    if (c->env_words == 1) {
+      if (int rc = ydc_update_servants(c, upd_idx, upd_rows, n_upd)) return rc;
+    } else {
+      // Wide masks do not fit a tick's rows: the servants keep their environments.
+      std::vector<uint64_t> env((size_t)n_upd * c->env_words, 0);
+      for (uint32_t i = 0; i < n_upd; ++i)
+        if (upd_idx[i] < c->n_servants)
+          std::copy_n(&c->h_env[(size_t)upd_idx[i] * c->env_words], c->env_words,
+                      &env[(size_t)i * c->env_words]);
+      if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, env.data(), c->env_words, n_upd))
+        return rc;
+    }
     graph_upd = 0;
   } else {
     for (uint32_t i = 0; i < n_upd; ++i) {
@@ -1705,7 +1802,7 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
     std::memcpy(sm.h_ip, tasks->requestor_ip, (size_t)n_tasks * 4);
   }
   for (uint32_t i = n_tasks; i < sm.max_tasks; ++i) {
-    sm.h_env[i] = 0xFFFFu;  // a digest nobody has: EnvironmentNotFound, consumes nothing
+    sm.h_env[i] = 0xFFFFFFFFu;  // a digest nobody has: EnvironmentNotFound, consumes nothing
     sm.h_minv[i] = 0;
     sm.h_ip[i] = 0;
   }

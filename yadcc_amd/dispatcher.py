@@ -37,14 +37,12 @@ class _RunningTask(C.Structure):
                 ("servant_location", C.c_char_p), ("task_digest", C.c_char_p)]
 
 
-_typed = False
-
-
-def _lib():
-    global _typed
-    L = binding.lib()
-    if not _typed:
+def type_td_functions(L):
+    """Declares the ydc_td_* prototypes on a loaded library (once per library object)."""
+    if not getattr(L, "_ydc_td_typed", False):
         u64p = C.POINTER(C.c_uint64)
+        L.ydc_strerror.restype = C.c_char_p
+        L.ydc_strerror.argtypes = [C.c_int]
         L.ydc_td_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.ydc_td_destroy.argtypes = [C.c_void_p]
         L.ydc_td_device_status.argtypes = [C.c_void_p]
@@ -67,8 +65,12 @@ def _lib():
         L.ydc_td_on_expiration_timer.argtypes = [C.c_void_p]
         L.ydc_td_dump_internals.argtypes = [C.c_void_p]
         L.ydc_td_dump_internals.restype = C.c_char_p
-        _typed = True
+        L._ydc_td_typed = True
     return L
+
+
+def _lib():
+    return type_td_functions(binding.lib())
 
 
 MS = 1_000_000  # ns
@@ -80,18 +82,24 @@ class GpuTaskDispatcher:
 
     LOC = 128
 
+    @staticmethod
+    def _load():
+        """The library behind this object: libydc.so (HIP; no CPU placement exists in it)."""
+        return _lib()
+
     def __init__(self, device=0, min_memory=None, start_timer=False, fake_clock=True):
+        self._L = self._load()
         h = C.c_void_p()
-        rc = _lib().ydc_td_create(device, min_memory.encode() if min_memory else None,
+        rc = self._L.ydc_td_create(device, min_memory.encode() if min_memory else None,
                                   int(start_timer), int(fake_clock), C.byref(h))
         if rc:
-            raise binding.YdcError("ydc_td_create: %s" % _lib().ydc_strerror(rc).decode())
+            raise binding.YdcError("ydc_td_create: %s" % self._L.ydc_strerror(rc).decode())
         self._h = h
         self._now_ns = 0
 
     def close(self):
         if self._h:
-            _lib().ydc_td_destroy(self._h)
+            self._L.ydc_td_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -102,11 +110,11 @@ class GpuTaskDispatcher:
 
     @property
     def device_status(self):
-        return _lib().ydc_td_device_status(self._h)
+        return self._L.ydc_td_device_status(self._h)
 
     def clock_advance_ms(self, ms):
         self._now_ns += int(ms) * MS
-        _lib().ydc_td_set_clock_ns(self._h, self._now_ns)
+        self._L.ydc_td_set_clock_ns(self._h, self._now_ns)
 
     def keep_servant_alive(self, location, envs, max_tasks, num_processors, current_load,
                            priority=PRIORITY_USER, version=8, total_memory=0,
@@ -116,19 +124,19 @@ class GpuTaskDispatcher:
         s = _Servant(version, location.encode(), (reported or location).encode(), arr, len(envs),
                      num_processors, current_load, total_memory, memory_available, max_tasks,
                      priority, reason)
-        rc = _lib().ydc_td_keep_servant_alive(self._h, C.byref(s), expires_in_ms * MS)
+        rc = self._L.ydc_td_keep_servant_alive(self._h, C.byref(s), expires_in_ms * MS)
         assert rc == 0
 
     def wait_for_starting_new_task(self, requestor_ip, digest, min_version=8,
                                    expires_in_ms=1000, timeout_in_ms=0, prefetching=False):
         tid = C.c_uint64(0)
         buf = C.create_string_buffer(self.LOC)
-        st = _lib().ydc_td_wait_for_starting_new_task(
+        st = self._L.ydc_td_wait_for_starting_new_task(
             self._h, requestor_ip.encode(), min_version, digest.encode(), expires_in_ms * MS,
             timeout_in_ms * MS, int(prefetching), C.byref(tid), buf, self.LOC)
         if st < 0:
             raise binding.YdcError("wait_for_starting_new_task: %s" %
-                                   _lib().ydc_strerror(st).decode())
+                                   self._L.ydc_strerror(st).decode())
         if st != GRANTED:
             return st, None, None
         return GRANTED, tid.value, buf.value.decode()
@@ -145,23 +153,23 @@ class GpuTaskDispatcher:
         st = np.empty(n, dtype=np.int32)
         ids = np.empty(n, dtype=np.uint64)
         locs = C.create_string_buffer(max(n, 1) * self.LOC)
-        rc = _lib().ydc_td_wait_for_starting_new_tasks(
+        rc = self._L.ydc_td_wait_for_starting_new_tasks(
             self._h, n, ips, mv.ctypes.data, dg, expires_in_ms * MS,
             pf.ctypes.data if pf is not None else None, st.ctypes.data, ids.ctypes.data, locs,
             self.LOC)
         if rc < 0:
             raise binding.YdcError("wait_for_starting_new_tasks: %s" %
-                                   _lib().ydc_strerror(rc).decode())
+                                   self._L.ydc_strerror(rc).decode())
         raw = locs.raw
         out_locs = [raw[i * self.LOC:(i + 1) * self.LOC].split(b"\0", 1)[0].decode()
                     for i in range(n)]
         return st, ids, out_locs
 
     def keep_task_alive(self, task_id, ms):
-        return bool(_lib().ydc_td_keep_task_alive(self._h, task_id, ms * MS))
+        return bool(self._L.ydc_td_keep_task_alive(self._h, task_id, ms * MS))
 
     def free_task(self, task_id):
-        _lib().ydc_td_free_task(self._h, task_id)
+        self._L.ydc_td_free_task(self._h, task_id)
 
     def notify_servant_running_tasks(self, location, grant_ids, servant_task_ids=None,
                                      digests=None):
@@ -173,7 +181,7 @@ class GpuTaskDispatcher:
             arr[i].servant_location = location.encode()
             arr[i].task_digest = digests[i].encode() if digests else None
         out = np.zeros(max(n, 1), dtype=np.uint64)
-        cnt = _lib().ydc_td_notify_servant_running_tasks(self._h, location.encode(), arr, n,
+        cnt = self._L.ydc_td_notify_servant_running_tasks(self._h, location.encode(), arr, n,
                                                          out.ctypes.data, len(out))
         assert cnt >= 0
         return [int(x) for x in out[:cnt]]
@@ -182,7 +190,7 @@ class GpuTaskDispatcher:
         st = np.zeros(cap, dtype=np.uint64)
         gr = np.zeros(cap, dtype=np.uint64)
         locs = C.create_string_buffer(cap * self.LOC) if with_strings else None
-        n = _lib().ydc_td_get_running_tasks(self._h, st.ctypes.data, gr.ctypes.data, locs,
+        n = self._L.ydc_td_get_running_tasks(self._h, st.ctypes.data, gr.ctypes.data, locs,
                                             self.LOC if with_strings else 0, None, 0, cap)
         pairs = list(zip(st[:n].tolist(), gr[:n].tolist()))
         if not with_strings:
@@ -192,7 +200,7 @@ class GpuTaskDispatcher:
                 for i, (a, b) in enumerate(pairs)]
 
     def on_expiration_timer(self):
-        _lib().ydc_td_on_expiration_timer(self._h)
+        self._L.ydc_td_on_expiration_timer(self._h)
 
     def dump_internals(self):
-        return json.loads(_lib().ydc_td_dump_internals(self._h).decode())
+        return json.loads(self._L.ydc_td_dump_internals(self._h).decode())

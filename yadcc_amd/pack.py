@@ -42,6 +42,6 @@ def to_abi_columns(sv, min_memory=MIN_MEMORY_DEFAULT):
         "max_tasks": c("max_tasks", np.uint32),
         "running_tasks": c("running_tasks", np.uint32),
         "flags": servant_flags(sv, min_memory),
-        "env_mask": c("env_mask", np.uint64),
+        "env_mask": c("env_mask", np.uint64),  # (n,) or (n, env_words)
         "ip_id": c("ip", np.uint32),
     }

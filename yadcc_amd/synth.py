@@ -35,6 +35,15 @@ def make_servants(n, n_tasks_hint=None, n_envs=1, seed=42, p_set=(64, 96, 128, 1
                      rng.integers(16 * GIB, 200 * GIB, n)).astype(np.uint64)
     if n_envs == 1:
         env_mask = np.ones(n, dtype=np.uint64)
+    elif n_envs > 64:
+        # More digests than one mask word holds: (n, env_words) masks, every servant advertises
+        # 1-5 of the digests (the reference keeps an unbounded list per servant,
+        # yadcc/scheduler/task_dispatcher.h:93-94).
+        words = (n_envs + 63) // 64
+        env_mask = np.zeros((n, words), dtype=np.uint64)
+        for s in range(n):
+            for j in rng.choice(n_envs, size=int(rng.integers(1, 6)), replace=False):
+                env_mask[s, j // 64] |= np.uint64(1) << np.uint64(j % 64)
     elif disjoint_envs:
         env_mask = (np.uint64(1) << rng.integers(0, n_envs, n).astype(np.uint64))
     else:
