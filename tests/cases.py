@@ -119,3 +119,26 @@ def handmade_cases():
         dict(num_processors=5_000_011, max_tasks=5_000_000, running_tasks=4_999_985,
              current_load=4_999_000, ip=0x0A000002, priority=1)]), tk([{}] * 30)))
     return out
+
+
+# ---------------------------------------------------------------------------
+# Full-size pools pinned to the VERBATIM reference: tests/golden/ref_cfg{3,4}_prefix_50k.npz hold
+# the reference's placement of the first 50k requests of the cfg3 / cfg4 batches (generated by
+# tests/golden/make_golden.py). A sequential batch's prefix is the prefix batch, so the first
+# 50k answers of any full-size run must equal them.
+# ---------------------------------------------------------------------------
+def reference_prefix(cfg, sv, tk):
+    """Returns the reference's servant indexes for the first requests of config `cfg`, after
+    checking that (sv, tk) are the inputs the fixture was generated from."""
+    import hashlib
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "ref_%s_prefix_50k.npz" % cfg))
+    n = int(z["prefix"])
+    h = hashlib.sha256()
+    for k in sorted(sv):
+        h.update(np.ascontiguousarray(sv[k]).tobytes())
+    for k in sorted(tk):
+        h.update(np.ascontiguousarray(tk[k][:n]).tobytes())
+    assert h.hexdigest() == str(z["input_sha256"]), "generator drift: regenerate tests/golden"
+    return z["ref_servant_idx"]

@@ -9,7 +9,8 @@ import pytest
 from oracle import oraclebind as O
 from tests.model import modelbind as M
 
-FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+ALL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+FILES = [f for f in ALL if "_prefix_" not in f]  # whole small batches (inputs inside)
 
 
 def test_fixtures_exist():
@@ -27,3 +28,17 @@ def test_oracle_and_model_reproduce_reference_vectors(path):
         assert np.array_equal(run, z["ref_running_after"]), method
     idx, _, run, _ = M.dispatch(sv, tk, 128)
     assert np.array_equal(idx, z["ref_servant_idx"]) and np.array_equal(run, z["ref_running_after"])
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_full_size_pools_prefix_matches_reference(cfg):
+    """BASELINE.json configs[2] / configs[3] at their real pool sizes (8k / 16k servants): the
+    slot-order restatement used for the full-size GPU parity checks reproduces the verbatim
+    reference on the first 50k requests of the batch."""
+    from tests import cases
+    from yadcc_amd import synth
+    sv, tk = synth.make_config(cfg)
+    ref = cases.reference_prefix(cfg, sv, tk)
+    head = {k: v[:len(ref)] for k, v in tk.items()}
+    idx, _, _ = O.dispatch(sv, head, "sorted")
+    assert np.array_equal(idx, ref)

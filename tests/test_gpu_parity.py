@@ -76,7 +76,8 @@ def test_golden_fixture_file(ctx):
     import glob
     import os
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-    assert files, "no golden fixtures committed"
+    files = [f for f in files if "_prefix_" not in f]  # (those: test_cfg3_full_size, cfg4)
+    assert len(files) >= 6, "golden fixtures missing"
     for f in files:
         z = np.load(f)
         sv = {k[3:]: z[k] for k in z.files if k.startswith("sv_")}
@@ -104,6 +105,20 @@ def test_cfg3_full_size(ctx):
     sv, tk = synth.make_config("cfg3")
     st = check(ctx, sv, tk)
     assert st["n_classes"] >= 20 and st["env_not_found"] > 0
+    # ... and pinned to the VERBATIM reference on the first 50k requests of this very batch.
+    ref = cases.reference_prefix("cfg3", sv, tk)
+    got, _, _ = ctx.dispatch(tk, want_util=False, want_running=False)
+    assert np.array_equal(got[:len(ref)], ref)
+
+
+def test_cfg4_full_size_one_gpu(ctx):
+    """BASELINE.json configs[3]'s batch (4M requests x 16k servants) on ONE GPU: against the
+    slot-order oracle, and its first 50k placements against the verbatim reference."""
+    sv, tk = synth.make_config("cfg4")
+    check(ctx, sv, tk)
+    ref = cases.reference_prefix("cfg4", sv, tk)
+    got, _, _ = ctx.dispatch(tk, want_util=False, want_running=False)
+    assert np.array_equal(got[:len(ref)], ref)
 
 
 def test_cfg3_disjoint_envs(ctx):

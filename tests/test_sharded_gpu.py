@@ -165,6 +165,10 @@ def test_cfg4_shape_eight_ranks(n_tasks):
     cuts = [n * r // 8 for r in range(9)]
     res = sharded_run(ctxs, sv, tk, cuts)
     check_against_oracle(res, sv, tk)
+    if n_tasks == 4_000_000:
+        # the real configs[3] pool: pinned to the verbatim reference on the first 50k requests
+        ref = cases.reference_prefix("cfg4", sv, tk)
+        assert np.array_equal(np.concatenate([r[0] for r in res])[:len(ref)], ref)
     [c.close() for c in ctxs]
 
 
