@@ -6,9 +6,19 @@ One "step" = one pass of the hot path over one batch: BASELINE.json configs[1]
 resident servant table, request columns and result buffers already in HBM. Each step
 starts from the same snapshot (no COMMIT), so every step does identical work.
 
+`value` is the HBM-resident rate (the bench contract: inputs resident when the timed
+region starts). The metric as SURVEY.md §8(d) words it — batch visible to the dispatcher ->
+all results visible to the host, i.e. H2D + kernels + D2H through ydc_dispatch — is in
+`end_to_end` on the same line (rate, p50 / p99 over >= 100 batches); `value_definition` says
+which is which.
+
 GPU work goes through yadcc_amd/libydc.so only (its own HIP runtime, /opt/rocm). For
-N > 1 (launched by torch.distributed.run, one rank per GPU) torch.distributed is used
-for the rendezvous, the barriers and the max-over-ranks of the wall time.
+N > 1 (launched by torch.distributed.run, one rank per GPU) torch.distributed (gloo) is used
+for the rendezvous, the barriers and the max-over-ranks of the wall time; the data path of
+the sharded batch is RCCL inside libydc.so. `--scaling weak` (default): G ranks place ONE
+global batch of G x (the config's requests) on a pool of G x (the config's servants);
+`--scaling strong`: the config's batch itself (e.g. --config cfg4: 4M requests x 16k
+servants = BASELINE.json configs[3]) is cut into G rank ranges.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,6 +31,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+METRIC = "task-to-servant assignments/sec on synthetic pool"
 
 
 def percentile(a, q):
@@ -71,30 +83,58 @@ def stream_main(args):
     """BASELINE.json configs[4]: 10k requests/tick x 2k servants with rolling heartbeats (10 % of
     the servants per tick) and 10k frees per tick; the whole tick is one replay of a captured
     hipGraph (ydc_stream_tick). A step is a tick; only the tick call is timed (the event
-    generator is host-side test scaffolding). Host buffers in, host results out."""
+    generator is host-side test scaffolding). Host buffers in, host results out. The reference
+    class replays the first ticks of the very same stream beside it (heartbeats, frees by
+    grant id, sequential WaitForStartingNewTask calls): cpu_baseline + per-tick parity."""
     from yadcc_amd import binding, pack, streaming, synth
     sv, _ = synth.make_config("cfg5")
     es = streaming.EventStream(sv, 10_000, 10_000)
     ctx = binding.Context(device=int(os.environ.get("LOCAL_RANK", 0)))
     ctx.upload_servants(pack.to_abi_columns(sv))
     ctx.stream_begin(es.hb + 8, 10_000, 10_000)
+    ref = ref_ids = None
+    ref_ticks = 0 if args.no_cpu_baseline else 30  # ~ 300k reference calls, ~10 s
+    ref_secs, ref_granted, ref_lat, parity = 0.0, 0, [], True
+    if ref_ticks:
+        from oracle import refbind as R
+        if R.available():
+            ref = R.RefDispatcher()
+            ref.load_servants(sv)
+            ref_ids = np.empty(0, np.uint64)  # grant id of every live grant, stream order
     lat, granted = [], 0
     for t in range(args.warmup + args.steps):
         who, rows, rel, tk = es.next_tick()
+        if ref is not None and t < ref_ticks:
+            # heartbeats: the same personalities, current_load as the stream reports it
+            hb = {k: v[who] for k, v in es.sv.items()}
+            hb["running_tasks"] = np.zeros(len(who), np.uint32)  # (kept by a renewal anyway)
+            ref.load_servants(hb)
+            ref.free_tasks(ref_ids[es.last_freed])
+            ref_ids = ref_ids[es.last_kept]
+            ridx, rids, secs, rl = ref.dispatch_batch(tk, want_latency=True)
+            ref_secs += secs
+            ref_lat.append(rl)
+            ok = ridx < R.IDX_ENV_NOT_FOUND
+            ref_granted += int(ok.sum())
+            ref_ids = np.concatenate([ref_ids, rids[ok]])
         s0 = time.perf_counter()
         got = ctx.stream_tick(who, rows, rel, tk)
         dt = time.perf_counter() - s0
+        if ref is not None and t < ref_ticks:
+            parity &= bool(np.array_equal(got, ridx))
         es.commit(got)
         if t >= args.warmup:
             lat.append(dt)
             granted += int((got < binding.IDX_ENV_NOT_FOUND).sum())
     st = ctx.stats()
     out = {
-        "metric": "task-to-servant assignments/sec on synthetic pool",
+        "metric": METRIC,
         "value": granted / sum(lat), "unit": "assignments/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * sum(lat) / len(lat),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
+        "value_definition": "end to end per tick: host buffers in (one H2D copy), registry "
+                            "deltas + batch + commit, results back on the host (PCIe included)",
         "config": {"workload": "cfg5 streaming: 10000 requests + 10000 frees + %d heartbeats per "
                                "tick x %d servants, hipGraph-captured step" % (es.hb, es.n),
                    "parallelism": "1 GPU", "inputs": "host buffers per tick (PCIe included)"},
@@ -102,6 +142,28 @@ def stream_main(args):
         "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
         "stats": {k: v for k, v in st.items() if k != "stage_ms"},
     }
+    # 16 B per request + 40 B per servant per tick over the whole tick: the
+    # captured step is one graph launch, so the "dominant kernel" is the step itself.
+    alg = 16 * 10_000 + 40 * es.n
+    tick_s = sum(lat) / len(lat)
+    out["roofline"] = {"bound": "hbm", "kernel": "captured step (17 graph nodes)",
+                       "achieved": alg / tick_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": alg / tick_s / 8e12, "traffic": None,
+                       "algorithmic_bytes_per_launch": alg, "avg_launch_us": tick_s * 1e6}
+    if ref is not None:
+        ref.close()
+        rl = np.concatenate(ref_lat)
+        out["cpu_baseline"] = {
+            "value": ref_granted / ref_secs, "unit": "assignments/s", "cores": 1,
+            "kind": "reference",
+            "sample": "the first %d ticks of the same stream replayed through the reference class "
+                      "(heartbeats, frees by grant id, %d sequential WaitForStartingNewTask calls, "
+                      "%.2f s inside them)" % (ref_ticks, len(rl), ref_secs),
+            "p99_latency_us": percentile(rl, 0.99) / 1e3,
+            "ms_per_tick": 1e3 * ref_secs / ref_ticks,
+            "host_cores_available": os.cpu_count()}
+        out["parity_vs_cpu_baseline"] = parity
+        out["parity_ticks"] = ref_ticks
     print(json.dumps(out))
     ctx.stream_end()
     ctx.close()
@@ -115,6 +177,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--shared-ip-frac", type=float, default=0.0,
+                    help="fraction of servants that share a host with an earlier one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.config == "cfg5":
@@ -138,12 +203,16 @@ def main():
         if dist:
             dist.barrier()
 
-    # Weak scaling: G ranks place ONE global batch of G x (the config's requests) on a pool of
-    # G x (the config's servants); rank r owns the r-th range of the batch (arrival order).
+    # Weak: one global batch of G x (the config's requests) on G x (the config's servants).
+    # Strong: the config's own batch and pool. Either way rank r owns the r-th range of the
+    # batch (arrival order).
     n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[args.config]
-    sv = synth.make_servants(s_cfg * world, n_tasks_hint=n_cfg * world, n_envs=n_envs, seed=42)
-    tk_all = synth.make_tasks(n_cfg * world, sv, n_envs=n_envs, unknown_env_frac=unk)
-    lo, hi = n_cfg * rank, n_cfg * (rank + 1)
+    mult = world if args.scaling == "weak" else 1
+    n_all = n_cfg * mult
+    sv = synth.make_servants(s_cfg * mult, n_tasks_hint=n_all, n_envs=n_envs, seed=42,
+                             shared_ip_frac=args.shared_ip_frac)
+    tk_all = synth.make_tasks(n_all, sv, n_envs=n_envs, unknown_env_frac=unk)
+    lo, hi = n_all * rank // world, n_all * (rank + 1) // world
     tk = {k: v[lo:hi] for k, v in tk_all.items()}
     n_tasks, n_serv = hi - lo, len(sv["version"])
     # One rank per GPU; if the launcher narrowed this process to a single visible device it is 0.
@@ -154,6 +223,7 @@ def main():
     ctx.upload_servants(pack.to_abi_columns(sv))
     group_note = None
     sharded = False
+    rccl_ranks, is_rccl = 0, False
     if use_dist:
         try:
             ids = [binding.group_unique_id() if rank == 0 else None]
@@ -170,6 +240,8 @@ def main():
                 ctx.group_destroy()
                 sharded = False
                 group_note = group_note or "another rank could not join the RCCL group"
+        if sharded:
+            rccl_ranks, is_rccl = ctx.group_size()  # ncclCommCount of the communicator
     DA = binding.DeviceArray
     d_env = DA.from_numpy(tk["env_id"], local_rank)
     d_minv = DA.from_numpy(tk["min_version"], local_rank)
@@ -205,17 +277,43 @@ def main():
         g = torch.tensor([granted_all], dtype=torch.float64)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         elapsed, granted_all = float(t[0]), float(g[0])
+    # p50 / p99 want >= 100 samples whatever --steps is (extra batches, outside the timed region).
+    lat_all = list(lat)
+    while len(lat_all) < 100:
+        barrier()
+        s0 = time.perf_counter()
+        step()
+        lat_all.append(time.perf_counter() - s0)
 
-    # Host-buffer entry point (H2D of 12 B/request + D2H of 4 B/request over PCIe): reported
-    # beside `value`, never as `value`.
-    host_rate = None
+    # SURVEY.md §8(d)'s assignments/s: batch visible to the dispatcher -> all results visible to
+    # the host, through the host-buffer entry point ydc_dispatch (H2D of 12 B/request over
+    # PCIe, kernels, D2H of 4 B/request). Reported in `end_to_end`, next to `value`.
+    e2e = None
     if not use_dist:
-        n_host = max(3, min(20, args.steps))
         ctx.dispatch(tk, want_util=False, want_running=False)
-        h0 = time.perf_counter()
-        for _ in range(n_host):
+        hl = []
+        for _ in range(max(100, min(1000, args.steps))):
+            s0 = time.perf_counter()
             ctx.dispatch(tk, want_util=False, want_running=False)
-        host_rate = st["granted"] * n_host / (time.perf_counter() - h0)
+            hl.append(time.perf_counter() - s0)
+        e2e = {"assignments_per_s": st["granted"] * len(hl) / sum(hl),
+               "ms_per_batch": 1e3 * sum(hl) / len(hl),
+               "p50_ms": 1e3 * percentile(hl, 0.50), "p99_ms": 1e3 * percentile(hl, 0.99),
+               "batches": len(hl),
+               "definition": "ydc_dispatch with host buffers: H2D + kernels + D2H (PCIe included), "
+                             "SURVEY.md 8(d)"}
+
+    # N > 1: the placement of the whole batch against the oracle (one more step, gathered).
+    parity_oracle = None
+    if use_dist and dist:
+        step()
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(d_out.numpy(), parts, dst=0)
+        if rank == 0:
+            from oracle import oraclebind as O
+            want, _, wrun = O.dispatch(sv, tk_all, "sorted", want_util=False)
+            parity_oracle = bool(np.array_equal(np.concatenate(parts), want) and
+                                 np.array_equal(d_run.numpy(), wrun))
 
     # Per-kernel durations: HIP events on the dispatch stream, separate profiled steps so
     # the events do not perturb the timed region.
@@ -237,31 +335,44 @@ def main():
 
     if rank == 0:
         host_idx = d_out.numpy()
+        shape = "%d pending requests x %d servants" % (n_all, n_serv)
         out = {
-            "metric": "task-to-servant assignments/sec on synthetic pool",
+            "metric": METRIC,
             "value": granted_all * args.steps / elapsed,
             "unit": "assignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32" if st["key_bits"] <= 32 else "u64",
             "data": "synthetic",
-            "config": {"workload": "%s: %d pending requests x %d servants per GPU, %d classes"
-                                   % (args.config, n_cfg, s_cfg, st["n_classes"]),
+            "value_definition": "HBM-resident: request columns, servant table and results stay in "
+                                "HBM (kernels + one 200-byte outcome read-back per batch); the "
+                                "host-buffer rate of SURVEY.md 8(d) is in end_to_end",
+            "config": {"workload": "%s%s: %s%s, %d classes" % (
+                           args.config, "" if world == 1 else " (%s scaling)" % args.scaling, shape,
+                           ", %.0f %% of the servants on shared hosts" % (100 * args.shared_ip_frac)
+                           if args.shared_ip_frac else "", st["n_classes"]),
                        "parallelism": "1 GPU" if world == 1 else
                                       ("one global batch of %d requests x %d servants sharded by "
                                        "rank range over %d GPUs, RCCL all-gather of boundary states "
-                                       "and servant-slot deltas" % (n_cfg * world, n_serv, world)
+                                       "and servant-slot deltas" % (n_all, n_serv, world)
                                        if sharded else group_note),
                        "inputs": "request columns + servant table resident in HBM; results in HBM"},
-            "p99_dispatch_latency_ms": 1e3 * percentile(lat, 0.99),
-            "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
+            "p99_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.99),
+            "p50_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.50),
+            "latency_samples": len(lat_all),
             "stats": {k: v for k, v in st.items() if k != "stage_ms"},
             "stage_ms": stage_ms,
             "kernels_us_per_step": {k: 1e3 * v[1] / n_prof for k, v in prof.items()},
+            "kernel_launches_per_step": {k: v[0] / n_prof for k, v in prof.items()},
         }
-        if host_rate:
-            out["host_buffers_assignments_per_s"] = host_rate
+        if e2e:
+            out["end_to_end"] = e2e
+            out["host_buffers_assignments_per_s"] = e2e["assignments_per_s"]
+        if use_dist:
+            out["rccl_ranks"] = rccl_ranks
+            out["rccl"] = is_rccl
+            out["parity_vs_oracle"] = parity_oracle
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
             launches, total_ms = prof[dom]
@@ -301,8 +412,8 @@ def main():
 
 def pmc_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this config
-    (profiles/*_<config>_pmc_hbm.json, written by tools/profile.sh: FETCH_SIZE doubled for wide
-    coalesced reads + WRITE_SIZE, per MI355X_MICROARCH.md §HBM; separate --pmc passes), or None
+    (profiles/*_<config>_pmc_hbm.json, written by tools/profile.sh: FETCH_SIZE + WRITE_SIZE with
+    the calibration factors of profiles/*_hbm_calibration.txt; separate --pmc passes), or None
     when no profile of this kernel is committed. PMC counters cannot be read from inside the
     timed run, so this is the figure of the profiled run of the same command."""
     import glob

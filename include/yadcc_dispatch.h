@@ -200,6 +200,9 @@ int ydc_group_init(ydc_context* ctx, const void* id128, int rank, int n_ranks);
  * sharding protocol is exercised on a single-GPU machine. */
 int ydc_group_init_local(ydc_context** ctxs, int n);
 int ydc_group_destroy(ydc_context* ctx);
+/* Ranks of the group this context belongs to (0: none). For an RCCL group the number comes
+ * from the communicator (ncclCommCount) and *out_is_rccl (nullable) is 1. */
+int ydc_group_size(ydc_context* ctx, int* out_ranks, int* out_is_rccl);
 /* Collective. The global batch is the concatenation, in rank order, of the slices the ranks
  * pass in (device pointers; a slice may be empty); placement is identical to
  * ydc_dispatch_device of the whole batch on one GPU. d_out_servant_idx / d_out_utilization

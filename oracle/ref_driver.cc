@@ -219,6 +219,10 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
   }
 }
 
+void ref_free_tasks(ref_dispatcher* d, const uint64_t* task_ids, size_t n) {
+  for (size_t i = 0; i != n; ++i) d->impl.FreeTask(task_ids[i]);
+}
+
 double ref_dispatch_batch(ref_dispatcher* d, size_t n, const uint32_t* env_id,
                           const uint32_t* min_version, const uint32_t* requestor_ip,
                           uint32_t* out_servant_idx, uint64_t* out_task_id,

@@ -83,6 +83,9 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
                             const uint64_t* memory_available, const uint64_t* env_mask,
                             uint32_t env_words, const uint32_t* ip, const uint32_t* port);
 
+/* n x FreeTask (one call across the binding instead of n). */
+void ref_free_tasks(ref_dispatcher* d, const uint64_t* task_ids, size_t n);
+
 /* N sequential WaitForStartingNewTask(timeout = now). out_servant_idx[i] is the
  * registry index of the granted servant, or REF_IDX_TIMEOUT / REF_IDX_ENV_NOT_FOUND.
  * env_id >= 64 * env_words of the loaded masks denotes a digest no servant has. out_latency_ns may be NULL.

@@ -51,6 +51,7 @@ def lib():
         L.ref_load_servants.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 11
         L.ref_load_servants_wide.argtypes = ([C.c_void_p, C.c_size_t] + [C.c_void_p] * 9 +
                                              [C.c_uint32] + [C.c_void_p] * 2)
+        L.ref_free_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_dispatch_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.ref_dispatch_batch.restype = C.c_double
         L.ref_digest_name.argtypes = [C.c_uint32, C.c_char_p]
@@ -102,6 +103,10 @@ class RefDispatcher:
 
     def free_task(self, task_id):
         lib().ref_free_task(self._h, task_id)
+
+    def free_tasks(self, task_ids):
+        a = np.ascontiguousarray(task_ids, dtype=np.uint64)
+        lib().ref_free_tasks(self._h, _p(a), len(a))
 
     def notify_servant_running_tasks(self, location, grant_ids, servant_task_ids=None):
         g = np.asarray(grant_ids, dtype=np.uint64)

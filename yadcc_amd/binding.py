@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
     "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_end",
     "ydc_group_unique_id", "ydc_group_init", "ydc_group_init_local", "ydc_group_destroy",
+    "ydc_group_size",
     "ydc_dispatch_sharded",
     # host class wrapper (yadcc_amd/dispatcher.py types them)
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
@@ -115,6 +116,7 @@ def lib():
         L.ydc_group_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ydc_group_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.ydc_group_destroy.argtypes = [C.c_void_p]
+        L.ydc_group_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ydc_dispatch_sharded.argtypes = L.ydc_dispatch.argtypes
         L.ydc_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -325,6 +327,12 @@ class Context:
         """Collective (like ncclCommInitRank). unique_id: the 128 bytes of group_unique_id()."""
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(lib().ydc_group_init(self._h, buf, rank, n_ranks), "ydc_group_init")
+
+    def group_size(self):
+        """(ranks, is_rccl): for an RCCL group the count is ncclCommCount of the communicator."""
+        n, r = C.c_int(0), C.c_int(0)
+        self._check(lib().ydc_group_size(self._h, C.byref(n), C.byref(r)), "ydc_group_size")
+        return n.value, bool(r.value)
 
     def group_destroy(self):
         self._check(lib().ydc_group_destroy(self._h), "ydc_group_destroy")

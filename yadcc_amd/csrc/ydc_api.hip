@@ -108,6 +108,7 @@ struct ydc_context {
     ncclComm_t comm = nullptr;
     decltype(&ncclAllGather) all_gather_fn = nullptr;
     decltype(&ncclCommDestroy) comm_destroy_fn = nullptr;
+    decltype(&ncclCommCount) comm_count_fn = nullptr;
     decltype(&ncclGetErrorString) error_string_fn = nullptr;
     LocalHub* hub = nullptr;
     DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
@@ -1394,6 +1395,7 @@ int ydc_group_init(ydc_context* c, const void* id128, int rank, int n_ranks) {
   g.all_gather_fn = (decltype(&ncclAllGather))dlsym(g.rccl, "ncclAllGather");
   g.comm_destroy_fn = (decltype(&ncclCommDestroy))dlsym(g.rccl, "ncclCommDestroy");
   g.error_string_fn = (decltype(&ncclGetErrorString))dlsym(g.rccl, "ncclGetErrorString");
+  g.comm_count_fn = (decltype(&ncclCommCount))dlsym(g.rccl, "ncclCommCount");
   if (!init_fn || !g.all_gather_fn || !g.comm_destroy_fn)
     return fail(c, YDC_ERR_HIP, "librccl lacks ncclCommInitRank / ncclAllGather / ncclCommDestroy");
   ncclUniqueId id;
@@ -1421,6 +1423,21 @@ int ydc_group_init_local(ydc_context** ctxs, int n) {
     ctxs[r]->group.hub = hub;
     ctxs[r]->group.rank = r;
     ctxs[r]->group.n_ranks = n;
+  }
+  return YDC_OK;
+}
+
+int ydc_group_size(ydc_context* c, int* out_ranks, int* out_is_rccl) {
+  if (!c || !out_ranks) return YDC_ERR_INVALID_ARGUMENT;
+  auto& g = c->group;
+  *out_ranks = g.n_ranks;
+  if (out_is_rccl) *out_is_rccl = g.comm ? 1 : 0;
+  if (g.comm && g.comm_count_fn) {
+    // Ask the communicator itself (ncclCommCount), not our own bookkeeping.
+    int n = 0;
+    ncclResult_t r = g.comm_count_fn(g.comm, &n);
+    if (r != ncclSuccess) return fail(c, YDC_ERR_HIP, "ncclCommCount failed");
+    *out_ranks = n;
   }
   return YDC_OK;
 }

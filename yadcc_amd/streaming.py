@@ -43,6 +43,9 @@ class EventStream:
         rel = self.live[pick]
         keep = np.ones(len(self.live), bool)
         keep[pick] = False
+        # Which of the live grants (in the order commit() appended them) this tick frees: lets a
+        # caller that tracks grant ids beside the stream (the reference replay) free the same ones.
+        self.last_freed, self.last_kept = pick, keep
         self.live = self.live[keep]
         np.subtract.at(self.running, rel, 1)
         tk = synth.make_tasks(self.tasks_per_tick, self.sv, n_envs=self.n_envs,
