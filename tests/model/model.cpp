@@ -35,7 +35,9 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
   HostTables T;
   T.build(S, env_mask, version, max_tasks, nproc, ip_id, env_words);
   const uint32_t C = T.n_classes();
-  KeyFormat kf = choose_key_format(force_fp64 ? 32 : T.cap_bits);
+  uint32_t G = T.n_comp;  // independent parts of the registry (host_tables.h)
+  KeyFormat kf = choose_key_format(force_fp64 ? 32 : T.cap_bits, 11, &G);
+  auto comp_of = [&](uint32_t cls) { return G > 1 ? T.cls_comp[cls] : 0u; };
 
   // --- servant scan: slot counts and bases.
   std::vector<uint32_t> base(S + 1, 0);
@@ -49,14 +51,18 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
 
   // --- slot generation + stable sort by key (generation order breaks ties).
   std::vector<uint64_t> key(M);
+  std::vector<uint32_t> comp_rank_base(G + 1, 0);  // slots of the parts before g
   for (uint32_t s = 0; s < S; ++s) {
     for (uint32_t g = base[s]; g < base[s + 1]; ++g) {
       uint32_t r = running[s] + (g - base[s]);
       uint32_t cap = slot_capacity(nproc[s], load[s], max_tasks[s], r);
       uint32_t tier = slot_tier(nproc[s], flags[s], r);
       key[g] = kf.exact ? slot_key_exact(tier, r, cap, kf.cap_bits) : slot_key_fp64(tier, r, cap);
+      if (G > 1) key[g] |= (uint64_t)comp_of(T.class_of[s]) << kf.comp_shift;  // part-major order
+      comp_rank_base[comp_of(T.class_of[s]) + 1]++;
     }
   }
+  for (uint32_t g = 0; g < G; ++g) comp_rank_base[g + 1] += comp_rank_base[g];
   std::vector<uint32_t> sorted_g(M);
   std::iota(sorted_g.begin(), sorted_g.end(), 0u);
   std::stable_sort(sorted_g.begin(), sorted_g.end(),
@@ -113,30 +119,40 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
 
   // --- matching.
   std::vector<uint32_t> slot_of(N);
-  if (chunk_size == 0 || need_shared) chunk_size = N ? N : 1;
+  if (chunk_size == 0) chunk_size = N ? N : 1;
   const uint32_t K = N ? (N + chunk_size - 1) / chunk_size : 0;
   std::vector<ClassRun> runs(std::max<uint32_t>(C, 1));
-  std::vector<uint32_t> left;
-  SharedIpTable sh{T.ip_sorted.data(), T.ip_servant.data(), S, T.class_of.data(),
-                   base.data(),        S,                   nullptr};
-  if (need_shared) {
-    left.resize(S);
-    for (uint32_t s = 0; s < S; ++s) left[s] = base[s + 1] - base[s];
-    sh.left = left.data();
+  // Hosts that run several servants: `self` is resolved at replay time from the class state
+  // (chunk-parallel like everything else), which needs every servant's last list position.
+  std::vector<uint32_t> pos_last(S, 0);
+  for (uint32_t i = 0; i < M; ++i) {
+    const uint32_t g = list_g[i], s = owner_of_slot(base.data(), S, g);
+    if (g + 1 == base[s + 1]) pos_last[s] = i;
   }
+  SharedIpTable sh{T.ip_sorted.data(), T.ip_servant.data(), S, T.class_of.data(),
+                   base.data(),        S,                   pos_last.data()};
   uint32_t rounds = 0, sims = 0;
   if (K) {
-    // consuming tasks before each chunk
-    std::vector<uint32_t> before(K + 1, 0);
+    // consuming tasks before each chunk, per part of the registry
+    std::vector<uint32_t> before((size_t)(K + 1) * G, 0);
     for (uint32_t k = 0; k < K; ++k) {
-      uint32_t n = 0;
-      for (uint32_t t = k * chunk_size; t < std::min(N, (k + 1) * chunk_size); ++t)
-        n += !task_mask_empty(ti, t);
-      before[k + 1] = before[k] + n;
+      for (uint32_t g = 0; g < G; ++g) before[(size_t)(k + 1) * G + g] = before[(size_t)k * G + g];
+      for (uint32_t t = k * chunk_size; t < std::min(N, (k + 1) * chunk_size); ++t) {
+        if (task_mask_empty(ti, t)) continue;
+        uint32_t c = 0;  // any eligible class names the request's part
+        for (uint32_t w = 0; w < W; ++w)
+          if (tmask[(size_t)t * W + w]) {
+            c = w * 64 + (uint32_t)__builtin_ctzll(tmask[(size_t)t * W + w]);
+            break;
+          }
+        before[(size_t)(k + 1) * G + comp_of(c)]++;
+      }
     }
     std::vector<ClassState> guess((size_t)K * C), endst((size_t)K * C);
     for (uint32_t k = 0; k < K; ++k)
-      for (uint32_t c = 0; c < C; ++c) guess[(size_t)k * C + c] = level_guess(L, c, before[k]);
+      for (uint32_t c = 0; c < C; ++c)
+        guess[(size_t)k * C + c] =
+            level_guess(L, c, comp_rank_base[comp_of(c)] + before[(size_t)k * G + comp_of(c)]);
     std::vector<uint8_t> dirty(K, 1);
     for (;;) {
       ++rounds;
@@ -217,7 +233,8 @@ int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, c
 // how many of its chunks were inconsistent, and finally its per-servant slot deltas.
 // ---------------------------------------------------------------------------
 struct model_shard {
-  uint32_t S = 0, C = 0, N = 0, K = 0, W = 1, chunk = 256;
+  uint32_t S = 0, C = 0, N = 0, K = 0, W = 1, chunk = 256, G = 1;
+  std::vector<uint32_t> cls_comp, comp_rank_base;  // parts of the registry (host_tables.h)
   std::vector<uint32_t> base, running, nproc, load, max_tasks;
   std::vector<uint32_t> cls_begin, list_p, list_g;
   std::vector<uint64_t> tmask;
@@ -227,6 +244,10 @@ struct model_shard {
   ClassLists L{};
   TaskTable ti{};
   uint32_t consuming_total = 0;
+  // hosts that run several servants (run-time `self`)
+  std::vector<uint32_t> ip_sorted, ip_servant, class_of, pos_last;
+  SharedIpTable sh{};
+  bool any_shared = false;
 };
 
 model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_t* nproc,
@@ -238,12 +259,13 @@ model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_
   auto* m = new model_shard();
   HostTables T;
   T.build(S, env_mask, version, max_tasks, nproc, ip_id);
-  if (T.any_shared_ip) {  // not supported by the sharded path (neither is it on the GPU)
-    delete m;
-    return nullptr;
-  }
   const uint32_t C = T.n_classes();
-  KeyFormat kf = choose_key_format(T.cap_bits);
+  uint32_t G = T.n_comp;
+  KeyFormat kf = choose_key_format(T.cap_bits, 11, &G);
+  m->G = G;
+  m->cls_comp.assign(C, 0);
+  if (G > 1) m->cls_comp = T.cls_comp;
+  m->comp_rank_base.assign(G + 1, 0);
   m->S = S;
   m->C = C;
   m->N = N;
@@ -268,7 +290,11 @@ model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_
       uint32_t cap = slot_capacity(nproc[s], load[s], max_tasks[s], r);
       uint32_t tier = slot_tier(nproc[s], flags[s], r);
       key[g] = kf.exact ? slot_key_exact(tier, r, cap, kf.cap_bits) : slot_key_fp64(tier, r, cap);
+      const uint32_t part = m->cls_comp[T.class_of[s]];
+      if (G > 1) key[g] |= (uint64_t)part << kf.comp_shift;
+      m->comp_rank_base[part + 1]++;
     }
+  for (uint32_t g = 0; g < G; ++g) m->comp_rank_base[g + 1] += m->comp_rank_base[g];
   std::vector<uint32_t> sorted_g(M);
   std::iota(sorted_g.begin(), sorted_g.end(), 0u);
   std::stable_sort(sorted_g.begin(), sorted_g.end(),
@@ -304,22 +330,48 @@ model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_
                     &m->tmask[(size_t)t * m->W]);
     uint32_t i = lower_bound_u32(T.ip_sorted.data(), S, requestor_ip[t]);
     if (i < S && T.ip_sorted[i] == requestor_ip[t]) {
-      uint32_t s = T.ip_servant[i];
-      if (m->base[s + 1] > m->base[s]) {
-        m->tself_lo[t] = m->base[s];
-        m->tself_hi[t] = m->base[s + 1];
+      if (i + 1 < S && T.ip_sorted[i + 1] == requestor_ip[t]) {
+        m->tself_lo[t] = i;  // several servants on the host: resolved at replay time
+        m->tself_hi[t] = kSelfShared;
+      } else {
+        uint32_t s = T.ip_servant[i];
+        if (m->base[s + 1] > m->base[s]) {
+          m->tself_lo[t] = m->base[s];
+          m->tself_hi[t] = m->base[s + 1];
+        }
       }
     }
   }
   m->ti = TaskTable{m->tmask.data(), m->tself_lo.data(), m->tself_hi.data(), m->W};
-  m->consuming_before.assign(m->K + 1, 0);
-  for (uint32_t k = 0; k < m->K; ++k) {
-    uint32_t n = 0;
-    for (uint32_t t = k * m->chunk; t < std::min(N, (k + 1) * m->chunk); ++t)
-      n += !task_mask_empty(m->ti, t);
-    m->consuming_before[k + 1] = m->consuming_before[k] + n;
+  m->any_shared = T.any_shared_ip;
+  m->ip_sorted = T.ip_sorted;
+  m->ip_servant = T.ip_servant;
+  m->class_of = T.class_of;
+  m->pos_last.assign(S, 0);
+  for (uint32_t i = 0; i < M; ++i) {
+    const uint32_t g = m->list_g[i], s = owner_of_slot(m->base.data(), S, g);
+    if (g + 1 == m->base[s + 1]) m->pos_last[s] = i;
   }
-  m->consuming_total = m->consuming_before[m->K];
+  m->sh = SharedIpTable{m->ip_sorted.data(), m->ip_servant.data(), S, m->class_of.data(),
+                        m->base.data(),      S,                    m->pos_last.data()};
+  // consuming_before[k * G + g]: requests of part g in the chunks before k (row K: the totals)
+  m->consuming_before.assign((size_t)(m->K + 1) * G, 0);
+  for (uint32_t k = 0; k < m->K; ++k) {
+    for (uint32_t g = 0; g < G; ++g)
+      m->consuming_before[(size_t)(k + 1) * G + g] = m->consuming_before[(size_t)k * G + g];
+    for (uint32_t t = k * m->chunk; t < std::min(N, (k + 1) * m->chunk); ++t) {
+      if (task_mask_empty(m->ti, t)) continue;
+      uint32_t c = 0;
+      for (uint32_t w = 0; w < m->W; ++w)
+        if (m->tmask[(size_t)t * m->W + w]) {
+          c = w * 64 + (uint32_t)__builtin_ctzll(m->tmask[(size_t)t * m->W + w]);
+          break;
+        }
+      m->consuming_before[(size_t)(k + 1) * G + m->cls_comp[c]]++;
+    }
+  }
+  m->consuming_total = 0;
+  for (uint32_t g = 0; g < G; ++g) m->consuming_total += m->consuming_before[(size_t)m->K * G + g];
   m->slot_of.assign(N, kIdxTimeout);
   m->guess0.resize((size_t)m->K * C);
   m->used_start.resize((size_t)m->K * C);
@@ -329,12 +381,17 @@ model_shard* model_shard_open(uint32_t S, const uint32_t* version, const uint32_
 
 uint32_t model_shard_n_classes(const model_shard* m) { return m->C; }
 uint32_t model_shard_consuming(const model_shard* m) { return m->consuming_total; }
+uint32_t model_shard_n_parts(const model_shard* m) { return m->G; }
+// out[g] = consuming requests of part g in this rank's slice (what the ranks all-gather first).
+void model_shard_consuming_parts(const model_shard* m, uint32_t* out) {
+  for (uint32_t g = 0; g < m->G; ++g) out[g] = m->consuming_before[(size_t)m->K * m->G + g];
+}
 
-// One matching pass. base: consuming requests of the ranks before this one (pass 0).
+// One matching pass. base[g]: consuming requests of part g on the ranks before this one (pass 0).
 // boundary_in: end state of the previous rank's last chunk (NULL on rank 0; unused in pass
 // 0). out_end[C]: what this rank publishes. Returns the number of inconsistent chunks
 // (pass 0: the number of chunks).
-uint32_t model_shard_pass(model_shard* m, uint32_t pass, uint32_t base,
+uint32_t model_shard_pass(model_shard* m, uint32_t pass, const uint32_t* base,
                           const ClassState* boundary_in, ClassState* out_end) {
   const uint32_t C = m->C, K = m->K;
   std::vector<ClassRun> runs(std::max<uint32_t>(C, 1));
@@ -344,7 +401,10 @@ uint32_t model_shard_pass(model_shard* m, uint32_t pass, uint32_t base,
     std::vector<ClassState> lvl;
     if (pass == 0) {
       lvl.resize(C);
-      for (uint32_t c = 0; c < C; ++c) lvl[c] = level_guess(m->L, c, base + m->consuming_before[k]);
+      for (uint32_t c = 0; c < C; ++c) {
+        const uint32_t g = m->cls_comp[c];
+        lvl[c] = level_guess(m->L, c, m->comp_rank_base[g] + base[g] + m->consuming_before[(size_t)k * m->G + g]);
+      }
       start = lvl.data();
     } else {
       if (k == 0 && !boundary_in) continue;  // rank 0, chunk 0: started from the true state
@@ -358,7 +418,7 @@ uint32_t model_shard_pass(model_shard* m, uint32_t pass, uint32_t base,
     std::vector<ClassState> st(start, start + C);  // endst[k-1] may be rewritten below? no: k ascending
     for (uint32_t c = 0; c < C; ++c) m->used_start[(size_t)k * C + c] = st[c];
     sim_chunk(m->L, m->ti, k * m->chunk, std::min(m->N, (k + 1) * m->chunk), st.data(),
-              &m->endst[(size_t)k * C], m->slot_of.data(), runs.data(), nullptr);
+              &m->endst[(size_t)k * C], m->slot_of.data(), runs.data(), m->any_shared ? &m->sh : nullptr);
   }
   for (uint32_t c = 0; c < C; ++c) {
     if (K) {

@@ -38,3 +38,17 @@ def test_speculation_converges_quickly():
                                unknown_env_frac=0.001)
     st = _check(sv, tk, 1024)
     assert st.n_chunks == 98 and st.rounds <= 4 and st.chunk_sims <= 2 * st.n_chunks
+
+
+def test_disjoint_partitions_converge_in_two_rounds():
+    """Disjoint environment partitions (independent parts of the registry, host_tables.h): every
+    part is consumed at the rate of its own requests, so level guesses counted per part are
+    exact and the replays agree at once; the global level needed about one round per chunk."""
+    sv, tk = cases.random_case(seed=22, n_tasks=60_000, n_servants=1500, n_envs=4,
+                               disjoint_envs=True, self_frac=0.0)
+    st = _check(sv, tk, 256)
+    assert st.n_chunks == 235 and st.rounds <= 2
+    # with requests from servant hosts (holes) a few more, but nowhere near a round per chunk
+    sv, tk = cases.random_case(seed=23, n_tasks=60_000, n_servants=1500, n_envs=4,
+                               disjoint_envs=True, self_frac=0.2)
+    assert _check(sv, tk, 256).rounds <= 6

@@ -186,8 +186,9 @@ def test_local_ranks_many_classes():
 
 @pytest.mark.parametrize("kind", ["shared_hosts", "many_classes"])
 def test_local_ranks_unsharded_registries(kind):
-    """Registries the sharded matching does not take (hosts with several servants; more than 256
-    classes): every rank places the whole batch redundantly and keeps its slice — same results."""
+    """Hosts with several servants (`self` resolved at replay time, sharded like any other
+    registry) and a registry the sharded matching does not take (more than 256 classes: every
+    rank places the whole batch redundantly and keeps its slice) — same results."""
     if kind == "shared_hosts":
         sv, tk = cases.random_case(seed=64, n_tasks=6000, n_servants=200, n_envs=3,
                                    shared_ip_frac=0.25, self_frac=0.3)

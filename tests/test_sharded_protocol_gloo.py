@@ -29,7 +29,7 @@ def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sv, tk = cases.random_case(**case_kw)
+        sv, tk = cases.random_case(**{k: v for k, v in case_kw.items() if k != "oracle"})
         a = pack.to_abi_columns(sv)
         lo, hi = cuts[rank], cuts[rank + 1]
         t = {k: np.ascontiguousarray(tk[k][lo:hi], dtype=np.uint32)
@@ -46,18 +46,23 @@ def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
         assert h, "model_shard_open failed"
         h = C.c_void_p(h)
         nc = L.model_shard_n_classes(h)
-        # (1) consuming-request counts of the slices -> base of this rank's level guesses
-        mine = torch.tensor([L.model_shard_consuming(h)], dtype=torch.int64)
-        totals = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(totals, mine)
-        base = int(sum(int(x[0]) for x in totals[:rank]))
+        # (1) consuming-request counts of the slices, one per independent part of the registry
+        #     -> base of this rank's level guesses
+        G = L.model_shard_n_parts(h)
+        cnt = np.zeros(G, np.uint32)
+        L.model_shard_consuming_parts(h, p(cnt))
+        totals = [torch.zeros(G, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(totals, torch.from_numpy(cnt.astype(np.int64)))
+        base = np.zeros(G, np.uint32)
+        for x in totals[:rank]:
+            base += x.numpy().astype(np.uint32)
         # (2) passes: publish (end state of the last chunk, busy count), stop when nobody is busy
         bounds = None
         passes = 0
         while True:
             out_end = np.zeros(nc * 4, dtype=np.uint32)
             bin_ = None if (rank == 0 or bounds is None) else p(bounds[rank - 1])
-            busy = L.model_shard_pass(h, C.c_uint32(passes), C.c_uint32(base), bin_, p(out_end))
+            busy = L.model_shard_pass(h, C.c_uint32(passes), p(base), bin_, p(out_end))
             rec = torch.from_numpy(np.concatenate([out_end, np.array([busy], np.uint32)]).astype(np.int64))
             got = [torch.zeros_like(rec) for _ in range(world)]
             dist.all_gather(got, rec)
@@ -82,11 +87,12 @@ def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
         dist.all_gather(allp, mine)
         L.model_shard_close(h)
         if rank == 0:
-            want, _, wrun = O.dispatch(sv, tk, "sorted")
+            want, _, wrun = O.dispatch(sv, tk, case_kw.get("oracle", "sorted"))
             got = np.concatenate([allp[r].numpy()[:sizes[r]] for r in range(world)]).astype(np.uint32)
             ret["placement_ok"] = bool(np.array_equal(got, want))
             ret["running_ok"] = bool(np.array_equal(running.astype(np.uint32), wrun))
             ret["passes"] = passes
+            ret["parts"] = int(G)
             ret["timeouts"] = int((want == O.IDX_TIMEOUT).sum())
     finally:
         dist.destroy_process_group()
@@ -116,3 +122,20 @@ def test_three_ranks_with_an_empty_slice_and_timeouts():
     kw = dict(seed=72, n_tasks=9000, n_servants=120, n_envs=2, oversubscribed=True)
     r = _run(3, kw, [0, 4000, 4000, 9000], chunk=128)
     assert r["timeouts"] > 100
+
+
+def test_two_ranks_hosts_with_several_servants():
+    """`self` for hosts that run several servants is resolved at replay time from the class
+    state, so such registries shard like any other (checked against the literal restatement)."""
+    kw = dict(seed=73, n_tasks=6000, n_servants=160, n_envs=3, shared_ip_frac=0.3, self_frac=0.4,
+              oracle="scan")
+    _run(2, kw, [0, 2500, 6000], chunk=128)
+
+
+def test_two_ranks_disjoint_environment_partitions():
+    """Disjoint environment partitions = independent parts of the registry, each consumed at
+    its own requests' rate: the per-part level guesses are exact, the ranks agree after the
+    first pass (the global level would need about one pass per chunk)."""
+    kw = dict(seed=74, n_tasks=20_000, n_servants=400, n_envs=4, disjoint_envs=True, self_frac=0.0)
+    r = _run(2, kw, [0, 9000, 20_000], chunk=128)
+    assert r["parts"] == 4 and r["passes"] <= 3

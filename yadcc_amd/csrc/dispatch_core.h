@@ -183,9 +183,12 @@ struct ClassState {
   uint32_t cursor, lo, hown_lo, hown_hi;
 };
 
-// Optional run-time resolution of `self` when several servants share a host
-// (`self` = first servant in registry order that is eligible for the task AND
-// still free, :372-379). Only usable when ONE chunk covers the whole batch.
+// Run-time resolution of `self` when several servants share a host (`self` = first
+// servant in registry order that is eligible for the task AND still free, :372-379).
+// "Still free" is read off the class state, so a chunk replayed from any start state
+// resolves it consistently with that state: a servant's slots sit in its class list in
+// ascending order, hence it has an unconsumed slot iff its LAST slot (list position
+// pos_last[s]) is at or after the cursor, or is one of the class's holes.
 struct SharedIpTable {
   const uint32_t* ip;        // ip table sorted by (ip, servant)
   const uint32_t* servant;
@@ -193,8 +196,13 @@ struct SharedIpTable {
   const uint32_t* class_of;  // per servant (kNone: max_tasks == 0)
   const uint32_t* slot_base; // [n_servants + 1]
   uint32_t n_servants;
-  uint32_t* left;            // per servant unconsumed slots (mutable)
+  const uint32_t* pos_last;  // per servant with slots: class-list position of its last slot
 };
+
+YDC_HD bool servant_still_free(uint32_t pos_last, uint32_t first_g, uint32_t cursor, uint32_t lo,
+                               uint32_t hown_lo) {
+  return pos_last >= cursor || (lo < cursor && hown_lo == first_g && pos_last >= lo);
+}
 
 // Live state of one class inside a simulation (one per lane on the GPU).
 struct ClassRun {
@@ -320,20 +328,27 @@ YDC_HD void class_consume(const ClassLists& L, ClassRun& r, uint32_t ci, uint32_
   if (class_consume_state(L, r, ci, self_lo, self_hi)) class_load_head(L, r);
 }
 
-// Resolves `self` for a task whose host runs several servants.
+// Resolves `self` for a task whose host runs several servants. state(c, cursor, lo, hown_lo)
+// hands out the current state of class c (one implementation per caller: ClassRun array on
+// the CPU / thread-per-chunk kernel, lane registers in the wave kernel).
+template <typename StateOf>
 YDC_HD void resolve_shared_self(const uint64_t* mask, uint32_t group_begin,
-                                const SharedIpTable* shared, uint32_t& self_lo,
-                                uint32_t& self_hi) {
+                                const SharedIpTable* shared, const StateOf& state,
+                                uint32_t& self_lo, uint32_t& self_hi) {
   uint32_t i = group_begin;
   uint32_t ip = shared->ip[i];
   self_lo = self_hi = kNone;
   for (; i < shared->n && shared->ip[i] == ip; ++i) {
     uint32_t s = shared->servant[i];
     uint32_t c = shared->class_of[s];
-    if (c == kNone || !((mask[c >> 6] >> (c & 63)) & 1u) || shared->left[s] == 0) continue;
-    if (shared->slot_base[s + 1] == shared->slot_base[s]) continue;
-    self_lo = shared->slot_base[s];
-    self_hi = shared->slot_base[s + 1];
+    if (c == kNone || !((mask[c >> 6] >> (c & 63)) & 1u)) continue;  // not eligible (:324-338)
+    const uint32_t b = shared->slot_base[s], e = shared->slot_base[s + 1];
+    if (e == b) continue;  // offers nothing in this batch
+    uint32_t cursor, lo, hown_lo;
+    state(c, cursor, lo, hown_lo);
+    if (!servant_still_free(shared->pos_last[s], b, cursor, lo, hown_lo)) continue;  // (:350-358)
+    self_lo = b;
+    self_hi = e;
     break;
   }
 }
@@ -355,7 +370,14 @@ YDC_HD void sim_chunk(const ClassLists& L, const TaskTable& T, uint32_t t0, uint
       continue;
     }
     uint32_t self_lo = T.self_lo[t], self_hi = T.self_hi[t];
-    if (self_hi == kSelfShared) resolve_shared_self(mask, self_lo, shared, self_lo, self_hi);
+    if (self_hi == kSelfShared) {
+      auto state = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
+        cursor = runs[c].cursor;
+        lo = runs[c].lo;
+        hown_lo = runs[c].hown_lo;
+      };
+      resolve_shared_self(mask, self_lo, shared, state, self_lo, self_hi);
+    }
     uint32_t best_p = kNone, best_c = kNone, best_i = 0, best_g = 0;
     for (uint32_t w = 0; w < T.words; ++w) {
       for (uint64_t m = mask[w]; m; m &= m - 1) {
@@ -388,7 +410,6 @@ YDC_HD void sim_chunk(const ClassLists& L, const TaskTable& T, uint32_t t0, uint
       continue;
     }
     out_slot[t] = best_g;
-    if (shared) shared->left[owner_of_slot(shared->slot_base, shared->n_servants, best_g)]--;
     class_consume(L, runs[best_c], best_i, self_lo, self_hi);
   }
   for (uint32_t c = 0; c < C; ++c) end[c] = class_run_state(runs[c]);

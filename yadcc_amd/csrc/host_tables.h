@@ -21,6 +21,8 @@
 
 namespace ydc {
 
+constexpr uint32_t kMaxComponents = 16;
+
 struct HostTables {
   std::vector<uint32_t> class_of;   // per servant, kNone when max_tasks == 0
   std::vector<uint64_t> cls_env;    // per class, env_words words each
@@ -37,6 +39,14 @@ struct HostTables {
   // min_version. Empty when not built.
   std::vector<uint32_t> ver_sorted;
   std::vector<uint64_t> env_ver_mask;
+  // Independent parts of the registry: classes are linked when some request could take either
+  // (they share a digest), and a request only ever compares slots of ONE part. cls_comp[c] is
+  // the part of class c (ids below kMaxComponents; several parts may share an id, which is
+  // always exact — ids only group). Slots are ordered part-major (the id rides above the sort
+  // key), and the level guesses count consumed slots per part: with disjoint environment
+  // partitions every part is consumed at its own requests' rate, not at the global one.
+  std::vector<uint32_t> cls_comp;
+  uint32_t n_comp = 1;
   uint32_t cap_bits = 1;            // max over servants of bits(min(max_tasks, nproc))
   uint64_t max_slots = 0;           // sum over servants of min(max_tasks, nproc): bound on slots
 
@@ -104,6 +114,31 @@ struct HostTables {
       ver_sorted.clear();
     }
 
+    // Parts: union-find over the classes through the digests they advertise.
+    {
+      std::vector<uint32_t> parent(C);
+      for (uint32_t c = 0; c < C; ++c) parent[c] = c;
+      auto find = [&](uint32_t x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+      };
+      std::vector<uint32_t> first_with(64 * (size_t)EW, kNone);
+      for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t w = 0; w < EW; ++w)
+          for (uint64_t m = cls_env[(size_t)c * EW + w]; m; m &= m - 1) {
+            const uint32_t bit = w * 64 + (uint32_t)__builtin_ctzll(m);
+            if (first_with[bit] == kNone) first_with[bit] = c;
+            else parent[find(c)] = find(first_with[bit]);
+          }
+      cls_comp.assign(C, 0);
+      std::unordered_map<uint32_t, uint32_t> id_of;
+      for (uint32_t c = 0; c < C; ++c) {
+        auto it = id_of.emplace(find(c), (uint32_t)id_of.size()).first;
+        cls_comp[c] = it->second % kMaxComponents;
+      }
+      n_comp = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)id_of.size(), kMaxComponents));
+    }
+
     std::vector<std::pair<uint32_t, uint32_t>> byip(n);
     for (uint32_t s = 0; s < n; ++s) byip[s] = {ip_id[s], s};
     std::sort(byip.begin(), byip.end());
@@ -124,16 +159,30 @@ struct HostTables {
 struct KeyFormat {
   bool exact;         // slot_key_exact (integer) vs slot_key_fp64
   uint32_t cap_bits;  // only for exact
-  uint32_t key_bits;  // significant bits
+  uint32_t key_bits;  // significant bits, the part id included
   uint32_t passes;    // LSD radix passes
   uint32_t bits_per_pass;
+  uint32_t comp_shift;  // the part id sits at bits [comp_shift, key_bits) (== key_bits: no parts)
 };
 
-inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 11) {
+// n_comp > 1: the part id (HostTables::cls_comp) rides above the slot key. The fp64 key has no
+// room for it: such registries are treated as one part (*n_comp is set to 1).
+inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 11,
+                                   uint32_t* n_comp = nullptr) {
   KeyFormat f;
   f.exact = cap_bits <= kMaxExactCapBits;
   f.cap_bits = cap_bits;
   f.key_bits = f.exact ? 2 * cap_bits + 1 : 64;
+  f.comp_shift = f.key_bits;
+  if (n_comp && *n_comp > 1) {
+    if (f.exact) {
+      uint32_t b = 1;
+      while ((1u << b) < *n_comp) ++b;
+      f.key_bits += b;
+    } else {
+      *n_comp = 1;
+    }
+  }
   f.passes = (f.key_bits + max_radix_bits - 1) / max_radix_bits;
   f.bits_per_pass = (f.key_bits + f.passes - 1) / f.passes;
   return f;

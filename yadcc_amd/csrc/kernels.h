@@ -34,7 +34,7 @@ constexpr int kSortWaves = kSortThreads / 64;
 struct DeviceParams {
   uint32_t n_slots;       // M: free slots of this batch
   uint32_t overflow;      // M exceeded the workspace
-  uint32_t need_shared;   // some task's host runs several servants
+  uint32_t reserved0;     // (was: need_shared)
   uint32_t n_changed[64]; // pass r (index r & 63) changed some chunk's end state: not final yet
   // Sampled count of the end states pass r changed (chunks with index % 16 == 0 only: an
   // estimate at a sixteenth of the same-address atomics), same indexing as the flags.
@@ -117,12 +117,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 // k_servant_scan: ONE workgroup. slot_base[s] = number of free slots of the
 // servants before s; cls_begin[c] = number of slots of the classes before c.
 // ---------------------------------------------------------------------------
+// Registry parts (host_tables.h: classes that no request can choose between are independent):
+// cls_comp[c] = part of class c, n_parts of them (1: cls_comp is not read).
+struct PartTable {
+  const uint32_t* cls_comp;
+  uint32_t n_parts;
+  uint32_t* rank_base;  // [n_parts + 1] slots of the parts before g (k_servant_scan writes it)
+};
+
 __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
                                                        uint32_t max_slots, uint32_t* slot_base,
                                                        uint32_t* cls_begin, uint32_t* chunk_consuming,
-                                                       uint32_t n_chunks, DeviceParams* prm) {
+                                                       uint32_t n_chunks, PartTable parts,
+                                                       DeviceParams* prm) {
   // Per-batch reset of the request-side counters (saves a memset launch).
-  for (uint32_t k = threadIdx.x; k < n_chunks; k += blockDim.x) chunk_consuming[k] = 0;
+  for (uint32_t k = threadIdx.x; k < n_chunks * parts.n_parts; k += blockDim.x) chunk_consuming[k] = 0;
   __shared__ uint32_t lds[17];
   __shared__ uint32_t carry;
   extern __shared__ uint32_t cls_cnt[];  // n_classes + 1
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     slot_base[sv.n] = m;
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
-    prm->need_shared = 0;
+    prm->reserved0 = 0;
     for (int r = 0; r < 64; ++r) prm->n_changed[r] = prm->n_sampled[r] = 0;
     prm->chunk_sims = 0;
     prm->granted = 0;
@@ -179,6 +188,18 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
       acc += cls_cnt[c];
     }
     cls_begin[n_classes] = acc;
+    if (parts.n_parts > 1) {
+      // Slots per part -> first global rank of every part (slots are ordered part-major).
+      uint32_t cnt[16];  // kMaxComponents
+      for (uint32_t g = 0; g < parts.n_parts; ++g) cnt[g] = 0;
+      for (uint32_t c = 0; c < n_classes; ++c) cnt[parts.cls_comp[c]] += cls_cnt[c];
+      uint32_t a2 = 0;
+      for (uint32_t g = 0; g < parts.n_parts; ++g) {
+        parts.rank_base[g] = a2;
+        a2 += cnt[g];
+      }
+      parts.rank_base[parts.n_parts] = a2;
+    }
   }
 }
 
@@ -211,7 +232,9 @@ struct ClassifyArgs {
   uint64_t* mask;
   uint32_t* self_lo;
   uint32_t* self_hi;
-  uint32_t* chunk_consuming;
+  uint32_t* chunk_consuming;  // [chunk * n_parts + part]
+  const uint32_t* cls_comp;   // part of every class (n_parts > 1 only)
+  uint32_t n_parts;
 };
 
 __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
@@ -219,6 +242,7 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   const uint32_t t = block * blockDim.x + threadIdx.x;
   if (t >= a.n_tasks) return;
   uint64_t any = 0;
+  uint32_t first_cls = 0;  // an eligible class (names the request's part of the registry)
   {
     const uint32_t env = a.tk.env_id[t], minv = a.tk.min_version[t];
     if (a.env_ver_mask) {
@@ -229,6 +253,7 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
       for (uint32_t w = 0; w < a.words; ++w) {
         const uint64_t m = env < n_env ? row[w] : 0;
         a.mask[(size_t)t * a.words + w] = m;
+        if (!any && m) first_cls = w * 64 + (uint32_t)__builtin_ctzll(m);
         any |= m;
       }
     } else
@@ -243,6 +268,7 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
         }
       }
       a.mask[(size_t)t * a.words + w] = m;
+      if (!any && m) first_cls = w * 64 + (uint32_t)__builtin_ctzll(m);
       any |= m;
     }
   }
@@ -251,9 +277,8 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   const uint32_t i = lower_bound_u32(a.ip_sorted, a.n_servants, rip);
   if (i < a.n_servants && a.ip_sorted[i] == rip) {
     if (i + 1 < a.n_servants && a.ip_sorted[i + 1] == rip) {
-      lo = i;
+      lo = i;  // several servants on the host: `self` is resolved at replay time
       hi = kSelfShared;
-      if (any) prm->need_shared = 1;  // benign race: everybody writes 1
     } else {
       const uint32_t s = a.ip_servant[i];
       const uint32_t b = a.slot_base[s], e = a.slot_base[s + 1];
@@ -266,39 +291,55 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   a.self_lo[t] = lo;
   a.self_hi[t] = hi;
   // chunk_size is a multiple of 64 and waves start at multiples of 64, so all
-  // lanes of a wave fall into the same chunk: one atomic per wave.
-  const uint64_t consuming = __ballot(any != 0);
-  if (consuming && (threadIdx.x & 63) == __builtin_ctzll(__ballot(true)))
-    atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
+  // lanes of a wave fall into the same chunk: one atomic per wave (and part).
+  uint64_t consuming = __ballot(any != 0);
+  const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(true));
+  if (a.n_parts <= 1) {
+    if (consuming && (threadIdx.x & 63) == leader)
+      atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
+  } else {
+    const uint32_t part = any ? a.cls_comp[first_cls] : 0xFFFFFFFFu;
+    while (consuming) {
+      const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(consuming));
+      const uint64_t same = __ballot(part == g);
+      if ((threadIdx.x & 63) == leader)
+        atomicAdd(&a.chunk_consuming[(size_t)(t / a.chunk_size) * a.n_parts + g], (uint32_t)__popcll(same));
+      consuming &= ~same;
+    }
+  }
 }
 
 // before[k] = number of consuming requests in the chunks before k; before[n_chunks] = their
 // total. ONE workgroup: an extra workgroup of the first histogram launch of the sort (which
 // runs after the classification anyway), or k_chunk_prefix when nothing is sorted.
 struct PrefixArgs {
-  const uint32_t* chunk_consuming;  // NULL: nothing to do
+  const uint32_t* chunk_consuming;  // NULL: nothing to do; [chunk * n_parts + part]
   uint32_t n_chunks;
-  uint32_t* before;
+  uint32_t* before;                 // [(n_chunks + 1) * n_parts], row n_chunks: the totals
+  uint32_t n_parts;
 };
 
 __device__ __forceinline__ void chunk_prefix_block(const PrefixArgs& a, DeviceParams* prm) {
   // Each thread owns a run of consecutive chunks (K is a few thousand at most: the chunk
   // size grows with the batch): independent loads, one block scan, one barrier.
   __shared__ uint32_t lds[17];
+  const uint32_t G = a.n_parts ? a.n_parts : 1;
   const uint32_t per = (a.n_chunks + blockDim.x - 1) / blockDim.x;
   const uint32_t b = min(a.n_chunks, threadIdx.x * per), e = min(a.n_chunks, b + per);
-  uint32_t sum = 0;
-  for (uint32_t k = b; k < e; ++k) sum += a.chunk_consuming[k];
-  uint32_t total;
-  uint32_t acc = block_exclusive_scan(sum, lds, &total);
-  for (uint32_t k = b; k < e; ++k) {
-    a.before[k] = acc;
-    acc += a.chunk_consuming[k];
+  uint32_t all = 0;
+  for (uint32_t g = 0; g < G; ++g) {  // (one part almost always)
+    uint32_t sum = 0;
+    for (uint32_t k = b; k < e; ++k) sum += a.chunk_consuming[(size_t)k * G + g];
+    uint32_t total;
+    uint32_t acc = block_exclusive_scan(sum, lds, &total);
+    for (uint32_t k = b; k < e; ++k) {
+      a.before[(size_t)k * G + g] = acc;
+      acc += a.chunk_consuming[(size_t)k * G + g];
+    }
+    if (threadIdx.x == 0) a.before[(size_t)a.n_chunks * G + g] = total;
+    all += total;
   }
-  if (threadIdx.x == 0) {
-    a.before[a.n_chunks] = total;
-    prm->consuming = total;
-  }
+  if (threadIdx.x == 0) prm->consuming = all;
 }
 
 __global__ __launch_bounds__(1024) void k_chunk_prefix(PrefixArgs a, DeviceParams* prm) {
@@ -320,7 +361,8 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint16_t* cls_by_g, uint32_t* owner,
                                                   uint8_t* consumed, uint32_t gen_blocks,
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
-                                                  uint32_t gbits, uint32_t* hist, ClassifyArgs ca) {
+                                                  uint32_t gbits, uint32_t* hist, ClassifyArgs ca,
+                                                  uint32_t comp_shift) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
@@ -369,8 +411,10 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
     uint32_t tier = slot_tier(nproc, flags, r);
     uint64_t key = exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap);
-    keys[g] = (KeyT)key;
     const uint32_t cls = sv.class_of[s];
+    // Several independent parts: slots are ordered part-major (the id rides above the key).
+    if (ca.n_parts > 1) key |= (uint64_t)ca.cls_comp[cls] << comp_shift;
+    keys[g] = (KeyT)key;
     // The sort's value is the slot; with room above its bits (gbits != 0) the class rides
     // there, so that class digits need no gather (SortIn::gbits).
     vals[g] = gbits ? (cls << gbits) | g : g;
@@ -703,45 +747,49 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
 
 // Thread per (chunk, class): level guess, everything dirty.
 // base (nullable): consuming requests of the ranks before this one (multi-GPU).
+// (per part of the registry: before[k * n_parts + g], base[g], parts.rank_base[g])
 __global__ __launch_bounds__(256) void k_guess_init(ClassLists L, const uint32_t* before,
                                                     uint32_t n_chunks, const uint32_t* base,
-                                                    ClassState* guess, uint8_t* dirty) {
+                                                    PartTable parts, ClassState* guess,
+                                                    uint8_t* dirty) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t C = L.n_classes;
   if (i >= n_chunks * C) return;
   uint32_t k = i / C, c = i - k * C;
-  guess[i] = level_guess(L, c, before[k] + (base ? *base : 0u));
+  const uint32_t G = parts.n_parts, g = G > 1 ? parts.cls_comp[c] : 0u;
+  guess[i] = level_guess(L, c, (G > 1 ? parts.rank_base[g] : 0u) + before[(size_t)k * G + g] +
+                                   (base ? base[g] : 0u));
   if (c == 0) dirty[k] = 1;
 }
 
-// Thread per chunk, any number of classes, optional run-time `self` resolution
-// (then n_chunks must be 1). Slow path: hosts that run several servants, or
-// more than kMaxWaveClasses classes.
+// Thread per chunk, any number of classes (slow path: more than kMaxWaveClasses classes).
 __global__ __launch_bounds__(64) void k_sim_generic(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                     uint32_t chunk_size, uint32_t n_chunks,
                                                     const ClassState* guess, ClassState* endst,
                                                     uint8_t* dirty, uint32_t* slot_of,
                                                     ClassRun* runs, SharedIpTable shared,
-                                                    uint32_t only_if_shared, uint32_t round,
-                                                    DeviceParams* prm) {
-  if (!only_if_shared && blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
-  if (only_if_shared && !prm->need_shared) return;
+                                                    uint32_t round, DeviceParams* prm) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_chunks) return;
   if (!dirty[k]) return;
   const uint32_t C = L.n_classes;
   const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
   sim_chunk(L, T, t0, t1, guess + (size_t)k * C, endst + (size_t)k * C, slot_of,
-            runs + (size_t)k * C, shared.left ? &shared : nullptr);
+            runs + (size_t)k * C, shared.pos_last ? &shared : nullptr);
   dirty[k] = 0;
   atomicAdd(&prm->chunk_sims, 1u);
 }
 
-// left[s] = free slots of servant s (for the run-time `self` rule).
-__global__ __launch_bounds__(256) void k_init_left(const uint32_t* slot_base, uint32_t n,
-                                                   uint32_t* left) {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n) left[s] = slot_base[s + 1] - slot_base[s];
+// pos_last[s] = position in the class lists of servant s's last slot (registries with hosts
+// that run several servants only: SharedIpTable). Thread per list position.
+__global__ __launch_bounds__(256) void k_pos_last(const uint32_t* list_g, const uint32_t* owner,
+                                                  const uint32_t* slot_base, const DeviceParams* prm,
+                                                  uint32_t* pos_last) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= prm->n_slots) return;
+  const uint32_t g = list_g[i], s = owner[g];
+  if (g + 1 == slot_base[s + 1]) pos_last[s] = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -758,7 +806,6 @@ __global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_c
                                                 const ClassState* endst, ClassState* guess,
                                                 uint8_t* dirty, uint32_t round,
                                                 DeviceParams* prm) {
-  if (prm->need_shared) return;  // the whole batch went through the sequential path
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool changed = false;
   if (n_chunks && i < (n_chunks - 1) * n_classes) {
@@ -796,7 +843,7 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
       if (out_idx) out_idx[t] = g;
       if (out_util) out_util[t] = -1.0;
     } else {
-      if (slot_is_rank && !prm->need_shared) g = rank_to_g[g] & g_mask;  // (class bits above)
+      if (slot_is_rank) g = rank_to_g[g] & g_mask;  // (class bits above)
       const uint32_t s = owner[g];
       if (out_idx) out_idx[t] = s;
       if (out_util) {
@@ -876,12 +923,12 @@ __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_i
 // ---------------------------------------------------------------------------
 // Multi-GPU helpers (rank-range sharding of one batch).
 // ---------------------------------------------------------------------------
-// base = consuming requests of the ranks before `rank`.
-__global__ void k_rank_base(const uint32_t* totals, uint32_t rank, uint32_t* base) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+// base[g] = consuming requests of part g on the ranks before `rank` (totals[r * n_parts + g]).
+__global__ void k_rank_base(const uint32_t* totals, uint32_t rank, uint32_t n_parts, uint32_t* base) {
+  if (threadIdx.x < n_parts && blockIdx.x == 0) {
     uint32_t acc = 0;
-    for (uint32_t g = 0; g < rank; ++g) acc += totals[g];
-    *base = acc;
+    for (uint32_t r = 0; r < rank; ++r) acc += totals[(size_t)r * n_parts + threadIdx.x];
+    base[threadIdx.x] = acc;
   }
 }
 // What a rank publishes after a matching pass: the end state of its last chunk (C
@@ -907,7 +954,7 @@ __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const Class
     out[c] = s;
   } else if (c == C) {
     ClassState s;
-    s.cursor = prm->need_shared ? 0u : prm->n_changed[pass & 63];
+    s.cursor = prm->n_changed[pass & 63];
     s.lo = prm->overflow;
     s.hown_lo = s.hown_hi = 0;
     out[C] = s;

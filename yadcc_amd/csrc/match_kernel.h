@@ -55,10 +55,15 @@ constexpr uint32_t kPassSlots = 64;  // DeviceParams::n_changed is indexed by pa
 struct MatchBuffers {
   const ClassState* guess0;  // [K * C] level guesses (start states of pass 0)
   // Non-NULL (<= 64 classes, single GPU): pass 0 works its level guesses out itself from the
-  // prefix of the chunks' consuming counts, and guess0 is not used.
+  // prefix of the chunks' consuming counts, and guess0 is not used. Counts are kept per part
+  // of the registry (kernels.h: PartTable): before[chunk * n_parts + part].
   const uint32_t* before;
-  // Multi-GPU with own guesses: the consuming-request counts of all ranks (gathered); the
-  // guesses of rank base_rank start behind those of the ranks before it. NULL on one GPU.
+  const uint32_t* cls_comp;        // part of every class (n_parts > 1 only)
+  const uint32_t* part_rank_base;  // first global rank of every part (n_parts > 1 only)
+  uint32_t n_parts;
+  // Multi-GPU with own guesses: the consuming-request counts of all ranks (gathered,
+  // [rank * n_parts + part]); the guesses of rank base_rank start behind those of the ranks
+  // before it. NULL on one GPU.
   const uint32_t* base_totals;
   uint32_t base_rank;
   ClassState* endst;         // [K * C] end state of every chunk (in place)
@@ -469,28 +474,36 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
                                                    uint32_t chunk_size, uint32_t n_chunks,
                                                    MatchBuffers B, uint32_t pass,
                                                    uint32_t flags, uint32_t rshift,
-                                                   uint32_t init_fill, DeviceParams* prm) {
+                                                   uint32_t init_fill, SharedIpTable shared,
+                                                   DeviceParams* prm) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
   uint32_t kc = blockIdx.x;  // chunk
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
-  const uint32_t need_shared = prm->need_shared;
   const uint32_t batch_seq = prm->batch_seq;
   const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
   const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
+  // Level of this lane's class before / after the chunk: global rank of the first slot not yet
+  // consumed if consumption followed the slot order of the class's part of the registry.
   uint32_t before0 = 0, before1 = 0;
   if (own_guess && kc < n_chunks) {
-    before0 = B.before[kc];
-    before1 = B.before[kc + 1];
+    const uint32_t G = B.n_parts;
+    const uint32_t part = G > 1 && threadIdx.x < L.n_classes ? B.cls_comp[threadIdx.x] : 0u;
+    before0 = B.before[(size_t)kc * G + part];
+    before1 = B.before[(size_t)(kc + 1) * G + part];
     if (B.base_totals) {
       uint32_t base = 0;
-      for (uint32_t g = 0; g < B.base_rank; ++g) base += B.base_totals[g];
+      for (uint32_t r = 0; r < B.base_rank; ++r) base += B.base_totals[(size_t)r * G + part];
       before0 += base;
       before1 += base;
     }
+    if (G > 1) {
+      const uint32_t first = B.part_rank_base[part];
+      before0 += first;
+      before1 += first;
+    }
   }
-  if (need_shared) return;        // the batch went through the sequential path
   if (prev_changed == 0) return;  // an earlier pass found every chunk consistent
   const uint32_t lane = threadIdx.x;
   if (kc >= n_chunks) return;
@@ -550,9 +563,11 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     if (L.list_p && C <= 4) {
       // A handful of classes: the wave searches together, 64 probes per search and round
       // (three rounds for a list of 2^18 entries instead of eighteen dependent loads), the
-      // 2 * C searches side by side.
-      const uint32_t n0 = before0, n1 = before1;
-      uint32_t lo[8], hi[8];
+      // 2 * C searches side by side (targets: the class's own level, see before0 / before1).
+      uint32_t lo[8], hi[8], tgt[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        tgt[q] = readlane_u32((q & 1) ? before1 : before0, min((uint32_t)q >> 1, C - 1));
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const uint32_t c = (uint32_t)q >> 1;
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (hi[q] > lo[q]) {
-            const uint32_t target = (q & 1) ? n1 : n0;
+            const uint32_t target = tgt[q];
             // Segments wholly below the target form a prefix (the list is sorted).
             const uint32_t k = (uint32_t)__popcll(__ballot(v[q] < target));
             const uint32_t nlo = lo[q] + k * step[q];
@@ -774,6 +789,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
 
       const uint64_t has_self = __ballot(slo != kNone);
+      const uint64_t dyn_self = __ballot(shi == kSelfShared);
       uint32_t res = kIdxTimeout;
       uint32_t keep = 64;  // results of this block to store (fewer after an early stop)
       const uint32_t cnt = min(64u, t1 - tb);
@@ -786,8 +802,27 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 #pragma unroll
         for (int j = 0; j < W; ++j)
           mw[j] = ((uint64_t)readlane_u32(mhi[j], i) << 32) | readlane_u32(mlo[j], i);
-        const uint32_t self_lo = readlane_u32(slo, i);
-        const uint32_t self_hi = readlane_u32(shi, i);
+        uint32_t self_lo = readlane_u32(slo, i);
+        uint32_t self_hi = readlane_u32(shi, i);
+        if (self_hi == kSelfShared) {
+          // Several servants on the requestor's host: `self` = the first of them that is
+          // eligible and still free in the CURRENT state (dispatch_core.h). Wave-uniform.
+          auto state_of = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c & 63u));
+            cursor = lo = hown_lo = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              const uint32_t cur_j = readlane_u32(w.k[j].cursor, l), lo_j = readlane_u32(w.k[j].lo, l),
+                             ho_j = readlane_u32(w.k[j].hown_lo, l);
+              if ((uint32_t)j == (c >> 6)) {
+                cursor = cur_j;
+                lo = lo_j;
+                hown_lo = ho_j;
+              }
+            }
+          };
+          resolve_shared_self(mw, self_lo, &shared, state_of, self_lo, self_hi);
+        }
         uint32_t bp = kNone, bi = 0;
         int bj = 0;
 #pragma unroll
@@ -872,8 +907,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           const uint32_t budget = top_up();
           const uint32_t n = min(lim - i, budget);
           const uint32_t off = ((q.cursor + 1) & w.rmask) << 2;  // ring offset of `next`
-          // Requests that need a look before the plain step.
-          const uint64_t hole_hit = holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull;
+          // Requests that need a look before the plain step: an eligible class has holes, or
+          // the requestor's host runs several servants (`self` is resolved in the general step).
+          const uint64_t hole_hit = (holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull) | dyn_self;
           const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
                                               hole_hit, has_self, res, q.hq, q.nq, q.cursor, off,
                                               base, rmask4, steps,
@@ -920,6 +956,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           }
           if (many_i == 0) continue;
           const bool self = (has_self >> i) & 1;
+          if ((dyn_self >> i) & 1) general = true;
           if (self && !general) {
             const uint32_t self_lo = readlane_u32(slo, i);
             const uint32_t self_len = readlane_u32(shi, i) - self_lo;

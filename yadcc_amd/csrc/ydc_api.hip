@@ -61,6 +61,7 @@ struct BatchPlan {
   TaskTable T{};
   MatchBuffers mb{};
   const uint32_t* rank_to_g = nullptr;  // slots in key order (before the class partition)
+  SharedIpTable shared{};  // pos_last != NULL: some host runs several servants
 };
 }  // namespace
 
@@ -76,6 +77,7 @@ struct ydc_context {
   std::vector<uint32_t> h_version, h_nproc, h_load, h_max_tasks, h_flags, h_ip;
   std::vector<uint64_t> h_env;  // env_words words per servant
   uint32_t env_words = 1;
+  uint32_t n_parts = 1;         // independent parts of the registry (host_tables.h)
   HostTables tables;
   KeyFormat kf{};
   bool tables_dirty = true;
@@ -83,7 +85,7 @@ struct ydc_context {
   // Resident registry.
   DevBuf<uint32_t> d_version, d_nproc, d_load, d_max_tasks, d_running, d_flags, d_class_of;
   DevBuf<uint32_t> d_spare[6];  // ydc_remove_servants compacts into these, then swaps
-  DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted;
+  DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted, d_cls_comp, d_part_base;
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
 
   // Per-batch workspace.
@@ -94,7 +96,7 @@ struct ydc_context {
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
   DevBuf<uint8_t> d_consumed;   // slot taken by a request of this batch
   DevBuf<uint64_t> d_mask;
-  DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_left;
+  DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_running_out;
   DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint, d_early;
   DevBuf<unsigned long long> d_claim;
@@ -225,7 +227,8 @@ int rebuild_tables(ydc_context* c) {
   const uint32_t n = c->n_servants;
   c->tables.build(n, c->h_env.data(), c->h_version.data(), c->h_max_tasks.data(),
                   c->h_nproc.data(), c->h_ip.data(), c->env_words);
-  c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits);
+  c->n_parts = c->tables.n_comp;
+  c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits, &c->n_parts);
   const uint32_t C = c->tables.n_classes();
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
@@ -234,6 +237,12 @@ int rebuild_tables(ydc_context* c) {
   HIP_TRY(c, c->d_cls_env.reserve((size_t)C * c->env_words));
   HIP_TRY(c, c->d_cls_ver.reserve(C));
   HIP_TRY(c, c->d_cls_begin.reserve(C + 1));
+  HIP_TRY(c, c->d_part_base.reserve(kMaxComponents + 1));
+  if (c->n_parts > 1) {
+    HIP_TRY(c, c->d_cls_comp.reserve(C));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cls_comp.p, c->tables.cls_comp.data(), (size_t)C * 4,
+                              hipMemcpyHostToDevice, c->stream));
+  }
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->d_class_of.p, c->tables.class_of.data(), n * 4,
                               hipMemcpyHostToDevice, c->stream));
@@ -273,7 +282,7 @@ int reserve_registry(ydc_context* c, uint32_t n) {
   HIP_TRY(c, c->d_flags.reserve(n));
   HIP_TRY(c, c->d_running_out.reserve(n));
   HIP_TRY(c, c->d_slot_base.reserve((size_t)n + 1));
-  HIP_TRY(c, c->d_left.reserve(n));
+  HIP_TRY(c, c->d_pos_last.reserve(n));
   return YDC_OK;
 }
 
@@ -449,9 +458,10 @@ int ydc_destroy(ydc_context* c) {
   group_release(c);
   for (auto* b : {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
                   &c->d_flags, &c->d_class_of, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
+                  &c->d_cls_comp, &c->d_part_base,
                   &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist,
                   &c->d_row_total, &c->d_self_lo, &c->d_self_hi, &c->d_chunk_consuming,
-                  &c->d_before, &c->d_slot_of, &c->d_left, &c->d_running_out, &c->d_out_idx,
+                  &c->d_before, &c->d_slot_of, &c->d_pos_last, &c->d_running_out, &c->d_out_idx,
                   &c->d_upd_idx})
     b->release();
   for (auto* b : {&c->d_cls_env, &c->d_env_ver_mask, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
@@ -793,8 +803,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   HIP_TRY(c, c->d_self_lo.reserve(N));
   HIP_TRY(c, c->d_self_hi.reserve(N));
   HIP_TRY(c, c->d_slot_of.reserve(N));
-  HIP_TRY(c, c->d_chunk_consuming.reserve((size_t)K + 1));
-  HIP_TRY(c, c->d_before.reserve((size_t)K + 2));
+  HIP_TRY(c, c->d_chunk_consuming.reserve(((size_t)K + 1) * c->n_parts));
+  HIP_TRY(c, c->d_before.reserve(((size_t)K + 2) * c->n_parts));
   HIP_TRY(c, c->d_dirty.reserve((size_t)K + 1));
   HIP_TRY(c, c->d_guess[0].reserve((size_t)K * C + 1));
   HIP_TRY(c, c->d_endst.reserve((size_t)K * C + 1));
@@ -808,7 +818,6 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     }
   }
   if (p.use_generic) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
-  else if (p.any_shared) HIP_TRY(c, c->d_runs.reserve((size_t)C + 1));
 
   p.sv = ServantTable{c->d_version.p, c->d_nproc.p,  c->d_load.p,     c->d_max_tasks.p,
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
@@ -820,16 +829,18 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   p.L.list_p = p.cls_passes || p.fused_cls_bits ? (const uint32_t*)c->d_keys[cur].p : nullptr;
   p.L.list_g = c->d_vals[cur].p;
   p.T = TaskTable{c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p, W};
+  p.shared = SharedIpTable{c->d_ip_sorted.p, c->d_ip_servant.p, p.S, c->d_class_of.p, c->d_slot_base.p,
+                           p.S, p.any_shared ? c->d_pos_last.p : nullptr};
   p.mb = MatchBuffers{};
   if (p.wave_path) {
     p.mb.guess0 = c->d_guess[0].p;
     p.mb.endst = c->d_endst.p;
     p.mb.checkpoint = c->d_checkpoint.p;
-    // <= 64 classes on one GPU, one servant per host: pass 0 computes its level guesses
-    // itself (no k_guess_init; the shared-host path reads the guess array).
-    p.mb.before = p.W == 1 && !p.any_shared && c->group.n_ranks <= 1 && c->opt_own_guess
-                      ? c->d_before.p
-                      : nullptr;
+    // <= 64 classes on one GPU: pass 0 computes its level guesses itself (no k_guess_init).
+    p.mb.before = p.W == 1 && c->group.n_ranks <= 1 && c->opt_own_guess ? c->d_before.p : nullptr;
+    p.mb.cls_comp = c->d_cls_comp.p;
+    p.mb.part_rank_base = c->d_part_base.p;
+    p.mb.n_parts = c->n_parts;
     p.mb.early = c->d_early.p;
     p.mb.claim = c->d_claim.p;
     p.mb.slot_of = c->d_slot_of.p;
@@ -863,7 +874,8 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   mark(c, 0);
   // ---- servant scan (also resets the per-batch device counters)
   YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (C + 1) * sizeof(uint32_t), st,
-             p.sv, C, p.slot_bound, c->d_slot_base.p, c->d_cls_begin.p, c->d_chunk_consuming.p, K, prm);
+             p.sv, C, p.slot_bound, c->d_slot_base.p, c->d_cls_begin.p, c->d_chunk_consuming.p, K,
+             PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, prm);
   mark(c, 1);
   // ---- slot generation
   void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
@@ -879,8 +891,10 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
                       c->tables.env_ver_mask.empty() ? nullptr : c->d_env_ver_mask.p,
                       (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
-                      c->d_chunk_consuming.p};
+                      c->d_chunk_consuming.p, c->d_cls_comp.p, c->n_parts};
   }
+  ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
+  ca.n_parts = c->n_parts;
   // One slot-generating workgroup per sort tile: it leaves the tile's histogram of the first
   // sort pass behind as well (kernels.h).
   const uint32_t bpp0 = c->kf.bits_per_pass;
@@ -893,16 +907,18 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                  st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
                  (uint32_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca);
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca,
+                 c->kf.comp_shift);
     } else {
       YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                  st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
                  (uint64_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca);
+                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca,
+                 c->kf.comp_shift);
     }
   }
   // The chunk prefix of the consuming counts goes with the first histogram launch.
-  PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p};
+  PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, c->n_parts};
   const PrefixArgs* pending_prefix = N ? &pa : nullptr;
   mark(c, 2);
   // ---- sort by key
@@ -955,24 +971,21 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
   hipStream_t st = c->stream;
   if (N && C && !(p.wave_path && p.mb.before && !d_base))
     YDC_LAUNCH(c, "k_guess_init", k_guess_init, dim3(ceil_div(K * C, 256)), dim3(256), 0, st, p.L,
-               c->d_before.p, K, d_base, c->d_guess[0].p, c->d_dirty.p);
+               c->d_before.p, K, d_base, PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p},
+               c->d_guess[0].p, c->d_dirty.p);
   mark(c, 5);
   if (N && C == 0) {
     // No eligible servant at all: every request fails with EnvironmentNotFound
     // (task_dispatcher.cc:105-108).
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_slot_of.p, (int)kIdxEnvNotFound, N, st));
   }
-  if (N && C && p.any_shared) {
-    // Whole batch sequentially, only if some request actually comes from a host with
-    // several servants (decided on the device).
-    SharedIpTable sh{c->d_ip_sorted.p, c->d_ip_servant.p, S, c->d_class_of.p,
-                     c->d_slot_base.p, S, c->d_left.p};
-    YDC_LAUNCH(c, "k_init_left", k_init_left, dim3(ceil_div(std::max(S, 1u), 256)), dim3(256), 0, st,
-               c->d_slot_base.p, S, c->d_left.p);
-    YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(1), dim3(64), 0, st, p.L, p.T, N, N, 1u,
-               c->d_guess[0].p, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p, sh, 1u, 0u,
-               prm);
+  if (N && C && p.any_shared && p.slot_bound) {
+    // Hosts that run several servants: the replays resolve `self` from the class state, which
+    // takes the list position of every servant's last slot (dispatch_core.h: SharedIpTable).
+    YDC_LAUNCH(c, "k_pos_last", k_pos_last, dim3(ceil_div(p.slot_bound, 256)), dim3(256), 0, st,
+               p.L.list_g, c->d_owner.p, c->d_slot_base.p, prm, c->d_pos_last.p);
   }
+  (void)S;
   return YDC_OK;
 }
 
@@ -990,13 +1003,13 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   DeviceParams* prm = c->d_prm.p;
   if (p.W == 1) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
-               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, prm);
+               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
   } else if (p.W == 2) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<2>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
-               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, prm);
+               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
   } else {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<4>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
-               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, prm);
+               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
   }
 }
 
@@ -1033,10 +1046,6 @@ int read_outcome(ydc_context* c, const BatchPlan& p, uint32_t first, uint32_t la
   HIP_TRY(c, hipGetLastError());
   if (c->h_prm->overflow)
     return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
-  if (c->h_prm->need_shared) {  // the sequential path produced the result
-    *rounds = 1;
-    return 1;
-  }
   if (c->h_prm->n_changed[(launched - 1) & 63] != 0) return 0;
   *rounds = launched;
   for (uint32_t r = first; r < launched; ++r)
@@ -1158,13 +1167,12 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   } else {
     if (N && p.C && p.use_generic) {
       // > kMaxWaveClasses classes: thread-per-chunk kernel, host-checked rounds.
-      SharedIpTable no_shared{};
       for (;;) {
         for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
           ClassState* gold = c->d_guess[0].p;
           YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
                      p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
-                     no_shared, 0u, rounds, prm);
+                     p.shared, rounds, prm);
           YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(p.K * p.C, 256))), dim3(256),
                      0, st, p.C, p.K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
           ++rounds;
@@ -1458,11 +1466,10 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   HIP_TRY(c, hipSetDevice(c->device));
   BatchPlan p;
   if (int rc = plan_batch(c, N, &p)) return rc;
-  if (p.use_generic || p.any_shared) {
-    // Registries the sharded matching does not take (> 256 classes, or hosts that run several
-    // servants: both go through sequential paths): every rank gathers the whole batch, places
-    // it redundantly with the single-GPU pipeline — identical on all ranks — and keeps its own
-    // slice of the placement.
+  if (p.use_generic) {
+    // Registries the sharded matching does not take (> 256 classes: thread-per-chunk path):
+    // every rank gathers the whole batch, places it redundantly with the single-GPU pipeline
+    // — identical on all ranks — and keeps its own slice of the placement.
     const uint32_t G = (uint32_t)g.n_ranks;
     HIP_TRY(c, g.d_totals.reserve(G + 1));
     HIP_TRY(c, hipMemcpyAsync(g.d_totals.p + G, &N, 4, hipMemcpyHostToDevice, c->stream));
@@ -1514,8 +1521,9 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   }
   const uint32_t G = (uint32_t)g.n_ranks, C = p.C, S = p.S, K = p.K;
   const size_t rec = (size_t)C + 1;  // ClassStates a rank publishes per pass
-  HIP_TRY(c, g.d_totals.reserve(G));
-  HIP_TRY(c, g.d_base.reserve(1));
+  const uint32_t P = c->n_parts;  // counts are exchanged per independent part of the registry
+  HIP_TRY(c, g.d_totals.reserve((size_t)G * P));
+  HIP_TRY(c, g.d_base.reserve(P));
   HIP_TRY(c, g.d_send.reserve(rec));
   HIP_TRY(c, g.d_bounds.reserve(rec * G));
   HIP_TRY(c, g.d_delta.reserve(S));
@@ -1533,9 +1541,9 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
 
   if (int rc = enqueue_front_a(c, p, tk)) return rc;
-  if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, 4, st));  // before[K == 0] = total = 0
+  if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, (size_t)4 * P, st));  // totals row of K == 0
   // Level guesses count the consuming requests of the ranks before this one.
-  if (int rc = group_all_gather(c, c->d_before.p + K, g.d_totals.p, 4)) return rc;
+  if (int rc = group_all_gather(c, c->d_before.p + (size_t)K * P, g.d_totals.p, (size_t)4 * P)) return rc;
   if (p.wave_path && p.W == 1 && c->opt_own_guess) {
     // Pass 0 works the guesses out itself, from the gathered counts.
     p.mb.before = c->d_before.p;
@@ -1543,7 +1551,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
     p.mb.base_rank = (uint32_t)g.rank;
     if (int rc = enqueue_front_b(c, p, nullptr)) return rc;
   } else {
-    hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, g.d_base.p);
+    hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, P, g.d_base.p);
     if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
   }
   mark(c, 6);
@@ -1831,7 +1839,7 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
   if (c->h_prm->overflow)
     return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
   uint32_t rounds = sm.passes;
-  if (p.wave_path && !c->h_prm->need_shared) {
+  if (p.wave_path) {
     if (c->h_prm->n_changed[(sm.passes - 1) & 63] != 0) {
       // The captured passes were not enough (rare): finish eagerly and capture a longer
       // step next time.
