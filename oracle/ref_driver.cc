@@ -19,6 +19,16 @@ using yadcc::scheduler::TaskDispatcher;
 using yadcc::scheduler::TaskPersonality;
 using yadcc::scheduler::WaitStatus;
 
+// DumpInternals is private in the reference; its header befriends the gtest fixture class
+// SchedulerServiceImpl_TokenWithIntersection_Test (task_dispatcher.h:277 through FRIEND_TEST).
+// The driver lends that name to reach the dump without touching the reference's sources.
+namespace yadcc::scheduler {
+class SchedulerServiceImpl_TokenWithIntersection_Test {
+ public:
+  static std::string Dump(TaskDispatcher* d) { return d->DumpInternals().Dump(); }
+};
+}  // namespace yadcc::scheduler
+
 struct ref_dispatcher {
   TaskDispatcher impl;
   // location -> registry index, valid while no servant has expired.
@@ -217,6 +227,12 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
     d->impl.KeepServantAlive(s, 30s);
     d->index_of.emplace(location, static_cast<std::uint32_t>(d->index_of.size()));
   }
+}
+
+size_t ref_dump_internals(ref_dispatcher* d, char* out, size_t cap) {
+  const std::string j = yadcc::scheduler::SchedulerServiceImpl_TokenWithIntersection_Test::Dump(&d->impl);
+  if (out && cap) std::snprintf(out, cap, "%s", j.c_str());
+  return j.size();
 }
 
 void ref_free_tasks(ref_dispatcher* d, const uint64_t* task_ids, size_t n) {

@@ -83,6 +83,10 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
                             const uint64_t* memory_available, const uint64_t* env_mask,
                             uint32_t env_words, const uint32_t* ip, const uint32_t* port);
 
+/* TaskDispatcher::DumpInternals (task_dispatcher.cc:538-614) as JSON text (object keys sorted,
+ * the way jsoncpp writes them). Returns the length needed; writes at most cap - 1 characters. */
+size_t ref_dump_internals(ref_dispatcher* d, char* out, size_t cap);
+
 /* n x FreeTask (one call across the binding instead of n). */
 void ref_free_tasks(ref_dispatcher* d, const uint64_t* task_ids, size_t n);
 

@@ -52,6 +52,8 @@ def lib():
         L.ref_load_servants_wide.argtypes = ([C.c_void_p, C.c_size_t] + [C.c_void_p] * 9 +
                                              [C.c_uint32] + [C.c_void_p] * 2)
         L.ref_free_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_dump_internals.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.ref_dump_internals.restype = C.c_size_t
         L.ref_dispatch_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.ref_dispatch_batch.restype = C.c_double
         L.ref_digest_name.argtypes = [C.c_uint32, C.c_char_p]
@@ -103,6 +105,14 @@ class RefDispatcher:
 
     def free_task(self, task_id):
         lib().ref_free_task(self._h, task_id)
+
+    def dump_internals(self):
+        """TaskDispatcher::DumpInternals (task_dispatcher.cc:538-614) as a dict."""
+        import json
+        n = lib().ref_dump_internals(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().ref_dump_internals(self._h, buf, n + 1)
+        return json.loads(buf.value.decode())
 
     def free_tasks(self, task_ids):
         a = np.ascontiguousarray(task_ids, dtype=np.uint64)

@@ -25,13 +25,23 @@ enum NotAcceptingTaskReason : int {
   NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED = 100,
 };
 
-inline const std::string& ServantPriority_Name(ServantPriority) {
-  static const std::string s = "SERVANT_PRIORITY";
-  return s;
+// Value names of api/scheduler.proto:39-62 (what protoc's *_Name() return; an unknown
+// number yields the empty string there too).
+inline const std::string& ServantPriority_Name(ServantPriority v) {
+  static const std::string names[] = {"SERVANT_PRIORITY_UNKNOWN", "SERVANT_PRIORITY_DEDICATED",
+                                      "SERVANT_PRIORITY_USER"},
+                           none;
+  return (int)v >= 0 && (int)v <= 2 ? names[(int)v] : none;
 }
-inline const std::string& NotAcceptingTaskReason_Name(NotAcceptingTaskReason) {
-  static const std::string s = "NOT_ACCEPTING_TASK_REASON";
-  return s;
+inline const std::string& NotAcceptingTaskReason_Name(NotAcceptingTaskReason v) {
+  static const std::string names[] = {"NOT_ACCEPTING_TASK_REASON_UNKNOWN",
+                                      "NOT_ACCEPTING_TASK_REASON_USER_INSTRUCTED",
+                                      "NOT_ACCEPTING_TASK_REASON_POOR_MACHINE",
+                                      "NOT_ACCEPTING_TASK_REASON_CGROUPS_PRESENT",
+                                      "NOT_ACCEPTING_TASK_REASON_BEHIND_NAT"},
+                           not_verified = "NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED", none;
+  if ((int)v == 100) return not_verified;
+  return (int)v >= 0 && (int)v <= 4 ? names[(int)v] : none;
 }
 inline bool ServantPriority_IsValid(int v) { return v >= 0 && v <= 2; }
 

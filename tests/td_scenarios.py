@@ -304,6 +304,38 @@ def event_stream_matches_reference(make, seed, n_digests=3, n_pool=60, steps=400
         rst, rid, rloc = ref.wait_for_starting_new_task(ips[k], dg[k], min_version=0)
         assert (int(st[k]), locs[k] or None) == (rst, rloc), (seed, "drain", k)
     dump = td.dump_internals()
+    assert_same_dump(dump, ref.dump_internals())
     ref.close()
     td.close()
     return dump
+
+
+TIME_KEYS = ("discovered_at", "expires_at", "started_at")
+
+
+def assert_same_dump(ours, theirs):
+    """DumpInternals (task_dispatcher.cc:538-614) key for key and value for value against the
+    reference's own dump (written by the recording Json::Value stand-in of oracle/shims).
+    Formatted wall-clock times are left out (the two clocks have different origins); ours has
+    one extra key, "gpu"."""
+    ours = dict(ours)
+    ours.pop("gpu", None)
+
+    def strip(d):
+        return {k: v for k, v in d.items() if k not in TIME_KEYS}
+
+    assert set(ours) == set(theirs) | ({"tasks"} if "tasks" not in theirs else set()) | (
+        {"servants"} if "servants" not in theirs else set())
+    for k in ("servants_up", "running_tasks", "capacity", "capacity_available",
+              "capacity_unavailable"):
+        assert ours[k] == theirs[k], k
+    a, b = ours.get("servants", []), theirs.get("servants") or []
+    assert len(a) == len(b)
+    for x, y in zip(a, b):  # registry order
+        assert set(x) == set(y), (sorted(x), sorted(y))
+        assert strip(x) == strip(y)
+    ta, tb = ours.get("tasks", {}), theirs.get("tasks") or {}
+    assert set(ta) == set(tb)
+    for k in ta:
+        assert set(ta[k]) == set(tb[k])
+        assert strip(ta[k]) == strip(tb[k]), k

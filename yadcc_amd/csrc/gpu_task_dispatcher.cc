@@ -83,7 +83,8 @@ const char* PriorityName(int p) {  // ServantPriority_Name, api/scheduler.proto:
   switch (p) {
     case kServantPriorityDedicated: return "SERVANT_PRIORITY_DEDICATED";
     case kServantPriorityUser: return "SERVANT_PRIORITY_USER";
-    default: return "SERVANT_PRIORITY_UNKNOWN";
+    case kServantPriorityUnknown: return "SERVANT_PRIORITY_UNKNOWN";
+    default: return "";  // (protoc's *_Name() of a number without a name)
   }
 }
 
@@ -94,7 +95,8 @@ const char* ReasonName(int r) {  // NotAcceptingTaskReason_Name, api/scheduler.p
     case 3: return "NOT_ACCEPTING_TASK_REASON_CGROUPS_PRESENT";
     case 4: return "NOT_ACCEPTING_TASK_REASON_BEHIND_NAT";
     case 100: return "NOT_ACCEPTING_TASK_REASON_NOT_VERIFIED";
-    default: return "NOT_ACCEPTING_TASK_REASON_UNKNOWN";
+    case 0: return "NOT_ACCEPTING_TASK_REASON_UNKNOWN";
+    default: return "";
   }
 }
 
