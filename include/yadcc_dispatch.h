@@ -101,6 +101,10 @@ typedef struct ydc_stats {
   uint32_t rounds;         /* speculation rounds until the chunk states were consistent */
   uint32_t chunk_sims;     /* chunk simulations executed over all rounds */
   uint32_t granted, timeouts, env_not_found;
+  /* multi-GPU group, cumulative: batches that ran with a sharded sort (each rank generated and
+   * sorted only its key window) and how many of them had to be repeated with the full sort
+   * because a window turned out too small. */
+  uint32_t shard_sort_batches, shard_sort_misses;
   float stage_ms[16];      /* per-stage GPU time when profiling is on (ydc_set_profiling) */
 } ydc_stats;
 
@@ -209,9 +213,11 @@ int ydc_group_size(ydc_context* ctx, int* out_ranks, int* out_is_rccl);
  * cover the rank's own slice, d_out_running (nullable, n_servants entries) is the global
  * running_tasks after the batch, identical on all ranks; YDC_DISPATCH_COMMIT applies it.
  * Exchanges: all-gathers of 4 B, (n_classes + 1) * 16 B per matching pass, n_servants * 4 B
- * (the per-rank servant-slot deltas) per rank. Registries with more than 256 servant classes or
- * with hosts that run several servants are not sharded: every rank gathers the whole batch and
- * places it redundantly (same results, no speed-up). */
+ * (the per-rank servant-slot deltas) per rank, and — when the slot sort is sharded as well (each
+ * rank generates and sorts only the key window its rank range can reach; integer keys, one
+ * independent part, one servant per host) — n_classes * 8 B (the windows). Registries with more
+ * than 256 servant classes are not sharded: every rank gathers the whole batch and places it
+ * redundantly (same results, no speed-up). */
 int ydc_dispatch_sharded(ydc_context* ctx, const ydc_task_soa* d_tasks_slice, uint32_t n_slice,
                          uint32_t flags, uint32_t* d_out_servant_idx, double* d_out_utilization,
                          uint32_t* d_out_running);

@@ -450,3 +450,38 @@ void model_shard_finalize(const model_shard* m, uint32_t* out_idx, uint32_t* out
 void model_shard_close(model_shard* m) { delete m; }
 
 }  // extern "C"
+
+// first_slot_not_below (dispatch_core.h: the closed-form count behind the key windows of the
+// multi-GPU path) against a linear walk over the servant's slots. Returns the mismatches.
+extern "C" uint32_t model_check_first_slot(uint32_t seed, uint32_t iterations) {
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto rnd = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return (uint32_t)(x >> 16);
+  };
+  uint32_t bad = 0;
+  for (uint32_t it = 0; it < iterations; ++it) {
+    const uint32_t cap_bits = 1 + rnd() % 12, lim = (1u << cap_bits) - 1;
+    const uint32_t nproc = 1 + rnd() % (lim * 2), load = rnd() % (nproc * 5 / 4 + 1);
+    uint32_t mt = rnd() % (lim + 1);
+    const uint32_t top = mt < nproc ? mt : nproc;
+    const uint32_t running = rnd() % (top + 2), flags = rnd() % 4;
+    const uint64_t part = (uint64_t)(rnd() % 3) << (2 * cap_bits + 1);
+    uint64_t K = part | (((uint64_t)rnd() << 16 | rnd()) % (1ull << (2 * cap_bits + 1)));
+    if (rnd() % 10 == 0) K = part;
+    const uint32_t n = servant_slot_count(nproc, load, mt, running, flags);
+    uint32_t want = running + n;
+    for (uint32_t r = running; r < running + n; ++r) {
+      const uint64_t k = part | slot_key_exact(slot_tier(nproc, flags, r), r,
+                                               slot_capacity(nproc, load, mt, r), cap_bits);
+      if (k >= K) {
+        want = r;
+        break;
+      }
+    }
+    bad += first_slot_not_below(nproc, load, mt, running, flags, part, K, cap_bits) != want;
+  }
+  return bad;
+}

@@ -52,3 +52,9 @@ def test_disjoint_partitions_converge_in_two_rounds():
     sv, tk = cases.random_case(seed=23, n_tasks=60_000, n_servants=1500, n_envs=4,
                                disjoint_envs=True, self_frac=0.2)
     assert _check(sv, tk, 256).rounds <= 6
+
+
+def test_closed_form_slot_count_below_a_key():
+    """first_slot_not_below (the per-servant count behind the key windows of the multi-GPU
+    path) against a walk over the servant's slots, 1M random servants / keys."""
+    assert M.lib().model_check_first_slot(7, 1_000_000) == 0

@@ -172,6 +172,41 @@ def test_cfg4_shape_eight_ranks(n_tasks):
     [c.close() for c in ctxs]
 
 
+def test_sort_is_sharded_and_a_missed_window_falls_back(monkeypatch):
+    """every rank generates and sorts only the key window its rank range can
+    reach (stats: shard_sort_batches). A window that turns out too small — here forced with a
+    margin of zero slots on a registry whose classes run far from the global level — is
+    detected on every rank alike and the batch is repeated with the full sort: same results."""
+    sv, tk = cases.random_case(seed=66, n_tasks=120_000, n_servants=2500, n_envs=4,
+                               unknown_env_frac=0.001, self_frac=0.1)
+    n = len(tk["env_id"])
+    cuts = [n * r // 4 for r in range(5)]
+    ctxs = make_group(4, sv)
+    res = sharded_run(ctxs, sv, tk, cuts)
+    check_against_oracle(res, sv, tk)
+    st = [r[3] for r in res]
+    assert all(x["shard_sort_batches"] == 1 and x["shard_sort_misses"] == 0 for x in st), st
+    assert all(x["n_slots"] < 0.7 * sum(y["n_slots"] for y in st) for x in st)  # windows, not all
+    [c.close() for c in ctxs]
+    # the same batch with windows that cannot hold the deviation of the classes
+    monkeypatch.setenv("YDC_SHARD_MARGIN", "0")
+    sv2, tk2 = cases.random_case(seed=67, n_tasks=60_000, n_servants=1500, n_envs=4,
+                                 oversubscribed=True, self_frac=0.1)
+    n2 = len(tk2["env_id"])
+    ctxs = make_group(3, sv2)
+    res = sharded_run(ctxs, sv2, tk2, [0, n2 // 3, 2 * n2 // 3, n2])
+    check_against_oracle(res, sv2, tk2)
+    st = [r[3] for r in res]
+    assert len({(x["shard_sort_batches"], x["shard_sort_misses"]) for x in st}) == 1, st  # same verdict
+    [c.close() for c in ctxs]
+    monkeypatch.setenv("YDC_SHARD_SORT", "0")
+    ctxs = make_group(3, sv2)
+    res = sharded_run(ctxs, sv2, tk2, [0, n2 // 3, 2 * n2 // 3, n2])
+    check_against_oracle(res, sv2, tk2)
+    assert all(r[3]["shard_sort_batches"] == 0 for r in res)
+    [c.close() for c in ctxs]
+
+
 def test_local_ranks_many_classes():
     """> 64 classes (two classes per lane) across 3 ranks."""
     sv, tk = cases.random_case(seed=63, n_tasks=30_000, n_servants=1500, n_envs=7,

@@ -63,7 +63,8 @@ class TaskSoA(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "n_tasks", "n_servants", "n_classes", "n_slots", "key_bits", "radix_passes", "n_chunks",
-        "rounds", "chunk_sims", "granted", "timeouts", "env_not_found")] + [
+        "rounds", "chunk_sims", "granted", "timeouts", "env_not_found", "shard_sort_batches",
+        "shard_sort_misses")] + [
             ("stage_ms", C.c_float * 16)]
 
     def as_dict(self):

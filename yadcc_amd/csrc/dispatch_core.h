@@ -17,6 +17,7 @@
 #ifndef YADCC_AMD_DISPATCH_CORE_H_
 #define YADCC_AMD_DISPATCH_CORE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -94,6 +95,77 @@ YDC_HD uint64_t slot_key_fp64(uint32_t tier, uint32_t r, uint32_t cap) {
 }
 
 YDC_HD double slot_utilization(uint32_t r, uint32_t cap) { return (double)r / (double)cap; }
+
+// Smallest r in [running, top] (top = first r that is not a slot) whose exact key — with the
+// part id `part_key` already shifted into place — is >= K; top if there is none. The key is
+// strictly increasing in r, so this is "how many of the servant's slots sort below K" + running:
+// the closed-form count behind the per-rank key windows of the multi-GPU path.
+// A float estimate (utilisation u = q / 4^b, r ~ u * capacity) lands within a slot or two; the
+// exact integer key decides, so the estimate only costs steps, never correctness.
+YDC_HD uint32_t first_slot_not_below(uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                     uint32_t running, uint32_t flags, uint64_t part_key,
+                                     uint64_t K, uint32_t cap_bits) {
+  const uint32_t n = servant_slot_count(nproc, load, max_tasks, running, flags);
+  if (n == 0) return running;
+  const uint32_t top = running + n;
+  auto key_at = [&](uint32_t r) {
+    return part_key | slot_key_exact(slot_tier(nproc, flags, r), r,
+                                     slot_capacity(nproc, load, max_tasks, r), cap_bits);
+  };
+  if (key_at(running) >= K) return running;
+  if (key_at(top - 1) < K) return top;
+  // Estimate inside the tier the threshold falls into.
+  const uint64_t qmask = (1ull << (2 * cap_bits)) - 1;
+  const float u = (float)(K & qmask) / (float)(qmask + 1);
+  const uint32_t cmin = max_tasks < nproc ? max_tasks : nproc;
+  float est = u * (float)cmin;  // r >= load (or capped by max_tasks): capacity is constant
+  if (load > running) {
+    const float a = (float)(nproc - load);  // r < load: capacity a + r while below max_tasks
+    const float grow = u < 0.999f ? u * a / (1.0f - u) : (float)top;
+    if (grow < (float)load && a + grow < (float)max_tasks) est = grow;
+  }
+  uint32_t r = est <= (float)running ? running : (est >= (float)(top - 1) ? top - 1 : (uint32_t)est);
+  // Tier: all tier-0 slots sort below all tier-1 slots.
+  const uint32_t ktier = (uint32_t)((K & ~part_key) >> (2 * cap_bits)) & 1u;
+  if (slot_tier(nproc, flags, r) != ktier) {
+    // first tier-1 slot of a dedicated servant: r * 2 >= nproc
+    const uint32_t t1 = (nproc + 1) / 2;
+    r = ktier ? (t1 < running ? running : (t1 > top - 1 ? top - 1 : t1))
+              : (t1 == 0 || t1 - 1 < running ? running : (t1 - 1 > top - 1 ? top - 1 : t1 - 1));
+  }
+  // Bracket: key_at(lo) < K <= key_at(hi). Gallop away from the estimate, then bisect.
+  uint32_t lo = running, hi = top - 1;
+  if (r <= lo) r = lo + 1;
+  if (r > hi) r = hi;
+  if (key_at(r) >= K) {
+    hi = r;
+    for (uint32_t step = 1; hi - lo > 1; step *= 2) {
+      const uint32_t probe = hi - lo > step ? hi - step : lo + 1;
+      if (key_at(probe) >= K) {
+        hi = probe;
+      } else {
+        lo = probe;
+        break;
+      }
+    }
+  } else {
+    lo = r;
+    for (uint32_t step = 1; hi - lo > 1; step *= 2) {
+      const uint32_t probe = hi - lo > step ? lo + step : hi - 1;
+      if (key_at(probe) < K) {
+        lo = probe;
+      } else {
+        hi = probe;
+        break;
+      }
+    }
+  }
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (key_at(mid) >= K) hi = mid; else lo = mid;
+  }
+  return hi;
+}
 
 // ---------------------------------------------------------------------------
 // Tasks.

@@ -43,6 +43,12 @@ struct DeviceParams {
   uint32_t granted;       // requests that got a slot (k_running_out)
   uint32_t consuming;     // requests with at least one eligible class (k_chunk_prefix)
   uint32_t batch_seq;     // batches this context has started (never reset)
+  // Multi-GPU with a sharded sort (k_window): this rank only generated the slots of a key
+  // window. rank_offset = slots of the whole registry that sort below the window (global rank
+  // of local position 0; 0 otherwise); window_miss = some rank's window did not cover what its
+  // requests reached (every rank sets it alike; the batch is repeated with the full sort).
+  uint32_t rank_offset;
+  uint32_t window_miss;
 };
 
 struct ServantTable {
@@ -181,6 +187,8 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;
+    prm->rank_offset = 0;
+    prm->window_miss = 0;
     prm->batch_seq += 1;
     uint32_t acc = 0;
     for (uint32_t c = 0; c < n_classes; ++c) {
@@ -362,7 +370,8 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint8_t* consumed, uint32_t gen_blocks,
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
                                                   uint32_t gbits, uint32_t* hist, ClassifyArgs ca,
-                                                  uint32_t comp_shift) {
+                                                  uint32_t comp_shift, const uint32_t* r_first,
+                                                  const uint32_t* gslot_base) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
@@ -404,9 +413,14 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     } else {
       s = owner_of_slot(slot_base, sv.n, g);
     }
-    owner[g] = s;
-    consumed[g] = 0;
-    uint32_t r = sv.running[s] + (g - slot_base[s]);
+    // Key window (multi-GPU, k_window): slot_base is the LOCAL prefix, the servant's first local
+    // slot is r_first[s], and slots are named by their index in the whole registry's
+    // generation order (gslot_base) — the same name on every rank.
+    const uint32_t run0 = sv.running[s];
+    uint32_t r = (r_first ? r_first[s] : run0) + (g - slot_base[s]);
+    const uint32_t gg = gslot_base ? gslot_base[s] + (r - run0) : g;
+    owner[gg] = s;
+    consumed[gg] = 0;
     uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
     uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
     uint32_t tier = slot_tier(nproc, flags, r);
@@ -417,8 +431,8 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     keys[g] = (KeyT)key;
     // The sort's value is the slot; with room above its bits (gbits != 0) the class rides
     // there, so that class digits need no gather (SortIn::gbits).
-    vals[g] = gbits ? (cls << gbits) | g : g;
-    if (cls_by_g) cls_by_g[g] = (uint16_t)cls;
+    vals[g] = gbits ? (cls << gbits) | gg : gg;
+    if (cls_by_g) cls_by_g[gg] = (uint16_t)cls;
     uint32_t d = (uint32_t)key & ((1u << kbits) - 1);
     if (fused0) d |= cls << kbits;
     atomicAdd(&h0[d], 1u);
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, De
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
       const uint32_t i = min(base + j * kSortThreads + threadIdx.x, M - 1);
-      key[j] = in.keys ? in.keys[i] : (KeyT)i;
+      key[j] = in.keys ? in.keys[i] : (KeyT)(i + prm->rank_offset);  // (index == global rank)
       val[j] = in.cls_by_g ? in.vals[i] : 0u;  // (the slot: class digits only)
     }
 #pragma unroll
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     val[j] = 0;
     uint32_t d = 0;
     if (valid) {
-      key[j] = in.keys ? in.keys[i] : (KeyT)i;
+      key[j] = in.keys ? in.keys[i] : (KeyT)(i + prm->rank_offset);
       val[j] = in.vals[i];
       d = sort_digit(in, i, key[j], val[j]);
     }
@@ -738,7 +752,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
       const uint32_t kd = dig[j] & (kradix - 1);
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       const uint32_t grank = kstart[kd] + wkcnt[kd] + krank[j];
-      out_rank[pos] = grank;
+      out_rank[pos] = grank + prm->rank_offset;
       out_vals[pos] = val[j] & in.out_mask;
       rank_to_g[grank] = val[j] & in.out_mask;
     }
@@ -834,8 +848,10 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
                                                   double* out_util, uint8_t* consumed,
                                                   uint32_t check_slot, const DeviceParams* prm,
                                                   uint32_t g_mask) {
-  // Pre-launched behind the matching passes: only runs once they have converged.
+  // Pre-launched behind the matching passes: only runs once they have converged (and, with a
+  // sharded sort, only if every rank's key window covered what its requests reached).
   if (check_slot != kNone && prm->n_changed[check_slot] != 0) return;
+  if (prm->window_miss) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n_tasks) {
     uint32_t g = slot_of[t];
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
       if (out_idx) out_idx[t] = g;
       if (out_util) out_util[t] = -1.0;
     } else {
-      if (slot_is_rank) g = rank_to_g[g] & g_mask;  // (class bits above)
+      if (slot_is_rank) g = rank_to_g[g - prm->rank_offset] & g_mask;  // (class bits above)
       const uint32_t s = owner[g];
       if (out_idx) out_idx[t] = s;
       if (out_util) {
@@ -864,14 +880,20 @@ __global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, co
                                                      uint32_t* running_out, uint32_t* out_a,
                                                      uint32_t* out_b, uint32_t check_slot,
                                                      uint32_t count_all, DeviceParams* prm,
-                                                     uint32_t* taken_out) {
+                                                     uint32_t* taken_out, const uint32_t* win_lo,
+                                                     const uint32_t* win_hi) {
   __shared__ uint32_t lds[17];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t taken = 0;
-  if (s < n_servants && (check_slot == kNone || prm->n_changed[check_slot] == 0)) {
+  if (s < n_servants && (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss) {
     uint32_t lo = slot_base[s], hi = slot_base[s + 1];
     if (count_all) {
-      // One rank of a sharded batch: its requests took a run somewhere inside the range.
+      // One rank of a sharded batch: its requests took a run somewhere inside the range (the
+      // part of it inside the rank's key window, when the sort is sharded as well).
+      if (win_lo) {
+        lo = win_lo[s];
+        hi = win_hi[s];
+      }
       for (uint32_t g = lo; g < hi; ++g) taken += consumed[g];
     } else {
       const uint32_t b = lo;  // first free slot in [lo, hi]
@@ -935,10 +957,12 @@ __global__ void k_rank_base(const uint32_t* totals, uint32_t rank, uint32_t n_pa
 // entries; a rank without requests passes its predecessor's on, rank 0 the state before
 // the first request) followed by one entry whose cursor is the number of chunks the pass
 // found inconsistent.
+// shift (nullable; sharded sort): list positions are local to the rank's key window; what is
+// published is the position in the whole registry's lists, local + shift[c].
 __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const ClassState* endst,
                                                        uint32_t n_chunks, const ClassState* boundary_in,
                                                        const DeviceParams* prm, uint32_t pass,
-                                                       ClassState* out) {
+                                                       ClassState* out, const uint32_t* shift) {
   const uint32_t C = L.n_classes;
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
@@ -951,12 +975,17 @@ __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const Class
       s.cursor = s.lo = L.cls_begin[c];
       s.hown_lo = s.hown_hi = kNone;
     }
+    if (shift) {
+      s.cursor += shift[c];
+      s.lo += shift[c];
+    }
     out[c] = s;
   } else if (c == C) {
     ClassState s;
     s.cursor = prm->n_changed[pass & 63];
     s.lo = prm->overflow;
-    s.hown_lo = s.hown_hi = 0;
+    s.hown_lo = prm->window_miss;  // (sharded sort: this rank's window exceeded its workspace)
+    s.hown_hi = 0;
     out[C] = s;
   }
 }
@@ -979,14 +1008,211 @@ __global__ void k_global_flag(const ClassState* bounds, uint32_t rec, uint32_t n
 // out_a / out_b (nullable): the caller's copy and, when committing, the resident column.
 __global__ __launch_bounds__(256) void k_sum_deltas(const uint32_t* running, const uint32_t* deltas,
                                                     uint32_t n, uint32_t n_ranks, uint32_t* running_out,
-                                                    uint32_t* out_a, uint32_t* out_b) {
+                                                    uint32_t* out_a, uint32_t* out_b,
+                                                    const DeviceParams* prm) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
+  if (prm->window_miss) return;  // the batch is repeated with the full sort: nothing to commit
   uint32_t acc = running[s];
   for (uint32_t g = 0; g < n_ranks; ++g) acc += deltas[(size_t)g * n + s];
   running_out[s] = acc;
   if (out_a) out_a[s] = acc;
   if (out_b) out_b[s] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Sharded sort. Slot keys are a closed form of (servant, running) and strictly
+// increasing per servant, so "how many slots of the registry sort below key K" is a sum of
+// per-servant closed-form counts (first_slot_not_below). Every rank evaluates the same
+// kWindowThresholds - 1 evenly spaced keys (k_key_count), picks the two that bracket the global
+// ranks its own requests can reach — consuming requests of the ranks before it, its own, and a
+// margin on both sides for classes that run ahead of or behind the global level — and
+// generates, sorts and partitions only the slots between them (k_window; k_slot_gen with
+// r_first). Class-list positions are then local to the window; neighbours exchange them as
+// positions in the whole registry's lists (k_pack_boundary / k_boundary_in). A window that did
+// not cover what the requests reached is detected (k_boundary_in) and the batch repeated with
+// the full sort on every rank.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kWindowThresholds = 128;
+
+// cum[j] = slots with key < (j << shift), j = 1 .. kWindowThresholds - 1. One workgroup per j.
+__global__ __launch_bounds__(256) void k_key_count(ServantTable sv, uint32_t cap_bits, uint32_t shift,
+                                                   uint32_t* cum) {
+  __shared__ uint32_t lds[17];
+  const uint32_t j = blockIdx.x + 1;
+  const uint64_t K = (uint64_t)j << shift;
+  uint32_t cnt = 0;
+  for (uint32_t s = threadIdx.x; s < sv.n; s += blockDim.x) {
+    if (sv.class_of[s] == kNone) continue;
+    const uint32_t run = sv.running[s];
+    cnt += first_slot_not_below(sv.nproc[s], sv.load[s], sv.max_tasks[s], run, sv.flags[s], 0, K,
+                                cap_bits) - run;
+  }
+  uint32_t total;
+  (void)block_exclusive_scan(cnt, lds, &total);
+  if (threadIdx.x == 0) cum[j] = total;
+}
+
+struct WindowArgs {
+  const uint32_t* cum;        // k_key_count
+  uint32_t cap_bits, shift;
+  const uint32_t* totals;     // consuming requests of every rank (all-gathered)
+  uint32_t rank, n_ranks, margin;
+  uint32_t max_local;         // workspace / launch bound on the slots of the window
+  const uint32_t* gslot_base; // [S + 1] prefix of the slot counts of the whole registry
+  const uint32_t* cls_begin_glob;  // [C + 1] class lists of the whole registry
+  uint32_t n_classes;
+  // out
+  uint32_t* r_first;          // [S] first `running` value of the servant inside the window
+  uint32_t* lbase;            // [S + 1] local prefix of the slot counts
+  uint32_t* win_lo;           // [S] the window's slots of the servant, as registry-wide slot
+  uint32_t* win_hi;           //     names [win_lo, win_hi)
+  uint32_t* cls_begin;        // [C + 1] local class lists
+  uint32_t* shift_out;        // [C] registry-wide list position = local position + shift
+  uint32_t* winrec;           // [2 C] registry-wide list positions [start, end) the window covers
+};
+
+// ONE workgroup (like k_servant_scan): thresholds, per-servant windows, local prefix, class sizes.
+__global__ __launch_bounds__(1024) void k_window(ServantTable sv, WindowArgs a, DeviceParams* prm) {
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t carry;
+  __shared__ uint64_t k_lo_s, k_hi_s;
+  __shared__ uint32_t hi_is_end;
+  extern __shared__ uint32_t cls_acc[];  // below[C] | len[C]
+  const uint32_t C = a.n_classes;
+  for (uint32_t c = threadIdx.x; c < 2 * C; c += blockDim.x) cls_acc[c] = 0;
+  if (threadIdx.x == 0) {
+    carry = 0;
+    const uint32_t M = prm->n_slots;  // slots of the whole registry (k_servant_scan)
+    uint32_t base = 0;
+    for (uint32_t r = 0; r < a.rank; ++r) base += a.totals[r];
+    const uint32_t n = a.totals[a.rank];
+    const uint32_t want_lo = base > a.margin ? base - a.margin : 0u;
+    const uint64_t want_hi64 = (uint64_t)base + n + a.margin;
+    const uint32_t want_hi = want_hi64 > M ? M : (uint32_t)want_hi64;
+    // Largest threshold with at most want_lo slots below it; smallest with at least want_hi.
+    uint32_t jl = 0, jh = kWindowThresholds;
+    for (uint32_t j = 1; j < kWindowThresholds; ++j) {
+      if (a.cum[j] <= want_lo) jl = j;
+    }
+    for (uint32_t j = kWindowThresholds - 1; j >= 1; --j) {
+      if (a.cum[j] >= want_hi) jh = j;
+    }
+    k_lo_s = (uint64_t)jl << a.shift;
+    k_hi_s = (uint64_t)jh << a.shift;
+    hi_is_end = jh == kWindowThresholds;
+  }
+  __syncthreads();
+  const uint64_t k_lo = k_lo_s, k_hi = k_hi_s;
+  const bool to_end = hi_is_end != 0;
+  uint32_t below_total = 0;
+  for (uint32_t s0 = 0; s0 < sv.n; s0 += blockDim.x) {
+    const uint32_t s = s0 + threadIdx.x;
+    uint32_t len = 0, below = 0, cls = kNone, r0 = 0, run = 0;
+    if (s < sv.n) {
+      cls = sv.class_of[s];
+      run = sv.running[s];
+      r0 = run;
+      if (cls != kNone) {
+        const uint32_t nproc = sv.nproc[s], load = sv.load[s], mt = sv.max_tasks[s], fl = sv.flags[s];
+        const uint32_t top = run + servant_slot_count(nproc, load, mt, run, fl);
+        r0 = k_lo ? first_slot_not_below(nproc, load, mt, run, fl, 0, k_lo, a.cap_bits) : run;
+        const uint32_t r1 = to_end ? top : first_slot_not_below(nproc, load, mt, run, fl, 0, k_hi, a.cap_bits);
+        below = r0 - run;
+        len = r1 - r0;
+      }
+    }
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(len, lds, &total);
+    if (s < sv.n) {
+      a.lbase[s] = carry + ex;
+      a.r_first[s] = r0;
+      a.win_lo[s] = a.gslot_base[s] + below;
+      a.win_hi[s] = a.gslot_base[s] + below + len;
+      if (cls != kNone) {
+        if (below) atomicAdd(&cls_acc[cls], below);
+        if (len) atomicAdd(&cls_acc[C + cls], len);
+      }
+    }
+    below_total += below;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  uint32_t all_below;
+  (void)block_exclusive_scan(below_total, lds, &all_below);
+  if (threadIdx.x == 0) {
+    const uint32_t m = carry;
+    a.lbase[sv.n] = m;
+    if (m > a.max_local) {
+      prm->window_miss = 1;  // (the workspace bound: treated like any other miss)
+      prm->n_slots = 0;
+    } else {
+      prm->n_slots = m;
+    }
+    prm->rank_offset = all_below;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+      a.cls_begin[c] = acc;
+      const uint32_t start = a.cls_begin_glob[c] + cls_acc[c];
+      a.shift_out[c] = start - acc;
+      a.winrec[2 * c] = start;
+      a.winrec[2 * c + 1] = start + cls_acc[C + c];
+      acc += cls_acc[C + c];
+    }
+    a.cls_begin[C] = acc;
+  }
+}
+
+// After the all-gather of a pass's records (k_pack_boundary), sharded sort: the global "some
+// rank changed an end state" flag (like k_global_flag), the predecessor's end state translated
+// into this rank's local list positions, and the check that every rank's window covered what
+// its requests reached — evaluated for ALL ranks from the gathered windows, so every rank
+// comes to the same verdict: a predecessor's state outside the window, or a class consumed up
+// to the window's end while the registry's list goes on. Thread per class.
+__global__ __launch_bounds__(256) void k_boundary_in(const ClassState* bounds, uint32_t rec,
+                                                     uint32_t n_classes, uint32_t n_ranks,
+                                                     uint32_t rank, uint32_t pass,
+                                                     const uint32_t* winall,  // [rank][2 C]
+                                                     const uint32_t* cls_begin_glob,
+                                                     const uint32_t* totals, const uint32_t* shift,
+                                                     ClassState* boundary_local, DeviceParams* prm) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) {
+    uint32_t any = 0, over = 0, wmiss = 0;
+    for (uint32_t g = 0; g < n_ranks; ++g) {
+      any |= bounds[(size_t)g * rec + n_classes].cursor;
+      over |= bounds[(size_t)g * rec + n_classes].lo;
+      wmiss |= bounds[(size_t)g * rec + n_classes].hown_lo;
+    }
+    prm->n_changed[pass & 63] = any ? 1u : 0u;
+    if (over) prm->overflow = 1;
+    if (wmiss) prm->window_miss = 1;
+  }
+  if (c >= n_classes) return;
+  // The verdict on the windows is taken on final states only (a pass in which no rank changed
+  // anything): speculative replays may run off a window without any consequence.
+  uint32_t changed = 0;
+  for (uint32_t g = 0; g < n_ranks; ++g) changed |= bounds[(size_t)g * rec + n_classes].cursor;
+  bool miss = false;
+  for (uint32_t g = 0; g < n_ranks && !changed; ++g) {
+    if (totals[g] == 0) continue;  // consumes nothing: passes its predecessor's state on
+    const uint32_t w0 = winall[(size_t)g * 2 * n_classes + 2 * c];
+    const uint32_t w1 = winall[(size_t)g * 2 * n_classes + 2 * c + 1];
+    if (g > 0) {
+      const ClassState st = bounds[(size_t)(g - 1) * rec + c];
+      miss |= st.lo < w0 || st.cursor > w1 || st.lo > st.cursor;
+    }
+    const ClassState en = bounds[(size_t)g * rec + c];
+    miss |= en.cursor >= w1 && w1 < cls_begin_glob[c + 1];
+  }
+  if (miss) prm->window_miss = 1;  // (benign race: everybody writes 1)
+  if (rank > 0) {
+    ClassState st = bounds[(size_t)(rank - 1) * rec + c];
+    st.cursor -= shift[c];
+    st.lo -= shift[c];
+    boundary_local[c] = st;
+  }
 }
 
 // Heartbeats of known servants (KeepServantAlive replaces the personality and keeps

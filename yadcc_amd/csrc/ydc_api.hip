@@ -55,7 +55,9 @@ struct BatchPlan {
   uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
   uint32_t fused_cls_bits = 0;  // class partition folded into the last key pass (kernels.h)
   uint32_t gbits = 0;  // != 0: the sort's values carry the class above gbits slot bits (SortIn)
+  uint32_t slot_bound_glob = 0, win_margin = 0;  // (sharded sort: slot_bound is the window's)
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
+  bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
   ServantTable sv{};
   ClassLists L{};
   TaskTable T{};
@@ -114,6 +116,13 @@ struct ydc_context {
     decltype(&ncclGetErrorString) error_string_fn = nullptr;
     LocalHub* hub = nullptr;
     DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
+    // Sharded sort (k_window): key-count table, per-servant windows, local prefix, class lists
+    // of the whole registry, local -> registry-wide list position shifts, the ranks' windows.
+    DevBuf<uint32_t> d_cum, d_r_first, d_lbase, d_win_lo, d_win_hi, d_cls_begin_glob, d_shift,
+        d_winrec, d_winall;
+    DevBuf<ClassState> d_bound_local;
+    uint32_t margin_scale = 1;  // doubled after a batch whose window missed
+    uint64_t windowed_batches = 0, window_misses = 0;
     DevBuf<uint32_t> d_pad, d_gather, d_all[3], d_all_idx;  // replicated fallback (whole batch)
     DevBuf<double> d_all_util;
     DevBuf<ClassState> d_send, d_bounds;
@@ -179,6 +188,8 @@ struct ydc_context {
   bool opt_own_guess = true;
   bool opt_pair = true;
   bool opt_packed_class = true;
+  bool opt_shard_sort = true;
+  int64_t opt_shard_margin = -1;  // >= 0: margin of the key windows in slots (tests)
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
@@ -444,6 +455,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
   if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
+  if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -750,7 +763,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   if (slot_bound64 > 0xFFFFFFF0ull || (c->max_slots && slot_bound64 > c->max_slots))
     return fail(c, YDC_ERR_CAPACITY, "registry can offer %llu slots > max_slots %u",
                 (unsigned long long)slot_bound64, c->max_slots);
-  p.slot_bound = (uint32_t)slot_bound64;
+  p.slot_bound = p.slot_bound_glob = (uint32_t)slot_bound64;
   // Sort tiles: 256 threads x `items` elements; fewer elements per thread while that still
   // leaves the chip short of workgroups (the passes are latency-bound at this size).
   p.sort_items = p.slot_bound <= 300000 ? 2 : (p.slot_bound <= 700000 ? 4 : 8);
@@ -865,26 +878,30 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   return YDC_OK;
 }
 
-// Everything before the level guesses: slots, sort, class lists, request classification.
-int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
-  const uint32_t N = p.N, S = p.S, C = p.C, K = p.K, W = p.W, cs = p.cs;
-  DeviceParams* prm = c->d_prm.p;
-  hipStream_t st = c->stream;
+// ---- the pieces of the front: servant scan | slot generation (+ request classification) |
+// sort + class lists. enqueue_front_a strings them together; the multi-GPU path with a sharded
+// sort puts its key-window selection between them (enqueue_front_windowed).
+
+// Servant scan (also resets the per-batch device counters). cls_begin: where the class sizes
+// of the whole registry go.
+void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
   c->ksamples_used = 0;
   mark(c, 0);
-  // ---- servant scan (also resets the per-batch device counters)
-  YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (C + 1) * sizeof(uint32_t), st,
-             p.sv, C, p.slot_bound, c->d_slot_base.p, c->d_cls_begin.p, c->d_chunk_consuming.p, K,
-             PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, prm);
+  YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (p.C + 1) * sizeof(uint32_t),
+             c->stream, p.sv, p.C, p.slot_bound_glob, c->d_slot_base.p, cls_begin,
+             c->d_chunk_consuming.p, p.K, PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p},
+             c->d_prm.p);
   mark(c, 1);
-  // ---- slot generation
-  void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
-  uint32_t* vals[2] = {c->d_vals[0].p, c->d_vals[1].p};
-  int cur = 0;
-  // The request classification (class masks, own-servant ranges, consuming counts per chunk)
-  // rides in the same launch: workgroups [gen_blocks, gen_blocks + cls_blocks).
+}
+
+// Slot generation (one workgroup per sort tile: it leaves the tile's histogram of the first
+// sort pass behind as well, kernels.h) and / or the request classification (class masks,
+// own-servant ranges, consuming counts per chunk), which rides in the same launch as
+// workgroups [gen_blocks, gen_blocks + cls_blocks).
+void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, bool gen, bool classify) {
+  const uint32_t N = p.N, S = p.S, C = p.C, W = p.W, cs = p.cs;
   ClassifyArgs ca{};
-  if (N) {
+  if (N && classify) {
     ca = ClassifyArgs{TaskColumns{tk->env_id, tk->min_version, tk->requestor_ip}, N,
                       c->d_cls_env.p, c->d_cls_ver.p, C, W, c->env_words,
                       c->tables.env_ver_mask.empty() ? nullptr : c->d_ver_sorted.p,
@@ -895,31 +912,42 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   }
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
-  // One slot-generating workgroup per sort tile: it leaves the tile's histogram of the first
-  // sort pass behind as well (kernels.h).
   const uint32_t bpp0 = c->kf.bits_per_pass;
   const uint32_t fused0 = p.key_passes == 1 ? p.fused_cls_bits : 0;
   const uint32_t bits0 = std::min(bpp0, c->kf.key_bits) + fused0;
-  const uint32_t gen_blocks = p.slot_bound ? p.n_tiles : 0, cls_blocks = ceil_div(N, 256);
-  if (gen_blocks + cls_blocks) {
-    const size_t lds0 = ((size_t)4 << bits0);
-    if (p.key32) {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
-                 st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
-                 (uint32_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca,
-                 c->kf.comp_shift);
-    } else {
-      YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
-                 st, p.sv, c->d_slot_base.p, prm, (uint32_t)c->kf.exact, c->kf.cap_bits,
-                 (uint64_t*)keys[0], vals[0], C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr, c->d_owner.p,
-                 c->d_consumed.p, gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca,
-                 c->kf.comp_shift);
-    }
+  const uint32_t gen_blocks = gen && p.slot_bound ? p.n_tiles : 0;
+  const uint32_t cls_blocks = classify ? ceil_div(N, 256) : 0;
+  if (gen_blocks + cls_blocks == 0) return;
+  const size_t lds0 = ((size_t)4 << bits0);
+  // Key window (sharded sort): local prefix, first local slot and registry-wide names.
+  const uint32_t* base = p.win ? c->group.d_lbase.p : c->d_slot_base.p;
+  const uint32_t* r_first = p.win ? c->group.d_r_first.p : nullptr;
+  const uint32_t* gbase = p.win ? c->d_slot_base.p : nullptr;
+  uint16_t* cls_by_g = C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr;
+  if (p.key32) {
+    YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+               c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
+               (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p, c->d_consumed.p,
+               gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
+               r_first, gbase);
+  } else {
+    YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+               c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
+               (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p, c->d_consumed.p,
+               gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
+               r_first, gbase);
   }
-  // The chunk prefix of the consuming counts goes with the first histogram launch.
+}
+
+// Sort by key + class lists. prefix_pending: the chunk prefix of the consuming counts still
+// has to be computed — it goes with the first histogram launch (one more workgroup).
+int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
+  const uint32_t N = p.N, K = p.K;
+  void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
+  uint32_t* vals[2] = {c->d_vals[0].p, c->d_vals[1].p};
+  int cur = 0;
   PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, c->n_parts};
-  const PrefixArgs* pending_prefix = N ? &pa : nullptr;
+  const PrefixArgs* pending_prefix = N && prefix_pending ? &pa : nullptr;
   mark(c, 2);
   // ---- sort by key
   const uint32_t g_mask = p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu;  // strips the class again
@@ -959,8 +987,15 @@ int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) 
   mark(c, 4);
   // Nothing was sorted (no free slot anywhere): the prefix gets a launch of its own.
   if (pending_prefix)
-    YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, pa, prm);
+    YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, c->stream, pa, c->d_prm.p);
   return YDC_OK;
+}
+
+// Everything before the level guesses: slots, sort, class lists, request classification.
+int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
+  enqueue_scan(c, p, c->d_cls_begin.p);
+  enqueue_gen(c, p, tk, true, true);
+  return enqueue_sort(c, p, true);
 }
 
 // Level guesses of the chunks' start states (base: consuming requests of earlier ranks,
@@ -1032,7 +1067,8 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
     YDC_LAUNCH(c, "k_running_out", k_running_out, dim3(ceil_div(S, 256)), dim3(256), 0, st,
                c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p,
                d_out_running, (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr, check_slot,
-               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p, d_taken);
+               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p, d_taken,
+               p.win ? c->group.d_win_lo.p : nullptr, p.win ? c->group.d_win_hi.p : nullptr);
   }
   return YDC_OK;
 }
@@ -1071,6 +1107,8 @@ void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   // Every request is exactly one of: granted, Timeout (eligible classes exist but are full),
   // EnvironmentNotFound (no eligible class).
   s.granted = c->h_prm->granted;
+  s.shard_sort_batches = (uint32_t)c->group.windowed_batches;
+  s.shard_sort_misses = (uint32_t)c->group.window_misses;
   s.env_not_found = p.N - std::min(p.N, c->h_prm->consuming);
   s.timeouts = p.N - s.env_not_found - std::min(p.N - s.env_not_found, s.granted);
 }
@@ -1329,8 +1367,11 @@ void group_release(ydc_context* c) {
     g.hub = nullptr;
   }
   for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas, &g.d_pad, &g.d_gather,
-                  &g.d_all[0], &g.d_all[1], &g.d_all[2], &g.d_all_idx})
+                  &g.d_all[0], &g.d_all[1], &g.d_all[2], &g.d_all_idx, &g.d_cum, &g.d_r_first,
+                  &g.d_lbase, &g.d_win_lo, &g.d_win_hi, &g.d_cls_begin_glob, &g.d_shift, &g.d_winrec,
+                  &g.d_winall})
     b->release();
+  g.d_bound_local.release();
   g.d_all_util.release();
   g.d_send.release();
   g.d_bounds.release();
@@ -1536,76 +1577,161 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   }
   hipStream_t st = c->stream;
   DeviceParams* prm = c->d_prm.p;
-  // The chunks of this rank continue the previous rank's.
-  p.mb.boundary_in = g.rank > 0 ? g.d_bounds.p + (size_t)(g.rank - 1) * rec : nullptr;
   p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
 
-  if (int rc = enqueue_front_a(c, p, tk)) return rc;
-  if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, (size_t)4 * P, st));  // totals row of K == 0
-  // Level guesses count the consuming requests of the ranks before this one.
-  if (int rc = group_all_gather(c, c->d_before.p + (size_t)K * P, g.d_totals.p, (size_t)4 * P)) return rc;
-  if (p.wave_path && p.W == 1 && c->opt_own_guess) {
-    // Pass 0 works the guesses out itself, from the gathered counts.
-    p.mb.before = c->d_before.p;
-    p.mb.base_totals = g.d_totals.p;
-    p.mb.base_rank = (uint32_t)g.rank;
-    if (int rc = enqueue_front_b(c, p, nullptr)) return rc;
-  } else {
-    hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, P, g.d_base.p);
-    if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
-  }
-  mark(c, 6);
-
-  // Matching passes, pre-launched in groups like on one GPU: after every pass the ranks
-  // all-gather (end state of the last chunk, "changed an end state" flag); k_global_flag turns
-  // the flags into one global flag per pass, which gates the following passes on every rank
-  // alike. The host looks at the outcome once per group.
-  uint32_t launched = 0, rounds = 0;
+  // Sharded sort (kernels.h: k_key_count / k_window): this rank generates and
+  // sorts only the key window its rank range can reach. Taken for integer keys, one part, a
+  // servant per host, 2 .. 256 classes; anything else — and any batch whose window turns out
+  // too small (window_miss, the same verdict on every rank) — runs with the full sort on
+  // every rank. YDC_SHARD_SORT=0 switches it off.
+  // (Decided from the registry alone — every rank must take the same branch, whatever its slice.)
+  bool windowed = G > 1 && c->opt_shard_sort && c->kf.exact && P == 1 && !p.use_generic && C >= 2 &&
+                  !p.any_shared;
+  const BatchPlan full_plan = p;
+  uint32_t rounds = 0;
   for (;;) {
-    const uint32_t group = launched == 0 ? std::max(2u, std::min(g.pass_hint, 12u)) : 3u;
-    for (uint32_t r = launched; r < launched + group; ++r) {
-      if (launched) {
-        HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
-        HIP_TRY(c, hipMemsetAsync(&prm->n_sampled[r & 63], 0, 4, st));
+    p = full_plan;
+    if (windowed) {
+      // Slots of the window: this rank's requests + a margin on both sides (classes run ahead
+      // of or behind the global level) + the granularity of the thresholds.
+      const uint64_t margin = c->opt_shard_margin >= 0
+                                  ? (uint64_t)c->opt_shard_margin
+                                  : (uint64_t)g.margin_scale * std::max<uint64_t>(N / 8, 8192);
+      const uint64_t bound = std::min<uint64_t>(
+          full_plan.slot_bound, (uint64_t)N + 2 * margin + full_plan.slot_bound / 8 + 65536);
+      p.win = true;
+      p.win_margin = (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu);
+      p.slot_bound = (uint32_t)bound;
+      p.sort_items = p.slot_bound <= 300000 ? 2 : (p.slot_bound <= 700000 ? 4 : 8);
+      p.n_tiles = std::max<uint32_t>(1, ceil_div(p.slot_bound, kSortThreads * p.sort_items));
+      HIP_TRY(c, g.d_cum.reserve(kWindowThresholds + 1));
+      HIP_TRY(c, g.d_r_first.reserve(S));
+      HIP_TRY(c, g.d_lbase.reserve((size_t)S + 1));
+      HIP_TRY(c, g.d_win_lo.reserve(S));
+      HIP_TRY(c, g.d_win_hi.reserve(S));
+      HIP_TRY(c, g.d_cls_begin_glob.reserve((size_t)C + 1));
+      HIP_TRY(c, g.d_shift.reserve(C));
+      HIP_TRY(c, g.d_winrec.reserve((size_t)2 * C));
+      HIP_TRY(c, g.d_winall.reserve((size_t)2 * C * G));
+      HIP_TRY(c, g.d_bound_local.reserve(C));
+      ++g.windowed_batches;
+    }
+    // The chunks of this rank continue the previous rank's (sharded sort: the predecessor's
+    // state comes translated into this rank's local list positions, k_boundary_in).
+    p.mb.boundary_in = g.rank == 0 ? nullptr
+                       : windowed  ? g.d_bound_local.p
+                                   : g.d_bounds.p + (size_t)(g.rank - 1) * rec;
+
+    if (!windowed) {
+      if (int rc = enqueue_front_a(c, p, tk)) return rc;
+    } else {
+      enqueue_scan(c, p, g.d_cls_begin_glob.p);
+      enqueue_gen(c, p, tk, false, true);  // classification only
+      if (N) {
+        PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, P};
+        YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, pa, prm);
       }
-      if (p.wave_path) enqueue_pass(c, p, r, 1u);
-      hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
-                         c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, r, g.d_send.p);
-      if (int rc = group_all_gather(c, g.d_send.p, g.d_bounds.p, rec * sizeof(ClassState))) return rc;
-      hipLaunchKernelGGL(k_global_flag, dim3(1), dim3(64), 0, st, g.d_bounds.p, (uint32_t)rec, C, G, r,
-                         prm);
     }
-    const uint32_t first = launched;
-    launched += group;
-    // The tail behind the group, gated on the device by the last pass's global flag (the same
-    // on every rank): placement of this rank's slice, then the global running_tasks from
-    // everybody's slot deltas. Not converged yet: the deltas are zero and nothing changes.
-    if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, (launched - 1) & 63,
-                                  g.d_delta.p))
-      return rc;
-    if (S) {
-      if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
-      hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
-                         g.d_deltas.p, S, G, c->d_running_out.p, d_out_running,
-                         (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr);
+    if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, (size_t)4 * P, st));  // totals row of K == 0
+    // Level guesses count the consuming requests of the ranks before this one.
+    if (int rc = group_all_gather(c, c->d_before.p + (size_t)K * P, g.d_totals.p, (size_t)4 * P)) return rc;
+    if (windowed) {
+      const uint32_t log_t = 7;  // kWindowThresholds == 128
+      static_assert(kWindowThresholds == 128, "threshold shift");
+      const uint32_t shift = c->kf.key_bits > log_t ? c->kf.key_bits - log_t : 0;
+      YDC_LAUNCH(c, "k_key_count", k_key_count, dim3(kWindowThresholds - 1), dim3(256), 0, st, p.sv,
+                 c->kf.cap_bits, shift, g.d_cum.p);
+      WindowArgs wa{g.d_cum.p, c->kf.cap_bits, shift, g.d_totals.p, (uint32_t)g.rank, G, p.win_margin,
+                    p.slot_bound, c->d_slot_base.p, g.d_cls_begin_glob.p, C, g.d_r_first.p,
+                    g.d_lbase.p, g.d_win_lo.p, g.d_win_hi.p, c->d_cls_begin.p, g.d_shift.p,
+                    g.d_winrec.p};
+      YDC_LAUNCH(c, "k_window", k_window, dim3(1), dim3(1024), (size_t)2 * C * 4, st, p.sv, wa, prm);
+      if (int rc = group_all_gather(c, g.d_winrec.p, g.d_winall.p, (size_t)2 * C * 4)) return rc;
+      enqueue_gen(c, p, tk, true, false);  // the window's slots
+      if (int rc = enqueue_sort(c, p, false)) return rc;
     }
-    mark(c, 7);
-    HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    HIP_TRY(c, hipGetLastError());
-    if (c->h_prm->overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
-    if (c->h_prm->n_changed[(launched - 1) & 63] == 0) {
-      rounds = launched;
-      for (uint32_t r = first; r < launched; ++r)
-        if (c->h_prm->n_changed[r & 63] == 0) {
-          rounds = r + 1;  // first pass in which no rank changed anything
-          break;
+    if (p.wave_path && p.W == 1 && c->opt_own_guess) {
+      // Pass 0 works the guesses out itself, from the gathered counts.
+      p.mb.before = c->d_before.p;
+      p.mb.base_totals = g.d_totals.p;
+      p.mb.base_rank = (uint32_t)g.rank;
+      if (int rc = enqueue_front_b(c, p, nullptr)) return rc;
+    } else {
+      hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, P, g.d_base.p);
+      if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
+    }
+    mark(c, 6);
+
+    // Matching passes, pre-launched in groups like on one GPU: after every pass the ranks
+    // all-gather (end state of the last chunk, "changed an end state" flag); k_global_flag /
+    // k_boundary_in turn the flags into one global flag per pass, which gates the following
+    // passes on every rank alike. The host looks at the outcome once per group.
+    uint32_t launched = 0;
+    bool miss = false;
+    for (;;) {
+      const uint32_t group = launched == 0 ? std::max(2u, std::min(g.pass_hint, 12u)) : 3u;
+      for (uint32_t r = launched; r < launched + group; ++r) {
+        if (launched) {
+          HIP_TRY(c, hipMemsetAsync(&prm->n_changed[r & 63], 0, 4, st));
+          HIP_TRY(c, hipMemsetAsync(&prm->n_sampled[r & 63], 0, 4, st));
         }
-      g.pass_hint = rounds;
-      break;
+        if (p.wave_path) enqueue_pass(c, p, r, 1u);
+        hipLaunchKernelGGL(k_pack_boundary, dim3(ceil_div((uint32_t)rec, 256)), dim3(256), 0, st, p.L,
+                           c->d_endst.p, p.wave_path ? K : 0u, p.mb.boundary_in, prm, r, g.d_send.p,
+                           windowed ? g.d_shift.p : nullptr);
+        if (int rc = group_all_gather(c, g.d_send.p, g.d_bounds.p, rec * sizeof(ClassState))) return rc;
+        if (windowed) {
+          hipLaunchKernelGGL(k_boundary_in, dim3(ceil_div(C, 256)), dim3(256), 0, st, g.d_bounds.p,
+                             (uint32_t)rec, C, G, (uint32_t)g.rank, r, g.d_winall.p,
+                             g.d_cls_begin_glob.p, g.d_totals.p, g.d_shift.p, g.d_bound_local.p, prm);
+        } else {
+          hipLaunchKernelGGL(k_global_flag, dim3(1), dim3(64), 0, st, g.d_bounds.p, (uint32_t)rec, C,
+                             G, r, prm);
+        }
+      }
+      const uint32_t first = launched;
+      launched += group;
+      // The tail behind the group, gated on the device by the last pass's global flag (the same
+      // on every rank): placement of this rank's slice, then the global running_tasks from
+      // everybody's slot deltas. Not converged yet (or a window missed): the deltas are zero
+      // and nothing changes.
+      if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, (launched - 1) & 63,
+                                    g.d_delta.p))
+        return rc;
+      if (S) {
+        if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
+        hipLaunchKernelGGL(k_sum_deltas, dim3(ceil_div(S, 256)), dim3(256), 0, st, c->d_running.p,
+                           g.d_deltas.p, S, G, c->d_running_out.p, d_out_running,
+                           (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr, prm);
+      }
+      mark(c, 7);
+      HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, hipGetLastError());
+      if (c->h_prm->overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
+      if (c->h_prm->window_miss) {
+        miss = true;
+        break;
+      }
+      if (c->h_prm->n_changed[(launched - 1) & 63] == 0) {
+        rounds = launched;
+        for (uint32_t r = first; r < launched; ++r)
+          if (c->h_prm->n_changed[r & 63] == 0) {
+            rounds = r + 1;  // first pass in which no rank changed anything
+            break;
+          }
+        g.pass_hint = rounds;
+        break;
+      }
+      // Worst case one chunk per pass becomes final; K differs per rank, so bound it loosely.
+      if (launched > 4u * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
     }
-    // Worst case one chunk per pass becomes final; K differs per rank, so bound it loosely.
-    if (launched > 4u * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
+    if (!miss) break;
+    // Some rank's window did not cover what its requests reached (every rank saw the same
+    // flag): once more with the full sort everywhere, and wider margins from now on.
+    ++g.window_misses;
+    g.margin_scale = std::min(g.margin_scale * 2, 64u);
+    windowed = false;
   }
   g.passes = rounds;
 
