@@ -132,6 +132,7 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
   SharedIpTable sh{T.ip_sorted.data(), T.ip_servant.data(), S, T.class_of.data(),
                    base.data(),        S,                   pos_last.data()};
   uint32_t rounds = 0, sims = 0;
+  std::vector<ClassState> final_state(C);
   if (K) {
     // consuming tasks before each chunk, per part of the registry
     std::vector<uint32_t> before((size_t)(K + 1) * G, 0);
@@ -181,6 +182,7 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
       if (!any) break;
       if (rounds > K + 2) return -6;
     }
+    for (uint32_t c = 0; c < C; ++c) final_state[c] = endst[(size_t)(K - 1) * C + c];
   }
 
   // --- finalise.
@@ -199,6 +201,31 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
     run[s]++;
   }
   if (out_running) std::memcpy(out_running, run.data(), S * sizeof(uint32_t));
+  // Cross-check of what k_finalize does on the device: running_tasks in closed form from the
+  // final class states (servant_slots_before) must equal the count over the placements.
+  if (K && C) {
+    for (uint32_t s = 0; s < S; ++s) {
+      const uint32_t c = T.class_of[s];
+      uint32_t taken = 0;
+      if (c != kNone) {
+        const ClassState& st = final_state[c];
+        const bool holes_here = st.lo < st.cursor && st.hown_lo == base[s];
+        const uint32_t x = holes_here ? st.lo : st.cursor;
+        if (x >= cls_begin[c + 1]) {
+          taken = servant_slot_count(nproc[s], load[s], max_tasks[s], running[s], flags[s]);
+        } else {
+          const uint32_t g = list_g[x], hs = owner_of_slot(base.data(), S, g);
+          const uint32_t hr = running[hs] + (g - base[hs]);
+          const uint64_t part_key = G > 1 ? (uint64_t)comp_of(c) << kf.comp_shift : 0ull;
+          const uint64_t hkey = slot_sort_key(nproc[hs], load[hs], max_tasks[hs], flags[hs], hr,
+                                              part_key, kf.exact, kf.cap_bits);
+          taken = servant_slots_before(nproc[s], load[s], max_tasks[s], running[s], flags[s], s,
+                                       part_key, hkey, hs, kf.exact, kf.cap_bits);
+        }
+      }
+      if (running[s] + taken != run[s]) return -7;
+    }
+  }
   if (stats) {
     stats->n_slots = M;
     stats->n_classes = C;

@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/. Usage: tools/gpu_round_check.sh <tag> [quick]
 TAG=${1:-check}; MODE=${2:-full}
 O=gpurun_out/$TAG; mkdir -p $O
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > $O/pytest.log
+(timeout 600 python -m pytest tests -m gpu -x -q --timeout 120 2>&1 | tail -25) > $O/pytest.log
 timeout 300 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 timeout 300 python bench.py --shared-ip-frac 0.05 --steps 2000 --warmup 100 > $O/bench_cfg2_shared.json 2> $O/bench_cfg2_shared.err
 timeout 300 python bench.py --config cfg3 --steps 300 --warmup 20 > $O/bench_cfg3.json 2> $O/bench_cfg3.err

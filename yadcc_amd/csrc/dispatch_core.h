@@ -167,6 +167,44 @@ YDC_HD uint32_t first_slot_not_below(uint32_t nproc, uint32_t load, uint32_t max
   return hi;
 }
 
+// The sort key of slot (servant, r), exact or fp64 format, the part id in place.
+YDC_HD uint64_t slot_sort_key(uint32_t nproc, uint32_t load, uint32_t max_tasks, uint32_t flags,
+                              uint32_t r, uint64_t part_key, bool exact, uint32_t cap_bits) {
+  const uint32_t cap = slot_capacity(nproc, load, max_tasks, r), tier = slot_tier(nproc, flags, r);
+  return part_key | (exact ? slot_key_exact(tier, r, cap, cap_bits) : slot_key_fp64(tier, r, cap));
+}
+
+// How many slots of servant `s` precede the list entry (head_key, head_servant) in its class
+// list — i.e. sort before it: smaller key, or the same key on an earlier servant (ties go by
+// registry index, the reference's first-wins rule, task_dispatcher.cc:440-447). A class list is
+// consumed from the front, so with the entry at the class's cursor this is the number of
+// slots the batch took on the servant — running_tasks needs no per-slot bookkeeping.
+YDC_HD uint32_t servant_slots_before(uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                     uint32_t running, uint32_t flags, uint32_t s,
+                                     uint64_t part_key, uint64_t head_key, uint32_t head_servant,
+                                     bool exact, uint32_t cap_bits) {
+  const uint32_t n = servant_slot_count(nproc, load, max_tasks, running, flags);
+  if (n == 0) return 0;
+  const uint32_t top = running + n;
+  uint32_t r;
+  if (exact) {
+    r = first_slot_not_below(nproc, load, max_tasks, running, flags, part_key, head_key, cap_bits);
+  } else {
+    uint32_t lo = running, hi = top;  // first r in [running, top] with key >= head_key
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (slot_sort_key(nproc, load, max_tasks, flags, mid, part_key, false, cap_bits) < head_key) lo = mid + 1;
+      else hi = mid;
+    }
+    r = lo;
+  }
+  uint32_t cnt = r - running;
+  if (r < top && s < head_servant &&
+      slot_sort_key(nproc, load, max_tasks, flags, r, part_key, exact, cap_bits) == head_key)
+    ++cnt;  // the tie on an earlier servant sorts first
+  return cnt;
+}
+
 // ---------------------------------------------------------------------------
 // Tasks.
 // ---------------------------------------------------------------------------

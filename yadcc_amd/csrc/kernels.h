@@ -12,7 +12,8 @@
 //   k_radix_scatter_classed / class passes   per-class sorted lists (rank, slot)
 //   k_match_pass (match_kernel.h)     chunk-parallel speculative replay of the greedy picks;
 //                    pass 0 makes its own level guesses (k_guess_init: > 64 classes, sharded)
-//   k_finalize, k_running_out         rank -> slot -> servant index, utilisation, running_tasks
+//   k_finalize                        rank -> slot -> servant index, utilisation; running_tasks in
+//                    closed form from the final class states (same launch)
 //
 // The arithmetic (capacity, keys, class-state machine) lives in dispatch_core.h
 // and is shared with the CPU model in tests/model.
@@ -177,13 +178,13 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
+  if (threadIdx.x < 64) prm->n_changed[threadIdx.x] = prm->n_sampled[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     uint32_t m = carry;
     slot_base[sv.n] = m;
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->reserved0 = 0;
-    for (int r = 0; r < 64; ++r) prm->n_changed[r] = prm->n_sampled[r] = 0;
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   DeviceParams* prm, uint32_t exact,
                                                   uint32_t cap_bits, KeyT* keys, uint32_t* vals,
                                                   uint16_t* cls_by_g, uint32_t* owner,
-                                                  uint8_t* consumed, uint32_t gen_blocks,
+                                                  uint32_t gen_blocks,
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
                                                   uint32_t gbits, uint32_t* hist, ClassifyArgs ca,
                                                   uint32_t comp_shift, const uint32_t* r_first,
@@ -420,7 +421,6 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     uint32_t r = (r_first ? r_first[s] : run0) + (g - slot_base[s]);
     const uint32_t gg = gslot_base ? gslot_base[s] + (r - run0) : g;
     owner[gg] = s;
-    consumed[gg] = 0;
     uint32_t nproc = sv.nproc[s], flags = sv.flags[s];
     uint32_t cap = slot_capacity(nproc, sv.load[s], sv.max_tasks[s], r);
     uint32_t tier = slot_tier(nproc, flags, r);
@@ -836,24 +836,64 @@ __global__ __launch_bounds__(256) void k_update(uint32_t n_classes, uint32_t n_c
 }
 
 // ---------------------------------------------------------------------------
-// k_finalize: thread per request. slot_of[t] is the global rank of the request's slot
-// (matching passes) or its generation index (sequential paths: slot_is_rank == 0, or
-// need_shared); rank -> slot through the key-sorted order, slot -> servant through the
-// owner table slot_gen left. Marks the slot consumed — no atomics: k_running_out counts.
+// k_finalize: workgroups [0, req_blocks): thread per request — slot_of[t] is the global rank
+// of the request's slot (matching passes) or its generation index (thread-per-chunk path:
+// slot_is_rank == 0); rank -> slot through the key-sorted order, slot -> servant through the
+// owner table slot_gen left; utilisation. Workgroups behind them: thread per servant —
+// running_tasks after the batch, in closed form from the final class states: a class list is
+// consumed from the front (holes aside), so the slots the batch took on a servant are those
+// that sort before the entry at its class's cursor (servant_slots_before) — no per-slot
+// flags, no atomics on servant counters.
 // ---------------------------------------------------------------------------
+struct RunningArgs {
+  const ClassState* end_state;    // [C] state after this context's last request (NULL: no request)
+  const ClassState* start_state;  // [C] multi-GPU: state before its first request (NULL: batch start)
+  ClassLists L;
+  const uint32_t* gslot_base;     // registry-wide slot names (== slot_base unless the sort is sharded)
+  const uint32_t* cls_comp;
+  uint32_t n_parts, comp_shift, exact, cap_bits;
+  uint32_t n_servants;
+  uint32_t* running_out;  // running + taken
+  uint32_t* out_a;        // nullable: the caller's copy
+  uint32_t* out_b;        // nullable: the resident column itself (COMMIT)
+  uint32_t* taken_out;    // nullable: multi-GPU, this rank's slot delta
+};
+
+// Slots of servant s (class c) that sort before what `st` has not consumed yet.
+__device__ __forceinline__ uint32_t taken_until(const ServantTable& sv, const RunningArgs& ra,
+                                                const uint32_t* owner, uint32_t s, uint32_t c,
+                                                uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                                uint32_t running, uint32_t flags,
+                                                const ClassState& st) {
+  // Holes are slots of ONE servant that were stepped over: for that servant everything from
+  // the first hole on is unconsumed; for everybody else everything below the cursor is taken.
+  const bool owner_of_holes = st.lo < st.cursor && st.hown_lo == ra.gslot_base[s];
+  const uint32_t x = owner_of_holes ? st.lo : st.cursor;
+  const uint32_t end = ra.L.cls_begin[c + 1];
+  if (x >= end) return servant_slot_count(nproc, load, max_tasks, running, flags);  // all of them
+  const uint32_t g = ra.L.list_g[x], hs = owner[g];
+  const uint32_t hr = sv.running[hs] + (g - ra.gslot_base[hs]);
+  const uint64_t part_key = ra.n_parts > 1 ? (uint64_t)ra.cls_comp[c] << ra.comp_shift : 0ull;
+  const uint64_t hkey = slot_sort_key(sv.nproc[hs], sv.load[hs], sv.max_tasks[hs], sv.flags[hs], hr,
+                                      part_key, ra.exact != 0, ra.cap_bits);
+  return servant_slots_before(nproc, load, max_tasks, running, flags, s, part_key, hkey, hs,
+                              ra.exact != 0, ra.cap_bits);
+}
+
 __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_t* slot_base,
                                                   const uint32_t* owner, const uint32_t* rank_to_g,
                                                   const uint32_t* slot_of, uint32_t n_tasks,
                                                   uint32_t slot_is_rank, uint32_t* out_idx,
-                                                  double* out_util, uint8_t* consumed,
-                                                  uint32_t check_slot, const DeviceParams* prm,
-                                                  uint32_t g_mask) {
-  // Pre-launched behind the matching passes: only runs once they have converged (and, with a
-  // sharded sort, only if every rank's key window covered what its requests reached).
-  if (check_slot != kNone && prm->n_changed[check_slot] != 0) return;
-  if (prm->window_miss) return;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_tasks) {
+                                                  double* out_util, uint32_t check_slot,
+                                                  DeviceParams* prm, uint32_t g_mask,
+                                                  uint32_t req_blocks, RunningArgs ra) {
+  // Pre-launched behind the matching passes: only takes effect once they have converged (and,
+  // with a sharded sort, only if every rank's key window covered what its requests reached).
+  const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss;
+  if (blockIdx.x < req_blocks) {
+    if (!final) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tasks) return;
     uint32_t g = slot_of[t];
     if (g >= kIdxEnvNotFound) {
       if (out_idx) out_idx[t] = g;
@@ -866,52 +906,29 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
         uint32_t r = sv.running[s] + (g - slot_base[s]);
         out_util[t] = slot_utilization(r, slot_capacity(sv.nproc[s], sv.load[s], sv.max_tasks[s], r));
       }
-      consumed[g] = 1;
     }
+    return;
   }
-}
-
-// Thread per servant: running_out = running + consumed slots. A servant's slots are
-// consumed in ascending order of `running` (its slots sit in one class list in that
-// order, and the list is consumed smallest-first, holes included), so the consumed ones
-// are a prefix of its slot range: binary search for the first free one.
-__global__ __launch_bounds__(256) void k_running_out(const uint32_t* running, const uint32_t* slot_base,
-                                                     const uint8_t* consumed, uint32_t n_servants,
-                                                     uint32_t* running_out, uint32_t* out_a,
-                                                     uint32_t* out_b, uint32_t check_slot,
-                                                     uint32_t count_all, DeviceParams* prm,
-                                                     uint32_t* taken_out, const uint32_t* win_lo,
-                                                     const uint32_t* win_hi) {
   __shared__ uint32_t lds[17];
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t taken = 0;
-  if (s < n_servants && (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss) {
-    uint32_t lo = slot_base[s], hi = slot_base[s + 1];
-    if (count_all) {
-      // One rank of a sharded batch: its requests took a run somewhere inside the range (the
-      // part of it inside the rank's key window, when the sort is sharded as well).
-      if (win_lo) {
-        lo = win_lo[s];
-        hi = win_hi[s];
-      }
-      for (uint32_t g = lo; g < hi; ++g) taken += consumed[g];
-    } else {
-      const uint32_t b = lo;  // first free slot in [lo, hi]
-      while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (consumed[mid]) lo = mid + 1; else hi = mid;
-      }
-      taken = lo - b;
+  const uint32_t s = (blockIdx.x - req_blocks) * blockDim.x + threadIdx.x;
+  uint32_t taken = 0, running = 0;
+  if (s < ra.n_servants) {
+    running = sv.running[s];
+    const uint32_t c = sv.class_of[s];
+    if (final && ra.end_state && c != kNone) {
+      const uint32_t nproc = sv.nproc[s], load = sv.load[s], mt = sv.max_tasks[s], fl = sv.flags[s];
+      taken = taken_until(sv, ra, owner, s, c, nproc, load, mt, running, fl, ra.end_state[c]);
+      if (ra.start_state)
+        taken -= taken_until(sv, ra, owner, s, c, nproc, load, mt, running, fl, ra.start_state[c]);
     }
-  }
-  if (s < n_servants) {
-    // out_a / out_b (nullable): the caller's copy and, when committing, the resident column
-    // itself (same index read and written by this thread only).
-    const uint32_t v = running[s] + taken;
-    running_out[s] = v;
-    if (out_a) out_a[s] = v;
-    if (out_b) out_b[s] = v;
-    if (taken_out) taken_out[s] = taken;  // (multi-GPU: this rank's slot delta)
+    // When the passes have not converged yet this writes running unchanged everywhere and
+    // the launch is repeated later. out_b may be the resident column itself (same index read
+    // and written by this thread only).
+    const uint32_t v = running + taken;
+    ra.running_out[s] = v;
+    if (ra.out_a) ra.out_a[s] = v;
+    if (ra.out_b) ra.out_b[s] = v;
+    if (ra.taken_out) ra.taken_out[s] = taken;
   }
   // One counter update per workgroup (same-address atomics serialise at ~10 ns each).
   uint32_t total;
@@ -1065,8 +1082,6 @@ struct WindowArgs {
   // out
   uint32_t* r_first;          // [S] first `running` value of the servant inside the window
   uint32_t* lbase;            // [S + 1] local prefix of the slot counts
-  uint32_t* win_lo;           // [S] the window's slots of the servant, as registry-wide slot
-  uint32_t* win_hi;           //     names [win_lo, win_hi)
   uint32_t* cls_begin;        // [C + 1] local class lists
   uint32_t* shift_out;        // [C] registry-wide list position = local position + shift
   uint32_t* winrec;           // [2 C] registry-wide list positions [start, end) the window covers
@@ -1127,8 +1142,6 @@ __global__ __launch_bounds__(1024) void k_window(ServantTable sv, WindowArgs a, 
     if (s < sv.n) {
       a.lbase[s] = carry + ex;
       a.r_first[s] = r0;
-      a.win_lo[s] = a.gslot_base[s] + below;
-      a.win_hi[s] = a.gslot_base[s] + below + len;
       if (cls != kNone) {
         if (below) atomicAdd(&cls_acc[cls], below);
         if (len) atomicAdd(&cls_acc[C + cls], len);

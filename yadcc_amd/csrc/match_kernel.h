@@ -272,7 +272,7 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 // guarantees that every ring holds at least n + 2 entries beyond its cursor.
 //
 // Registers: hq / nq = ~rank of head / next of the lane's class (0: none), `off` = ring
-// byte offset of `next`, ring_p at LDS `base`, ring_g 8192 bytes further. m0 = i,
+// byte offset of `next`, ring_p at LDS `base`, ring_g at `gbase` (behind all of ring_p). m0 = i,
 // s[90:91] = class mask of request i (fetched one request ahead, in the wait states of
 // the DPP chain), s[92:93] scratch. One loop body per DPP depth (2^steps >= classes).
 // Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR ->
@@ -423,8 +423,8 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 __device__ __forceinline__ uint32_t match_fast_loop(
     uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
     uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& res, uint32_t& hq,
-    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t rmask4, uint32_t steps,
-    uint32_t pair) {
+    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t gbase, uint32_t rmask4,
+    uint32_t steps, uint32_t pair) {
   uint32_t status, c, t, c1, t1, a, mn, sp, ip, s0, s1, m0save;
   asm volatile(
       "s_mov_b32 %[m0s], m0\n"
@@ -463,7 +463,7 @@ __device__ __forceinline__ uint32_t match_fast_loop(
         [a] "=&v"(a), [mn] "=&s"(mn),
         [sp] "=&s"(sp), [ip] "=&s"(ip), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
       : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [special] "s"(special),
-        [hh] "s"(hole_hit), [hs] "s"(has_self), [base] "v"(base), [rmask4] "s"(rmask4),
+        [hh] "s"(hole_hit), [hs] "s"(has_self), [base] "v"(base), [gbase] "v"(gbase), [rmask4] "s"(rmask4),
         [steps] "s"(steps), [pair] "s"(pair)
       : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
   return status;
@@ -513,9 +513,11 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   // replayed graph gets fresh stamps too).
   const unsigned long long stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
 
-  // Fixed layout: ranks in the first 8 KB, generation indexes 8 KB further (the asm loop
-  // addresses the second array with an immediate offset). C << rshift <= 2048.
-  MatchWave<W> w{L, lds_ring, lds_ring + 2048, (1u << rshift) - 1, rshift, lane, {}};
+  // Layout: the ranks of all rings first, the generation indexes behind them. ring_total
+  // entries per array (flags >> 8; C << rshift <= ring_total): fewer entries = less LDS per
+  // wave = more waves of this latency-bound kernel per CU.
+  const uint32_t ring_total = flags >> 8;
+  MatchWave<W> w{L, lds_ring, lds_ring + ring_total, (1u << rshift) - 1, rshift, lane, {}};
   const uint32_t R = 1u << rshift;
   // A ring is topped up when no more than `thresh` entries are left in it.
   const uint32_t thresh = R / 4 < 4 ? 4 : (R / 4 > 12 ? 12 : R / 4);
@@ -897,6 +899,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       if constexpr (W == 1) {
         LaneClass& q = w.k[0];
         const uint32_t base = (uint32_t)(uintptr_t)lds_ring + ((lane << rshift) << 2);
+        const uint32_t gbase = base + (ring_total << 2);
         const uint32_t rmask4 = (R << 2) - 1;
         const uint64_t my_mask = ((uint64_t)mhi[0] << 32) | mlo[0];
         uint32_t i = 0;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           const uint64_t hole_hit = (holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull) | dyn_self;
           const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
                                               hole_hit, has_self, res, q.hq, q.nq, q.cursor, off,
-                                              base, rmask4, steps,
+                                              base, gbase, rmask4, steps,
                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode));
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;

@@ -53,6 +53,7 @@ namespace {
 struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
   uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
+  uint32_t ring_total = 2048;  // entries of all rings of a matching wave (x 8 B of LDS)
   uint32_t fused_cls_bits = 0;  // class partition folded into the last key pass (kernels.h)
   uint32_t gbits = 0;  // != 0: the sort's values carry the class above gbits slot bits (SortIn)
   uint32_t slot_bound_glob = 0, win_margin = 0;  // (sharded sort: slot_bound is the window's)
@@ -96,7 +97,6 @@ struct ydc_context {
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
-  DevBuf<uint8_t> d_consumed;   // slot taken by a request of this batch
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_running_out;
@@ -118,8 +118,7 @@ struct ydc_context {
     DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
     // Sharded sort (k_window): key-count table, per-servant windows, local prefix, class lists
     // of the whole registry, local -> registry-wide list position shifts, the ranks' windows.
-    DevBuf<uint32_t> d_cum, d_r_first, d_lbase, d_win_lo, d_win_hi, d_cls_begin_glob, d_shift,
-        d_winrec, d_winall;
+    DevBuf<uint32_t> d_cum, d_r_first, d_lbase, d_cls_begin_glob, d_shift, d_winrec, d_winall;
     DevBuf<ClassState> d_bound_local;
     uint32_t margin_scale = 1;  // doubled after a batch whose window missed
     uint64_t windowed_batches = 0, window_misses = 0;
@@ -184,6 +183,9 @@ struct ydc_context {
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
+  // 16 KB of LDS per matching wave = 10 waves per CU. Smaller rings (more waves per CU, shorter
+  // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
+  uint32_t opt_ring_total = 2048;
   bool opt_fused_class = true;
   bool opt_own_guess = true;
   bool opt_pair = true;
@@ -483,7 +485,6 @@ int ydc_destroy(ydc_context* c) {
   c->d_cls_by_g.release();
   c->d_owner.release();
   c->d_rank_to_g.release();
-  c->d_consumed.release();
   c->d_guess[0].release();
   c->d_endst.release();
   c->d_checkpoint.release();
@@ -811,7 +812,6 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     }
   }
   HIP_TRY(c, c->d_owner.reserve(slot_bound));
-  HIP_TRY(c, c->d_consumed.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
   HIP_TRY(c, c->d_self_lo.reserve(N));
   HIP_TRY(c, c->d_self_hi.reserve(N));
@@ -863,8 +863,10 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.flag_mask = 63;
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
+    p.ring_total = c->opt_ring_total;
+    while (p.ring_total < 2048 && ((size_t)C << 3) > p.ring_total) p.ring_total <<= 1;  // >= 8 per class
     p.rshift = 3;
-    while (p.rshift < 10 && ((size_t)C << (p.rshift + 1)) <= 2048) ++p.rshift;
+    while (p.rshift < 10 && ((size_t)C << (p.rshift + 1)) <= p.ring_total) ++p.rshift;
     const uint32_t R = 1u << p.rshift;
     uint32_t want = 2 * p.cs / std::max(C, 1u);
     p.init_fill = 8;
@@ -927,13 +929,13 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   if (p.key32) {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
-               (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p, c->d_consumed.p,
+               (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
                r_first, gbase);
   } else {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
-               (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p, c->d_consumed.p,
+               (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
                r_first, gbase);
   }
@@ -1032,9 +1034,10 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
 // One matching pass (match_kernel.h). device_check: return at once when the previous pass
 // found every chunk consistent.
 void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t device_check) {
-  const size_t lds = 16384;
+  const size_t lds = (size_t)p.ring_total * 8;
   device_check |= c->debug_sim ? 2u : 0u;
   device_check |= c->opt_pair ? 4u : 0u;
+  device_check |= p.ring_total << 8;
   DeviceParams* prm = c->d_prm.p;
   if (p.W == 1) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
@@ -1048,28 +1051,36 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   }
 }
 
-// slot -> servant index, utilisation, running_tasks. check_slot != kNone: only runs when
-// the pass with that counter slot found every chunk consistent.
+// slot -> servant index, utilisation, running_tasks (one launch). check_slot != kNone: only
+// takes effect when the pass with that counter slot found every chunk consistent. start_state
+// (multi-GPU): class states before this rank's first request; d_taken: its slot deltas.
 int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_t* d_out_idx,
                      double* d_out_util, uint32_t* d_out_running, uint32_t check_slot,
-                     uint32_t* d_taken = nullptr) {
-  hipStream_t st = c->stream;
+                     uint32_t* d_taken = nullptr, const ClassState* start_state = nullptr) {
   const uint32_t S = p.S, N = p.N;
-  if (N) {
-    YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(ceil_div(N, 256)), dim3(256), 0, st, p.sv,
-               c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N,
-               p.wave_path ? 1u : 0u, d_out_idx, d_out_util, c->d_consumed.p, check_slot, c->d_prm.p,
-               p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu);
-  }
-  if (S) {
-    // Also writes the caller's copy and (COMMIT) the resident column; when the passes have not
-    // converged yet it writes running unchanged everywhere and is repeated later.
-    YDC_LAUNCH(c, "k_running_out", k_running_out, dim3(ceil_div(S, 256)), dim3(256), 0, st,
-               c->d_running.p, c->d_slot_base.p, c->d_consumed.p, S, c->d_running_out.p,
-               d_out_running, (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr, check_slot,
-               c->group.n_ranks > 1 ? 1u : 0u, c->d_prm.p, d_taken,
-               p.win ? c->group.d_win_lo.p : nullptr, p.win ? c->group.d_win_hi.p : nullptr);
-  }
+  const uint32_t req_blocks = ceil_div(N, 256), srv_blocks = ceil_div(S, 256);
+  if (req_blocks + srv_blocks == 0) return YDC_OK;
+  RunningArgs ra{};
+  ra.end_state = N && p.C && p.K ? c->d_endst.p + (size_t)(p.K - 1) * p.C : nullptr;
+  ra.start_state = ra.end_state ? start_state : nullptr;
+  ra.L = p.L;
+  ra.gslot_base = c->d_slot_base.p;
+  ra.cls_comp = c->d_cls_comp.p;
+  ra.n_parts = c->n_parts;
+  ra.comp_shift = c->kf.comp_shift;
+  ra.exact = c->kf.exact ? 1u : 0u;
+  ra.cap_bits = c->kf.cap_bits;
+  ra.n_servants = S;
+  ra.running_out = c->d_running_out.p;
+  ra.out_a = d_out_running;
+  // (COMMIT: the resident column itself; when the passes have not converged yet the launch
+  // writes running unchanged everywhere and is repeated later.)
+  ra.out_b = (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr;
+  ra.taken_out = d_taken;
+  YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(req_blocks + srv_blocks), dim3(256), 0, c->stream, p.sv,
+             c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N, p.wave_path ? 1u : 0u,
+             d_out_idx, d_out_util, check_slot, c->d_prm.p, p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu,
+             req_blocks, ra);
   return YDC_OK;
 }
 
@@ -1368,8 +1379,7 @@ void group_release(ydc_context* c) {
   }
   for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas, &g.d_pad, &g.d_gather,
                   &g.d_all[0], &g.d_all[1], &g.d_all[2], &g.d_all_idx, &g.d_cum, &g.d_r_first,
-                  &g.d_lbase, &g.d_win_lo, &g.d_win_hi, &g.d_cls_begin_glob, &g.d_shift, &g.d_winrec,
-                  &g.d_winall})
+                  &g.d_lbase, &g.d_cls_begin_glob, &g.d_shift, &g.d_winrec, &g.d_winall})
     b->release();
   g.d_bound_local.release();
   g.d_all_util.release();
@@ -1607,8 +1617,6 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       HIP_TRY(c, g.d_cum.reserve(kWindowThresholds + 1));
       HIP_TRY(c, g.d_r_first.reserve(S));
       HIP_TRY(c, g.d_lbase.reserve((size_t)S + 1));
-      HIP_TRY(c, g.d_win_lo.reserve(S));
-      HIP_TRY(c, g.d_win_hi.reserve(S));
       HIP_TRY(c, g.d_cls_begin_glob.reserve((size_t)C + 1));
       HIP_TRY(c, g.d_shift.reserve(C));
       HIP_TRY(c, g.d_winrec.reserve((size_t)2 * C));
@@ -1643,8 +1651,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
                  c->kf.cap_bits, shift, g.d_cum.p);
       WindowArgs wa{g.d_cum.p, c->kf.cap_bits, shift, g.d_totals.p, (uint32_t)g.rank, G, p.win_margin,
                     p.slot_bound, c->d_slot_base.p, g.d_cls_begin_glob.p, C, g.d_r_first.p,
-                    g.d_lbase.p, g.d_win_lo.p, g.d_win_hi.p, c->d_cls_begin.p, g.d_shift.p,
-                    g.d_winrec.p};
+                    g.d_lbase.p, c->d_cls_begin.p, g.d_shift.p, g.d_winrec.p};
       YDC_LAUNCH(c, "k_window", k_window, dim3(1), dim3(1024), (size_t)2 * C * 4, st, p.sv, wa, prm);
       if (int rc = group_all_gather(c, g.d_winrec.p, g.d_winall.p, (size_t)2 * C * 4)) return rc;
       enqueue_gen(c, p, tk, true, false);  // the window's slots
@@ -1696,7 +1703,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       // everybody's slot deltas. Not converged yet (or a window missed): the deltas are zero
       // and nothing changes.
       if (int rc = enqueue_finalize(c, p, 0u, d_out_idx, d_out_util, nullptr, (launched - 1) & 63,
-                                    g.d_delta.p))
+                                    g.d_delta.p, p.mb.boundary_in))
         return rc;
       if (S) {
         if (int rc = group_all_gather(c, g.d_delta.p, g.d_deltas.p, (size_t)S * 4)) return rc;
