@@ -33,6 +33,32 @@ def pmc(path):
     return "\n".join(out)
 
 
+def calib(fetch_db, write_db):
+    """tools/hbm_calib under the two PMC passes: counter value against the bytes every
+    calibration kernel is known to move (1 GiB streamed once; the strided kernels touch one
+    4-byte word in each of the 2^24 64-byte lines of the same GiB)."""
+    gib = float(1 << 30)
+    known = {"k_calib_read": gib, "k_calib_write": gib,
+             "k_calib_read_strided": gib / 16, "k_calib_write_strided": gib / 16}
+    q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+         "where counter_name = ? group by kernel_name order by kernel_name")
+    out = ["%-44s %-11s %6s %14s %14s %9s %9s" % ("kernel", "counter", "calls", "counter_KB",
+                                                  "useful_bytes", "factor", "GB/s")]
+    for db, counter in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
+        for n, c, a, d in sqlite3.connect(db).execute(q, (counter,)):
+            nm = short(n).replace("ydc::", "")
+            base = nm.split("<")[0]
+            if ("read" in base) != (counter == "FETCH_SIZE") or base not in known:
+                continue
+            useful = known[base]
+            out.append("%-44s %-11s %6d %14.1f %14.0f %9.3f %9.1f" % (
+                nm[:44], counter, c, a, useful, useful / (a * 1024.0) if a else float("nan"),
+                useful / d if d else 0.0))
+    out.append("factor = useful bytes / (counter_KB * 1024): what a counter reading has to be "
+               "multiplied with to give bytes for that access width; GB/s = useful bytes / duration.")
+    return "\n".join(out)
+
+
 def plain(name):
     """void ydc::k_match_pass<1>(...) -> k_match_pass (the name bench.py uses)."""
     n = short(name)
@@ -40,11 +66,11 @@ def plain(name):
     return n.split("::")[-1].strip()
 
 
-def hbmjson(fetch_db, write_db):
-    """HBM bytes per launch per kernel from the two PMC passes. FETCH_SIZE / WRITE_SIZE are
-    reported in KB; gfx950: FETCH_SIZE reports exactly half the bytes of wide coalesced
-    streaming reads (MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is taken
-    as reported (uncalibrated)."""
+def hbmjson(fetch_db, write_db, f_fetch=2.0, f_write=1.0):
+    """Fabric bytes per launch per kernel from the two PMC passes. FETCH_SIZE / WRITE_SIZE are
+    reported in KB; f_fetch / f_write: calibration factors for the access width of these
+    kernels (dword loads / stores), measured with tools/hbm_calib on the same box
+    (profiles/*_hbm_calibration.txt). Raw counter values are kept beside the calibrated sum."""
     import json
     out = {}
     q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
@@ -54,9 +80,15 @@ def hbmjson(fetch_db, write_db):
             e = out.setdefault(plain(n), {"launches_profiled": c, "avg_ns": d})
             e[key] = e.get(key, 0.0) + a  # template instances of one kernel are merged
     for e in out.values():
-        e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e.get("fetch_kb", 0.0) + e.get("write_kb", 0.0))
+        e["raw_bytes_per_launch"] = 1024.0 * (e.get("fetch_kb", 0.0) + e.get("write_kb", 0.0))
+        e["hbm_bytes_per_launch"] = 1024.0 * (f_fetch * e.get("fetch_kb", 0.0) +
+                                              f_write * e.get("write_kb", 0.0))
     return json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
-                       "correction": "hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes)",
+                       "correction": "hbm_bytes = %.3f * FETCH_SIZE + %.3f * WRITE_SIZE (KB -> bytes); "
+                                     "factors from tools/hbm_calib (dword streaming), raw sum beside it"
+                                     % (f_fetch, f_write),
+                       "note": "memory-side (fabric) request counters: Infinity-Cache hits are counted, "
+                               "and every working set here fits the 256 MiB Infinity Cache",
                        "kernels": out}, indent=1)
 
 
@@ -86,7 +118,11 @@ def hbmtable(specs):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "hbmjson":
-        print(hbmjson(sys.argv[2], sys.argv[3]))
+        ff = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+        fw = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+        print(hbmjson(sys.argv[2], sys.argv[3], ff, fw))
+    elif mode == "calib":
+        print(calib(sys.argv[2], sys.argv[3]))
     elif mode == "hbmtable":
         print(hbmtable(sys.argv[2:]))
     else:

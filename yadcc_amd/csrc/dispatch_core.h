@@ -275,11 +275,14 @@ YDC_HD uint32_t owner_of_slot(const uint32_t* slot_base, uint32_t n_servants, ui
 // class's slots in ascending global rank; list_p = global rank of the slot in the
 // (tier, utilisation, servant) order (NULL when there is a single class: rank ==
 // index), list_g = generation index (servant-major) of the slot.
+// stride: distance of consecutive entries in 32-bit words — 2 when rank and slot sit side by
+// side in 8-byte records (the device's 32-bit-key sort), 1 for two plain arrays.
 struct ClassLists {
   const uint32_t* list_p;
   const uint32_t* list_g;
   const uint32_t* cls_begin;  // [n_classes + 1]
   uint32_t n_classes;
+  uint32_t stride = 1;
 };
 
 // Consumption state of one class: everything below `cursor` is consumed except
@@ -322,12 +325,15 @@ struct ClassRun {
   uint32_t head_g;  // (kNone when the class is exhausted)
 };
 
-YDC_HD uint32_t list_rank(const ClassLists& L, uint32_t i) { return L.list_p ? L.list_p[i] : i; }
+YDC_HD uint32_t list_rank(const ClassLists& L, uint32_t i) {
+  return L.list_p ? L.list_p[(size_t)i * L.stride] : i;
+}
+YDC_HD uint32_t list_slot(const ClassLists& L, uint32_t i) { return L.list_g[(size_t)i * L.stride]; }
 
 YDC_HD void class_load_head(const ClassLists& L, ClassRun& r) {
   if (r.cursor < r.end) {
     r.head_p = list_rank(L, r.cursor);
-    r.head_g = L.list_g[r.cursor];
+    r.head_g = list_slot(L, r.cursor);
   } else {
     r.head_p = kNone;
     r.head_g = kNone;
@@ -367,7 +373,7 @@ YDC_HD bool class_candidate(const ClassLists& L, const ClassRun& r, uint32_t sel
     // The smallest unconsumed slot is a hole somebody else's request may take.
     ci = r.lo;
     cp = list_rank(L, r.lo);
-    cg = L.list_g[r.lo];
+    cg = list_slot(L, r.lo);
     return true;
   }
   // No holes, or the holes are this requestor's own servant's: first entry
@@ -379,7 +385,7 @@ YDC_HD bool class_candidate(const ClassLists& L, const ClassRun& r, uint32_t sel
     ++ci;
     if (ci < r.end) {
       cp = list_rank(L, ci);
-      cg = L.list_g[ci];
+      cg = list_slot(L, ci);
     }
   }
   return ci < r.end;
@@ -392,7 +398,7 @@ YDC_HD bool class_self_candidate(const ClassLists& L, const ClassRun& r, uint32_
   if (r.lo < r.cursor) {
     if (r.hown_lo != self_lo) return false;
     ci = r.lo;
-    cg = L.list_g[r.lo];
+    cg = list_slot(L, r.lo);
     return true;
   }
   if (r.cursor < r.end && r.head_g >= self_lo && r.head_g < self_hi) {
@@ -413,7 +419,7 @@ YDC_HD bool class_consume_state(const ClassLists& L, ClassRun& r, uint32_t ci, u
     // servant below the cursor.
     uint32_t j = ci + 1;
     while (j < r.cursor) {
-      uint32_t g = L.list_g[j];
+      uint32_t g = list_slot(L, j);
       if (g >= r.hown_lo && g < r.hown_hi) break;
       ++j;
     }
@@ -535,7 +541,12 @@ YDC_HD ClassState level_guess(const ClassLists& L, uint32_t c, uint32_t consumed
   uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
   uint32_t cur;
   if (L.list_p) {
-    cur = b + lower_bound_u32(L.list_p + b, e - b, consumed);
+    uint32_t lo = b, hi = e;  // first entry of the class whose rank is >= consumed
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (list_rank(L, mid) < consumed) lo = mid + 1; else hi = mid;
+    }
+    cur = lo;
   } else {
     cur = b + (consumed < e - b ? consumed : e - b);
   }

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
                                                   uint32_t gbits, uint32_t* hist, ClassifyArgs ca,
                                                   uint32_t comp_shift, const uint32_t* r_first,
-                                                  const uint32_t* gslot_base) {
+                                                  const uint32_t* gslot_base, uint32_t packed) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
@@ -428,10 +428,17 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
     const uint32_t cls = sv.class_of[s];
     // Several independent parts: slots are ordered part-major (the id rides above the key).
     if (ca.n_parts > 1) key |= (uint64_t)ca.cls_comp[cls] << comp_shift;
-    keys[g] = (KeyT)key;
-    // The sort's value is the slot; with room above its bits (gbits != 0) the class rides
-    // there, so that class digits need no gather (SortIn::gbits).
-    vals[g] = gbits ? (cls << gbits) | gg : gg;
+    const uint32_t sort_val = gbits ? (cls << gbits) | gg : gg;
+    if (sizeof(KeyT) == 4 && packed) {
+      // 32-bit keys: (key, value) side by side, one 8-byte store — and one per sort pass
+      // instead of two scattered 4-byte ones (each of those moves a 32-byte sector).
+      reinterpret_cast<uint2*>(keys)[g] = make_uint2((uint32_t)key, sort_val);
+    } else {
+      keys[g] = (KeyT)key;
+      vals[g] = sort_val;
+    }
+    // (The sort's value is the slot; with room above its bits (gbits != 0) the class rides
+    // there, so that class digits need no gather, SortIn::gbits.)
     if (cls_by_g) cls_by_g[gg] = (uint16_t)cls;
     uint32_t d = (uint32_t)key & ((1u << kbits) - 1);
     if (fused0) d |= cls << kbits;
@@ -449,9 +456,11 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
 // ---------------------------------------------------------------------------
 constexpr int kMaxRadixBits = 11;
 
+// 32-bit keys travel with their values in 8-byte records (packed: `keys` points to uint2
+// {key, value}, `vals` is unused); 64-bit keys (fp64 format) keep two arrays.
 template <typename KeyT>
 struct SortIn {
-  const KeyT* keys;         // NULL in the class pass: key == index
+  const KeyT* keys;         // NULL: key == index (+ rank_offset) — first class pass, unpacked
   const uint32_t* vals;
   const uint16_t* cls_by_g; // non-NULL in the class pass
   uint32_t shift;
@@ -464,7 +473,32 @@ struct SortIn {
   // cls_by_g is only the "class digit needed" flag). out_mask: applied to the values this pass
   // writes — the last pass of the sort strips the class again.
   uint32_t gbits, out_mask;
+  uint32_t packed;        // input is records
+  uint32_t key_is_index;  // first class pass: the key is the element's index (its global rank)
 };
+
+template <typename KeyT>
+__device__ __forceinline__ void sort_load(const SortIn<KeyT>& in, uint32_t i, uint32_t rank_off,
+                                          bool want_val, KeyT& key, uint32_t& val) {
+  if (in.packed) {
+    const uint2 r = reinterpret_cast<const uint2*>(in.keys)[i];
+    key = in.key_is_index ? (KeyT)(i + rank_off) : (KeyT)r.x;
+    val = r.y;
+  } else {
+    key = in.keys && !in.key_is_index ? in.keys[i] : (KeyT)(i + rank_off);
+    val = want_val ? in.vals[i] : 0u;
+  }
+}
+template <typename OutKeyT>
+__device__ __forceinline__ void sort_store(OutKeyT* out_keys, uint32_t* out_vals, uint32_t packed,
+                                           uint32_t pos, OutKeyT key, uint32_t val) {
+  if (packed) {
+    reinterpret_cast<uint2*>(out_keys)[pos] = make_uint2((uint32_t)key, val);
+  } else {
+    out_keys[pos] = key;
+    out_vals[pos] = val;
+  }
+}
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t sort_class(const SortIn<KeyT>& in, uint32_t val) {
@@ -507,8 +541,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, De
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
       const uint32_t i = min(base + j * kSortThreads + threadIdx.x, M - 1);
-      key[j] = in.keys ? in.keys[i] : (KeyT)(i + prm->rank_offset);  // (index == global rank)
-      val[j] = in.cls_by_g ? in.vals[i] : 0u;  // (the slot: class digits only)
+      sort_load(in, i, prm->rank_offset, in.cls_by_g != nullptr, key[j], val[j]);
     }
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
@@ -588,8 +621,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     val[j] = 0;
     uint32_t d = 0;
     if (valid) {
-      key[j] = in.keys ? in.keys[i] : (KeyT)(i + prm->rank_offset);
-      val[j] = in.vals[i];
+      sort_load(in, i, prm->rank_offset, true, key[j], val[j]);
       d = sort_digit(in, i, key[j], val[j]);
     }
     dig[j] = d;
@@ -624,8 +656,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     const uint32_t i = base + wave * wave_span + j * 64 + lane;
     if ((uint32_t)j < in.items && i < M) {
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
-      out_keys[pos] = (OutKeyT)key[j];
-      out_vals[pos] = val[j] & in.out_mask;
+      sort_store(out_keys, out_vals, in.packed, pos, (OutKeyT)key[j], val[j] & in.out_mask);
     }
   }
 }
@@ -701,8 +732,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
     val[j] = 0;
     uint32_t d = 0;
     if (valid) {
-      val[j] = in.vals[i];
-      d = sort_digit(in, i, in.keys[i], val[j]);
+      KeyT key;
+      sort_load(in, i, prm->rank_offset, true, key, val[j]);
+      d = sort_digit(in, i, key, val[j]);
     }
     dig[j] = d;
     uint64_t kpeers = __ballot(valid);
@@ -752,8 +784,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
       const uint32_t kd = dig[j] & (kradix - 1);
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
       const uint32_t grank = kstart[kd] + wkcnt[kd] + krank[j];
-      out_rank[pos] = grank + prm->rank_offset;
-      out_vals[pos] = val[j] & in.out_mask;
+      sort_store(out_rank, out_vals, in.packed, pos, grank + prm->rank_offset, val[j] & in.out_mask);
       rank_to_g[grank] = val[j] & in.out_mask;
     }
   }
@@ -797,12 +828,12 @@ __global__ __launch_bounds__(64) void k_sim_generic(ClassLists L, TaskTable T, u
 
 // pos_last[s] = position in the class lists of servant s's last slot (registries with hosts
 // that run several servants only: SharedIpTable). Thread per list position.
-__global__ __launch_bounds__(256) void k_pos_last(const uint32_t* list_g, const uint32_t* owner,
+__global__ __launch_bounds__(256) void k_pos_last(ClassLists L, const uint32_t* owner,
                                                   const uint32_t* slot_base, const DeviceParams* prm,
                                                   uint32_t* pos_last) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= prm->n_slots) return;
-  const uint32_t g = list_g[i], s = owner[g];
+  const uint32_t g = list_slot(L, i), s = owner[g];
   if (g + 1 == slot_base[s + 1]) pos_last[s] = i;
 }
 
@@ -871,7 +902,7 @@ __device__ __forceinline__ uint32_t taken_until(const ServantTable& sv, const Ru
   const uint32_t x = owner_of_holes ? st.lo : st.cursor;
   const uint32_t end = ra.L.cls_begin[c + 1];
   if (x >= end) return servant_slot_count(nproc, load, max_tasks, running, flags);  // all of them
-  const uint32_t g = ra.L.list_g[x], hs = owner[g];
+  const uint32_t g = list_slot(ra.L, x), hs = owner[g];
   const uint32_t hr = sv.running[hs] + (g - ra.gslot_base[hs]);
   const uint64_t part_key = ra.n_parts > 1 ? (uint64_t)ra.cls_comp[c] << ra.comp_shift : 0ull;
   const uint64_t hkey = slot_sort_key(sv.nproc[hs], sv.load[hs], sv.max_tasks[hs], sv.flags[hs], hr,
@@ -886,7 +917,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
                                                   uint32_t slot_is_rank, uint32_t* out_idx,
                                                   double* out_util, uint32_t check_slot,
                                                   DeviceParams* prm, uint32_t g_mask,
-                                                  uint32_t req_blocks, RunningArgs ra) {
+                                                  uint32_t req_blocks, RunningArgs ra,
+                                                  uint32_t rank_stride) {
   // Pre-launched behind the matching passes: only takes effect once they have converged (and,
   // with a sharded sort, only if every rank's key window covered what its requests reached).
   const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss;
@@ -899,7 +931,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
       if (out_idx) out_idx[t] = g;
       if (out_util) out_util[t] = -1.0;
     } else {
-      if (slot_is_rank) g = rank_to_g[g - prm->rank_offset] & g_mask;  // (class bits above)
+      // (rank_stride 2: the values of the key-sorted records; class bits above the slot)
+      if (slot_is_rank) g = rank_to_g[(size_t)(g - prm->rank_offset) * rank_stride] & g_mask;
       const uint32_t s = owner[g];
       if (out_idx) out_idx[t] = s;
       if (out_util) {

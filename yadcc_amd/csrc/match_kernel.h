@@ -159,7 +159,7 @@ struct MatchWave {
     if (e < to) {
       const bool real = e < end;
       ring_p[at(cl, e)] = real ? ~list_rank(L, e) : 0u;
-      ring_g[at(cl, e)] = real ? L.list_g[e] : kNone;
+      ring_g[at(cl, e)] = real ? list_slot(L, e) : kNone;
     }
   }
   // First fill, n (<= R) entries per class. Few classes (C * ceil(n / 64) <= 16): one
@@ -181,7 +181,7 @@ struct MatchWave {
           const uint32_t e = cur + part * 64 + lane;
           if (e < end && part * 64 + lane < n) {
             tp[u] = ~list_rank(L, e);
-            tg[u] = L.list_g[e];
+            tg[u] = list_slot(L, e);
           }
         }
       }
@@ -209,7 +209,7 @@ struct MatchWave {
           for (int u = 0; u < 16; ++u) {
             const uint32_t e = b0 + u;
             tp[u] = e < q.end ? ~list_rank(L, e) : 0u;
-            tg[u] = e < q.end ? L.list_g[e] : kNone;
+            tg[u] = e < q.end ? list_slot(L, e) : kNone;
           }
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         uint32_t lo0 = b, hi0 = e, lo1 = b, hi1 = e;
         while (lo0 < hi0 || lo1 < hi1) {
           const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-          const uint32_t v0 = lo0 < hi0 ? L.list_p[m0] : 0u, v1 = lo1 < hi1 ? L.list_p[m1] : 0u;
+          const uint32_t v0 = lo0 < hi0 ? list_rank(L, m0) : 0u, v1 = lo1 < hi1 ? list_rank(L, m1) : 0u;
           if (lo0 < hi0) {
             if (v0 < n0) lo0 = m0 + 1; else hi0 = m0;
           }
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           if (hi[q] > lo[q]) {
             any = true;
             const uint32_t first = lo[q] + lane * step[q];
-            if (first < hi[q]) v[q] = L.list_p[min(first + step[q] - 1, hi[q] - 1)];
+            if (first < hi[q]) v[q] = list_rank(L, min(first + step[q] - 1, hi[q] - 1));
           }
         }
         if (!any) break;

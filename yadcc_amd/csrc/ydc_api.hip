@@ -58,12 +58,14 @@ struct BatchPlan {
   uint32_t gbits = 0;  // != 0: the sort's values carry the class above gbits slot bits (SortIn)
   uint32_t slot_bound_glob = 0, win_margin = 0;  // (sharded sort: slot_bound is the window's)
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
+  bool packed = false;  // the sort moves 8-byte (key, value) records (32-bit keys)
   bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
   ServantTable sv{};
   ClassLists L{};
   TaskTable T{};
   MatchBuffers mb{};
   const uint32_t* rank_to_g = nullptr;  // slots in key order (before the class partition)
+  uint32_t rank_stride = 1;             // 2: rank_to_g are the values of 8-byte sort records
   SharedIpTable shared{};  // pos_last != NULL: some host runs several servants
 };
 }  // namespace
@@ -191,6 +193,7 @@ struct ydc_context {
   bool opt_pair = true;
   bool opt_packed_class = true;
   bool opt_shard_sort = true;
+  bool opt_packed_sort = true;  // 8-byte (key, value) sort records for 32-bit keys
   int64_t opt_shard_margin = -1;  // >= 0: margin of the key windows in slots (tests)
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
@@ -458,6 +461,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
@@ -784,10 +788,14 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
 
   // Workspace.
   p.key32 = c->kf.key_bits <= 32;
-  HIP_TRY(c, c->d_keys[0].reserve(p.key32 ? (slot_bound + 1) / 2 : slot_bound));
-  HIP_TRY(c, c->d_keys[1].reserve(p.key32 ? (slot_bound + 1) / 2 : slot_bound));
-  HIP_TRY(c, c->d_vals[0].reserve(slot_bound));
-  HIP_TRY(c, c->d_vals[1].reserve(slot_bound));
+  // 32-bit keys: 8-byte (key, value) records in d_keys; 64-bit keys: keys there, values in d_vals.
+  HIP_TRY(c, c->d_keys[0].reserve(slot_bound));
+  HIP_TRY(c, c->d_keys[1].reserve(slot_bound));
+  if (!p.key32 || !c->opt_packed_sort) {
+    HIP_TRY(c, c->d_vals[0].reserve(slot_bound));
+    HIP_TRY(c, c->d_vals[1].reserve(slot_bound));
+  }
+  p.packed = p.key32 && c->opt_packed_sort;
   HIP_TRY(c, c->d_hist.reserve(((size_t)1 << kMaxRadixBits) * p.n_tiles));
   if (C > 1) HIP_TRY(c, c->d_cls_by_g.reserve(slot_bound));
   p.key_passes = c->kf.passes;
@@ -836,11 +844,23 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
   // The sort ping-pongs between the two key/value buffers: where the lists end up.
   const int cur = (int)(((slot_bound ? p.key_passes : 0) + p.cls_passes) & 1);
-  p.rank_to_g = p.fused_cls_bits ? c->d_rank_to_g.p : c->d_vals[(slot_bound ? p.key_passes : 0) & 1].p;
+  const int key_sorted = (int)((slot_bound ? p.key_passes : 0) & 1);
   p.L.n_classes = C;
   p.L.cls_begin = c->d_cls_begin.p;
-  p.L.list_p = p.cls_passes || p.fused_cls_bits ? (const uint32_t*)c->d_keys[cur].p : nullptr;
-  p.L.list_g = c->d_vals[cur].p;
+  if (p.packed) {
+    const uint32_t* rec = (const uint32_t*)c->d_keys[cur].p;  // {rank, slot} pairs
+    p.L.list_p = p.cls_passes || p.fused_cls_bits ? rec : nullptr;
+    p.L.list_g = rec + 1;
+    p.L.stride = 2;
+    p.rank_to_g = p.fused_cls_bits ? c->d_rank_to_g.p : (const uint32_t*)c->d_keys[key_sorted].p + 1;
+    p.rank_stride = p.fused_cls_bits ? 1 : 2;
+  } else {
+    p.L.list_p = p.cls_passes || p.fused_cls_bits ? (const uint32_t*)c->d_keys[cur].p : nullptr;
+    p.L.list_g = c->d_vals[cur].p;
+    p.L.stride = 1;
+    p.rank_to_g = p.fused_cls_bits ? c->d_rank_to_g.p : c->d_vals[key_sorted].p;
+    p.rank_stride = 1;
+  }
   p.T = TaskTable{c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p, W};
   p.shared = SharedIpTable{c->d_ip_sorted.p, c->d_ip_servant.p, p.S, c->d_class_of.p, c->d_slot_base.p,
                            p.S, p.any_shared ? c->d_pos_last.p : nullptr};
@@ -931,13 +951,13 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
-               r_first, gbase);
+               r_first, gbase, p.packed ? 1u : 0u);
   } else {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
-               r_first, gbase);
+               r_first, gbase, p.packed ? 1u : 0u);
   }
 }
 
@@ -962,12 +982,13 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
       const uint16_t* cls = fused ? c->d_cls_by_g.p : nullptr;
       if (p.key32) {
         SortIn<uint32_t> in{(const uint32_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
-                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu};
+                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu,
+                            p.packed ? 1u : 0u, 0u};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], q ? pending_prefix : nullptr,
                          q == 0);
       } else {
         SortIn<uint64_t> in{(const uint64_t*)keys[cur], vals[cur], cls, q * bpp, bits_of(q) + fused,
-                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu};
+                            p.sort_items, fused, p.gbits, fused ? g_mask : 0xFFFFFFFFu, 0u, 0u};
         launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], false, vals[cur ^ 1], q ? pending_prefix : nullptr,
                          q == 0);
       }
@@ -979,9 +1000,10 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
   // ---- class lists: stable partition of ranks by class
   for (uint32_t q = 0; q < p.cls_passes; ++q) {
     // First pass: key == index (global rank). Later passes carry the rank along.
-    SortIn<uint32_t> in{q == 0 ? nullptr : (const uint32_t*)keys[cur], vals[cur], c->d_cls_by_g.p,
-                        q * p.cls_bits, p.cls_bits, p.sort_items, 0u, p.gbits,
-                        q + 1 == p.cls_passes ? g_mask : 0xFFFFFFFFu};
+    SortIn<uint32_t> in{q == 0 && !p.packed ? nullptr : (const uint32_t*)keys[cur], vals[cur],
+                        c->d_cls_by_g.p, q * p.cls_bits, p.cls_bits, p.sort_items, 0u, p.gbits,
+                        q + 1 == p.cls_passes ? g_mask : 0xFFFFFFFFu, p.packed ? 1u : 0u,
+                        q == 0 ? 1u : 0u};
     launch_sort_pass(c, in, p.n_tiles, keys[cur ^ 1], true, vals[cur ^ 1], pending_prefix);
     pending_prefix = nullptr;
     cur ^= 1;
@@ -1020,7 +1042,7 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
     // Hosts that run several servants: the replays resolve `self` from the class state, which
     // takes the list position of every servant's last slot (dispatch_core.h: SharedIpTable).
     YDC_LAUNCH(c, "k_pos_last", k_pos_last, dim3(ceil_div(p.slot_bound, 256)), dim3(256), 0, st,
-               p.L.list_g, c->d_owner.p, c->d_slot_base.p, prm, c->d_pos_last.p);
+               p.L, c->d_owner.p, c->d_slot_base.p, prm, c->d_pos_last.p);
   }
   (void)S;
   return YDC_OK;
@@ -1080,7 +1102,7 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(req_blocks + srv_blocks), dim3(256), 0, c->stream, p.sv,
              c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N, p.wave_path ? 1u : 0u,
              d_out_idx, d_out_util, check_slot, c->d_prm.p, p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu,
-             req_blocks, ra);
+             req_blocks, ra, p.rank_stride);
   return YDC_OK;
 }
 
