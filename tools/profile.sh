@@ -17,6 +17,6 @@ S=$(find "$OUT/stats" -name "*.db" | head -1); F=$(find "$OUT/fetch" -name "*.db
 python tools/rocprof_summary.py stats "$S" > "$OUT/kernel_stats.txt" 2>&1
 python tools/rocprof_summary.py pmc "$F" > "$OUT/pmc_fetch.txt" 2>&1
 python tools/rocprof_summary.py pmc "$W" > "$OUT/pmc_write.txt" 2>&1
-python tools/rocprof_summary.py hbmjson "$F" "$W" > "$OUT/pmc_hbm.json" 2>&1
+python tools/rocprof_summary.py hbmjson "$F" "$W" 2.0 1.0 > "$OUT/pmc_hbm.json" 2>&1  # factors: tools/hbm_calib
 tail -1 "$OUT/bench_stats.json" | cut -c1-300
 head -20 "$OUT/kernel_stats.txt"

@@ -93,25 +93,30 @@ def hbmjson(fetch_db, write_db, f_fetch=2.0, f_write=1.0):
 
 
 def hbmtable(specs):
-    """specs: tag=path/to/pmc_hbm.json ... -> the per-kernel HBM traffic / bandwidth table."""
+    """specs: tag=path/to/pmc_hbm.json ... -> the per-kernel fabric traffic / bandwidth table."""
     import json
-    out = ["# HBM traffic per launch and bandwidth per kernel, from the rocprofv3 PMC passes in this directory",
-           "# (r01_<cfg>_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB per dispatch).",
-           "# 'corrected' doubles FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads,",
-           "# MI355X_MICROARCH.md HBM section); 'raw' takes both counters as reported. Durations are",
-           "# those of the profiled (counter-collecting) runs. Peak 8000 GB/s."]
+    out = ["# Fabric traffic per launch and bandwidth per kernel, from the rocprofv3 PMC passes in this directory",
+           "# (<round>_<cfg>_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB per dispatch).",
+           "# 'calibrated' = 2 x FETCH_SIZE + 1 x WRITE_SIZE: the factors tools/hbm_calib measured on this",
+           "# hardware for byte / dword / dwordx2 / dwordx4 streaming (profiles/*_hbm_calibration.txt: FETCH_SIZE",
+           "# reports half the bytes at every width, WRITE_SIZE all of them; a scattered 4-byte access moves a",
+           "# 32-byte sector). 'raw' takes both counters as reported. These are memory-side request counters:",
+           "# Infinity-Cache hits are counted, and the working sets here (<= ~100 MB) fit the 256 MiB cache, so",
+           "# this is fabric traffic, an upper bound on HBM traffic. Durations are those of the profiled",
+           "# (counter-collecting) runs. Peak 8000 GB/s."]
     for spec in specs:
         tag, path = spec.split("=", 1)
         ks = json.load(open(path))["kernels"]
         out += ["", tag, "  %-26s %10s %10s %9s %16s %16s" % ("kernel", "fetch KB", "write KB", "avg us",
-                                                               "raw GB/s (%pk)", "corr. GB/s (%pk)")]
+                                                               "raw GB/s (%pk)", "calib GB/s (%pk)")]
         rows = [(k, v) for k, v in ks.items() if not k.startswith("__amd")]
-        rows.sort(key=lambda kv: -(2 * kv[1]["fetch_kb"] + kv[1]["write_kb"]))
+        rows.sort(key=lambda kv: -(2 * kv[1].get("fetch_kb", 0) + kv[1].get("write_kb", 0)))
         for k, v in rows:
-            raw = (v["fetch_kb"] + v["write_kb"]) * 1024 / v["avg_ns"]
-            cor = (2 * v["fetch_kb"] + v["write_kb"]) * 1024 / v["avg_ns"]
+            f, w = v.get("fetch_kb", 0.0), v.get("write_kb", 0.0)
+            raw = (f + w) * 1024 / v["avg_ns"]
+            cor = (2 * f + w) * 1024 / v["avg_ns"]
             out.append("  %-26s %10.0f %10.0f %9.1f %9.0f (%4.1f%%) %9.0f (%4.1f%%)" % (
-                k, v["fetch_kb"], v["write_kb"], v["avg_ns"] / 1e3, raw, raw / 80.0, cor, cor / 80.0))
+                k, f, w, v["avg_ns"] / 1e3, raw, raw / 80.0, cor, cor / 80.0))
     return "\n".join(out)
 
 

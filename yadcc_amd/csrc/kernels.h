@@ -886,7 +886,7 @@ struct RunningArgs {
   uint32_t n_servants;
   uint32_t* running_out;  // running + taken
   uint32_t* out_a;        // nullable: the caller's copy
-  uint32_t* out_b;        // nullable: the resident column itself (COMMIT)
+  uint32_t* out_b;        // nullable: a second copy (never the resident column: see k_finalize)
   uint32_t* taken_out;    // nullable: multi-GPU, this rank's slot delta
 };
 
@@ -955,8 +955,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
         taken -= taken_until(sv, ra, owner, s, c, nproc, load, mt, running, fl, ra.start_state[c]);
     }
     // When the passes have not converged yet this writes running unchanged everywhere and
-    // the launch is repeated later. out_b may be the resident column itself (same index read
-    // and written by this thread only).
+    // the launch is repeated later. None of the outputs may alias sv.running: taken_until
+    // reads the running value of OTHER servants (the head of the class list).
     const uint32_t v = running + taken;
     ra.running_out[s] = v;
     if (ra.out_a) ra.out_a[s] = v;

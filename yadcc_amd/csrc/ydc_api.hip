@@ -180,6 +180,17 @@ struct ydc_context {
     const void* src = nullptr;
     size_t bytes = 0;
   } post_copy;  // D2H copy to enqueue after every finalise of the current batch (bytes == 0: none)
+  // ydc_dispatch: the request columns are only needed by the classification, so the slot
+  // generation and the sort are enqueued first and run while the host stages the columns and
+  // the H2D copy travels on a stream of its own (stage_host_requests).
+  struct {
+    bool active = false;
+    const ydc_task_soa* tk = nullptr;
+    uint32_t n = 0;
+    size_t col = 0, bytes = 0;
+  } host_in;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_ev = nullptr;
   DevBuf<uint32_t> d_out_idx, d_upd_idx;
   DevBuf<ydc_servant_row> d_upd_rows;
 
@@ -501,6 +512,8 @@ int ydc_destroy(ydc_context* c) {
   if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_rel) (void)hipHostFree(c->h_rel);
   if (c->h_rel_ev) (void)hipEventDestroy(c->h_rel_ev);
+  if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h_res) (void)hipHostFree(c->h_res);
   c->d_in.release();
   c->d_res.release();
@@ -1048,7 +1061,31 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
   return YDC_OK;
 }
 
+// Host columns -> pinned arena -> device mirror, on the copy stream; the dispatch stream waits
+// for the copy (only the kernels behind this point read the columns).
+int stage_host_requests(ydc_context* c) {
+  auto& h = c->host_in;
+  std::memcpy(c->h_in, h.tk->env_id, (size_t)h.n * 4);
+  std::memcpy(c->h_in + h.col, h.tk->min_version, (size_t)h.n * 4);
+  std::memcpy(c->h_in + 2 * h.col, h.tk->requestor_ip, (size_t)h.n * 4);
+  HIP_TRY(c, hipMemcpyAsync(c->d_in.p, c->h_in, h.bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(c, hipEventRecord(c->copy_ev, c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+  return YDC_OK;
+}
+
 int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
+  if (c->host_in.active && p.N) {
+    // Host-buffer entry point: everything that does not read the requests first.
+    enqueue_scan(c, p, c->d_cls_begin.p);
+    enqueue_gen(c, p, tk, true, false);
+    if (int rc = enqueue_sort(c, p, false)) return rc;
+    if (int rc = stage_host_requests(c)) return rc;
+    enqueue_gen(c, p, tk, false, true);
+    PrefixArgs pa{c->d_chunk_consuming.p, p.K, c->d_before.p, c->n_parts};
+    YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, c->stream, pa, c->d_prm.p);
+    return enqueue_front_b(c, p, nullptr);
+  }
   if (int rc = enqueue_front_a(c, p, tk)) return rc;
   return enqueue_front_b(c, p, nullptr);
 }
@@ -1095,14 +1132,19 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   ra.n_servants = S;
   ra.running_out = c->d_running_out.p;
   ra.out_a = d_out_running;
-  // (COMMIT: the resident column itself; when the passes have not converged yet the launch
-  // writes running unchanged everywhere and is repeated later.)
-  ra.out_b = (flags & YDC_DISPATCH_COMMIT) ? c->d_running.p : nullptr;
+  // The resident column is NOT written by this launch: its servant threads read the running
+  // value of other servants (the head of their class list), so COMMIT is a copy behind it.
+  ra.out_b = nullptr;
   ra.taken_out = d_taken;
   YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(req_blocks + srv_blocks), dim3(256), 0, c->stream, p.sv,
              c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N, p.wave_path ? 1u : 0u,
              d_out_idx, d_out_util, check_slot, c->d_prm.p, p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu,
              req_blocks, ra, p.rank_stride);
+  // COMMIT (`++pick->running_tasks`, task_dispatcher.cc:123): running_out -> the resident column.
+  // When the passes have not converged yet running_out == running and the step is repeated.
+  if ((flags & YDC_DISPATCH_COMMIT) && S)
+    HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4, hipMemcpyDeviceToDevice,
+                              c->stream));
   return YDC_OK;
 }
 
@@ -1302,12 +1344,15 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
   HIP_TRY(c, pinned(&c->h_res, &c->h_res_cap, res_bytes));
   HIP_TRY(c, c->d_in.reserve(std::max<size_t>(in_bytes, 256)));
   HIP_TRY(c, c->d_res.reserve(std::max<size_t>(res_bytes, 256)));
-  if (N) {
-    std::memcpy(c->h_in, tk->env_id, (size_t)N * 4);
-    std::memcpy(c->h_in + col, tk->min_version, (size_t)N * 4);
-    std::memcpy(c->h_in + 2 * col, tk->requestor_ip, (size_t)N * 4);
-    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
-  }
+  if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+  // The columns are staged and copied inside the batch, behind the launches that do not need
+  // them (enqueue_front / stage_host_requests).
+  c->host_in.active = N != 0;
+  c->host_in.tk = tk;
+  c->host_in.n = N;
+  c->host_in.col = col;
+  c->host_in.bytes = in_bytes;
   ydc_task_soa d{(const uint32_t*)c->d_in.p, (const uint32_t*)(c->d_in.p + col),
                  (const uint32_t*)(c->d_in.p + 2 * col)};
   c->post_copy.dst = c->h_res;
@@ -1317,6 +1362,7 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
                                out_util ? (double*)(c->d_res.p + o_util) : nullptr,
                                out_running && S ? (uint32_t*)(c->d_res.p + o_run) : nullptr);
   c->post_copy.bytes = 0;
+  c->host_in.active = false;
   if (rc) return rc;
   // ydc_dispatch_device has waited for the stream: the results are in the pinned arena.
   if (N) std::memcpy(out_idx, c->h_res, (size_t)N * 4);
