@@ -146,7 +146,7 @@ def stream_main(args):
     # captured step is one graph launch, so the "dominant kernel" is the step itself.
     alg = 16 * 10_000 + 40 * es.n
     tick_s = sum(lat) / len(lat)
-    out["roofline"] = {"bound": "hbm", "kernel": "captured step (17 graph nodes)",
+    out["roofline"] = {"bound": "hbm", "kernel": "captured step (one hipGraph launch)",
                        "achieved": alg / tick_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                        "frac": alg / tick_s / 8e12, "traffic": None,
                        "algorithmic_bytes_per_launch": alg, "avg_launch_us": tick_s * 1e6}
