@@ -136,14 +136,18 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
                                                        uint32_t max_slots, uint32_t* slot_base,
                                                        uint32_t* cls_begin, uint32_t* chunk_consuming,
                                                        uint32_t n_chunks, PartTable parts,
+                                                       uint32_t tile_size, uint32_t* tile_first,
                                                        DeviceParams* prm) {
   // Per-batch reset of the request-side counters (saves a memset launch).
   for (uint32_t k = threadIdx.x; k < n_chunks * parts.n_parts; k += blockDim.x) chunk_consuming[k] = 0;
   __shared__ uint32_t lds[17];
-  __shared__ uint32_t carry;
+  __shared__ uint32_t carry, last_with_slots;
   extern __shared__ uint32_t cls_cnt[];  // n_classes + 1
   for (uint32_t c = threadIdx.x; c <= n_classes; c += blockDim.x) cls_cnt[c] = 0;
-  if (threadIdx.x == 0) carry = 0;
+  if (threadIdx.x == 0) {
+    carry = 0;
+    last_with_slots = 0;
+  }
   __syncthreads();
   // A servant's six columns are fetched together, one slab of servants ahead of the scan
   // that uses them (unconditional loads at a clamped index: one round trip per slab, and it
@@ -158,6 +162,8 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     if (s >= sv.n) r.cls = kNone;
     return r;
   };
+  const uint32_t tile_shift = 31 - (uint32_t)__clz((int)tile_size), tile_mask = tile_size - 1;
+  uint32_t my_last = 0;
   Row next = fetch(threadIdx.x);
   for (uint32_t s0 = 0; s0 < sv.n; s0 += blockDim.x) {
     const uint32_t s = s0 + threadIdx.x;
@@ -172,16 +178,34 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
     uint32_t base = carry + ex;
     if (s < sv.n) {
       slot_base[s] = base;
-      if (k) atomicAdd(&cls_cnt[cls], k);
+      if (k) {
+        atomicAdd(&cls_cnt[cls], k);
+        my_last = s;  // (ascending per thread)
+        // tile_first[t] = owner of the first slot of sort tile t (k_slot_gen would otherwise
+        // find it with a dependent binary search over slot_base): the tiles that start inside
+        // this servant's slots. Tiles are 2^tile_shift slots.
+        if (tile_first)
+          for (uint32_t t = (base + tile_mask) >> tile_shift; ((uint64_t)t << tile_shift) < (uint64_t)base + k; ++t)
+            tile_first[t] = s;
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
   if (threadIdx.x < 64) prm->n_changed[threadIdx.x] = prm->n_sampled[threadIdx.x] = 0;
+  if (tile_first) {  // last servant that has slots: one LDS atomic per wave
+    uint32_t v = my_last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(&last_with_slots, v);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     uint32_t m = carry;
     slot_base[sv.n] = m;
+    // (behind the last tile: the last servant that has slots, as the end of that tile's run)
+    if (tile_first && m <= max_slots) tile_first[(m + tile_mask) >> tile_shift] = last_with_slots;
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->reserved0 = 0;
@@ -372,7 +396,8 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   uint32_t items, uint32_t bits0, uint32_t fused0,
                                                   uint32_t gbits, uint32_t* hist, ClassifyArgs ca,
                                                   uint32_t comp_shift, const uint32_t* r_first,
-                                                  const uint32_t* gslot_base, uint32_t packed) {
+                                                  const uint32_t* gslot_base, uint32_t packed,
+                                                  const uint32_t* tile_first) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
@@ -390,8 +415,13 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
   const uint32_t tile = blockIdx.x, base = tile * (blockDim.x * items);
   const uint32_t g_end = min(M, base + blockDim.x * items);  // (base >= M: nothing to generate)
   if (base < M) {
-    if (threadIdx.x == 0) run_ends[0] = owner_of_slot(slot_base, sv.n, base);
-    if (threadIdx.x == 64) run_ends[1] = owner_of_slot(slot_base, sv.n, g_end - 1);
+    if (tile_first) {  // (k_servant_scan left the owners of the tiles' first slots behind)
+      if (threadIdx.x == 0) run_ends[0] = tile_first[tile];
+      if (threadIdx.x == 64) run_ends[1] = tile_first[tile + 1];  // >= the owner of slot g_end - 1
+    } else {
+      if (threadIdx.x == 0) run_ends[0] = owner_of_slot(slot_base, sv.n, base);
+      if (threadIdx.x == 64) run_ends[1] = owner_of_slot(slot_base, sv.n, g_end - 1);
+    }
   }
   __syncthreads();
   const uint32_t s_first = base < M ? run_ends[0] : 0;

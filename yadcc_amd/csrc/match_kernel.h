@@ -280,14 +280,19 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_MAXDPP(first, ctrl) "v_max_u32_dpp %[t], " first " " ctrl " bound_ctrl:0\n"
 #define YDC_GAP "s_nop 1\n"
 #define YDC_RED_1(K) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")
-#define YDC_RED_2(K) YDC_RED_1(K) "v_readlane_b32 s91, %[mhi], %[ip]\ns_nop 0\n" \
+// HI: how the upper mask word of the next request gets into s91 in the gap behind the first
+// step — a v_readlane, or nothing at all with <= 32 classes (the word is always 0 and s91
+// stays 0: one VALU instruction less per request in a loop that is bound by VALU issue).
+#define YDC_HI_READ "v_readlane_b32 s91, %[mhi], %[ip]\ns_nop 0\n"
+#define YDC_HI_ZERO "s_nop 1\n"
+#define YDC_RED_2(K, HI) YDC_RED_1(K) HI \
   YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")
-#define YDC_RED_3(K) YDC_RED_2(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:4 row_mask:0xf bank_mask:0xf")
-#define YDC_RED_4(K) YDC_RED_3(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:8 row_mask:0xf bank_mask:0xf")
-#define YDC_RED_5(K) YDC_RED_4(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
-#define YDC_RED_6(K) YDC_RED_5(K) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:31 row_mask:0xc bank_mask:0xf")
-// With one step the second mask word has no gap to hide in.
-#define YDC_TAILFILL_1 "v_readlane_b32 s91, %[mhi], %[ip]\n"
+#define YDC_RED_3(K, HI) YDC_RED_2(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:4 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_4(K, HI) YDC_RED_3(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define YDC_RED_5(K, HI) YDC_RED_4(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+#define YDC_RED_6(K, HI) YDC_RED_5(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+// With one step there is no gap to hide anything in (one wait state before the v_readlane).
+#define YDC_TAILFILL_1 "s_nop 0\n"
 #define YDC_TAILFILL_N "s_nop 0\n"
 
 // Two requests per iteration (>= 5 classes): the two selections and DPP chains are
@@ -302,16 +307,18 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   YDC_MAX2("%[t]", "%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")              \
   "v_readlane_b32 s90, %[mlo], %[ip]\n"                                               \
   YDC_MAX2("%[t1]", "%[c1], %[c1]", "row_shr:1 row_mask:0xf bank_mask:0xf")
-#define YDC_P2                                                                        \
+#define YDC_P2(HIFILL)                                                                \
   YDC_MAX2("%[t]", "%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")              \
-  "v_readlane_b32 s91, %[mhi], %[ip]\n"                                               \
+  HIFILL                                                                              \
   YDC_MAX2("%[t1]", "%[t1], %[t1]", "row_shr:2 row_mask:0xf bank_mask:0xf")
 #define YDC_PN(ctrl)                                                                  \
   YDC_MAX2("%[t]", "%[t], %[t]", ctrl) "s_nop 0\n" YDC_MAX2("%[t1]", "%[t1], %[t1]", ctrl)
-#define YDC_PRED_3 YDC_P1 YDC_P2 YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf")
-#define YDC_PRED_4 YDC_PRED_3 YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf")
-#define YDC_PRED_5 YDC_PRED_4 YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf")
-#define YDC_PRED_6 YDC_PRED_5 YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define YDC_P2_HI "v_readlane_b32 s91, %[mhi], %[ip]\n"
+#define YDC_P2_ZERO "s_nop 0\n"
+#define YDC_PRED_3(F) YDC_P1 YDC_P2(F) YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf")
+#define YDC_PRED_4(F) YDC_PRED_3(F) YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf")
+#define YDC_PRED_5(F) YDC_PRED_4(F) YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf")
+#define YDC_PRED_6(F) YDC_PRED_5(F) YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf")
 #define YDC_COMMIT                                                                    \
   "s_waitcnt lgkmcnt(0)\n"                                                            \
   "v_mov_b32 %[hq], %[nq]\n"                                                          \
@@ -321,7 +328,9 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "ds_read_b32 %[nq], %[a]\n"                                                         \
   "v_add_u32 %[cur], 1, %[cur]\n"                                                     \
   "s_mov_b64 exec, -1\n"
-#define YDC_PAIR(K, PRED, LASTLANE)                                                   \
+#define YDC_PAIR_HI93 "v_readlane_b32 s93, %[mhi], %[ip]\n"
+#define YDC_PAIR_ZERO93 "s_mov_b32 s93, 0\n"
+#define YDC_PAIR(K, PRED, LASTLANE, HI93)                                             \
   "s_cmp_eq_u32 %[pair], 0\n"                                                         \
   "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
   "s_cmp_eq_u32 %[n], 0\n"                                                            \
@@ -331,7 +340,7 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
   "s_add_u32 %[ip], %[ip], 1\n"                                                       \
   "v_readlane_b32 s92, %[mlo], %[ip]\n"                                               \
-  "v_readlane_b32 s93, %[mhi], %[ip]\n"                                               \
+  HI93                                                                                \
   "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                          \
   "s_add_u32 %[ip], %[ip], 1\n"                                                       \
   "v_cndmask_b32 %[c1], 0, %[hq], s[92:93]\n" PRED                                    \
@@ -447,11 +456,15 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_cbranch_scc1 L5_loop%=\n"
       "s_branch L6_loop%=\n"
       YDC_LOOP_BODY(1, YDC_RED_1(1), YDC_TAILFILL_1, "1", "")
-      YDC_LOOP_BODY(2, YDC_RED_2(2), YDC_TAILFILL_N, "3", "")
-      YDC_LOOP_BODY(3, YDC_RED_3(3), YDC_TAILFILL_N, "7", YDC_PAIR(3, YDC_PRED_3, "7"))
-      YDC_LOOP_BODY(4, YDC_RED_4(4), YDC_TAILFILL_N, "15", YDC_PAIR(4, YDC_PRED_4, "15"))
-      YDC_LOOP_BODY(5, YDC_RED_5(5), YDC_TAILFILL_N, "31", YDC_PAIR(5, YDC_PRED_5, "31"))
-      YDC_LOOP_BODY(6, YDC_RED_6(6), YDC_TAILFILL_N, "63", YDC_PAIR(6, YDC_PRED_6, "63"))
+      YDC_LOOP_BODY(2, YDC_RED_2(2, YDC_HI_ZERO), YDC_TAILFILL_N, "3", "")
+      YDC_LOOP_BODY(3, YDC_RED_3(3, YDC_HI_ZERO), YDC_TAILFILL_N, "7",
+                    YDC_PAIR(3, YDC_PRED_3(YDC_P2_ZERO), "7", YDC_PAIR_ZERO93))
+      YDC_LOOP_BODY(4, YDC_RED_4(4, YDC_HI_ZERO), YDC_TAILFILL_N, "15",
+                    YDC_PAIR(4, YDC_PRED_4(YDC_P2_ZERO), "15", YDC_PAIR_ZERO93))
+      YDC_LOOP_BODY(5, YDC_RED_5(5, YDC_HI_ZERO), YDC_TAILFILL_N, "31",
+                    YDC_PAIR(5, YDC_PRED_5(YDC_P2_ZERO), "31", YDC_PAIR_ZERO93))
+      YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ), YDC_TAILFILL_N, "63",
+                    YDC_PAIR(6, YDC_PRED_6(YDC_P2_HI), "63", YDC_PAIR_HI93))
       "L_slow%=:\n"
       "s_mov_b32 %[st], 1\n"
       "L_out%=:\n"

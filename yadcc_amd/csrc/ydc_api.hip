@@ -94,7 +94,7 @@ struct ydc_context {
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
 
   // Per-batch workspace.
-  DevBuf<uint32_t> d_slot_base, d_cls_begin, d_vals[2], d_hist, d_row_total;
+  DevBuf<uint32_t> d_slot_base, d_cls_begin, d_vals[2], d_hist, d_row_total, d_tile_first;
   DevBuf<uint64_t> d_keys[2];  // viewed as u32 when the key fits
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
@@ -489,7 +489,7 @@ int ydc_destroy(ydc_context* c) {
   for (auto* b : {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
                   &c->d_flags, &c->d_class_of, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
                   &c->d_cls_comp, &c->d_part_base,
-                  &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist,
+                  &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist, &c->d_tile_first,
                   &c->d_row_total, &c->d_self_lo, &c->d_self_hi, &c->d_chunk_consuming,
                   &c->d_before, &c->d_slot_of, &c->d_pos_last, &c->d_running_out, &c->d_out_idx,
                   &c->d_upd_idx})
@@ -810,6 +810,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   }
   p.packed = p.key32 && c->opt_packed_sort;
   HIP_TRY(c, c->d_hist.reserve(((size_t)1 << kMaxRadixBits) * p.n_tiles));
+  HIP_TRY(c, c->d_tile_first.reserve((size_t)p.n_tiles + 2));
   if (C > 1) HIP_TRY(c, c->d_cls_by_g.reserve(slot_bound));
   p.key_passes = c->kf.passes;
   p.cls_passes = 0;
@@ -925,7 +926,7 @@ void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
   YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (p.C + 1) * sizeof(uint32_t),
              c->stream, p.sv, p.C, p.slot_bound_glob, c->d_slot_base.p, cls_begin,
              c->d_chunk_consuming.p, p.K, PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p},
-             c->d_prm.p);
+             kSortThreads * p.sort_items, p.win ? nullptr : c->d_tile_first.p, c->d_prm.p);
   mark(c, 1);
 }
 
@@ -964,13 +965,13 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
-               r_first, gbase, p.packed ? 1u : 0u);
+               r_first, gbase, p.packed ? 1u : 0u, p.win ? nullptr : c->d_tile_first.p);
   } else {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
-               r_first, gbase, p.packed ? 1u : 0u);
+               r_first, gbase, p.packed ? 1u : 0u, p.win ? nullptr : c->d_tile_first.p);
   }
 }
 
