@@ -271,8 +271,10 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 // default in `res`; a served request gets the global rank of its slot. The caller
 // guarantees that every ring holds at least n + 2 entries beyond its cursor.
 //
-// Registers: hq / nq = ~rank of head / next of the lane's class (0: none), `off` = ring
-// byte offset of `next`, ring_p at LDS `base`, ring_g at `gbase` (behind all of ring_p). m0 = i,
+// Registers: hq / nq = ~rank of head / next of the lane's class (0: none), `an` = LDS address
+// of `next` in the lane's ring of ring_p (rings are aligned to their size, so stepping is an
+// add + bit-field insert; the cursor is recovered from `an` by the caller), ring_g `goff` bytes
+// further (behind all of ring_p). m0 = i,
 // s[90:91] = class mask of request i (fetched one request ahead, in the wait states of
 // the DPP chain), s[92:93] scratch. One loop body per DPP depth (2^steps >= classes).
 // Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR ->
@@ -322,11 +324,9 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_COMMIT                                                                    \
   "s_waitcnt lgkmcnt(0)\n"                                                            \
   "v_mov_b32 %[hq], %[nq]\n"                                                          \
-  "v_add_u32 %[off], 4, %[off]\n"                                                     \
-  "v_and_b32 %[off], %[rmask4], %[off]\n"                                             \
-  "v_add_u32 %[a], %[base], %[off]\n"                                                 \
-  "ds_read_b32 %[nq], %[a]\n"                                                         \
-  "v_add_u32 %[cur], 1, %[cur]\n"                                                     \
+  "v_add_u32 %[a], 4, %[an]\n"                                                        \
+  "v_bfi_b32 %[an], %[rmask4], %[a], %[an]\n"                                         \
+  "ds_read_b32 %[nq], %[an]\n"                                                        \
   "s_mov_b64 exec, -1\n"
 #define YDC_PAIR_HI93 "v_readlane_b32 s93, %[mhi], %[ip]\n"
 #define YDC_PAIR_ZERO93 "s_mov_b32 s93, 0\n"
@@ -396,11 +396,9 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "s_mov_b64 exec, vcc\n"                                                          \
   "s_waitcnt lgkmcnt(0)\n"                                                         \
   "v_mov_b32 %[hq], %[nq]\n"                                                       \
-  "v_add_u32 %[off], 4, %[off]\n"                                                  \
-  "v_and_b32 %[off], %[rmask4], %[off]\n"                                          \
-  "v_add_u32 %[a], %[base], %[off]\n"                                              \
-  "ds_read_b32 %[nq], %[a]\n"                                                      \
-  "v_add_u32 %[cur], 1, %[cur]\n"                                                  \
+  "v_add_u32 %[a], 4, %[an]\n"                                                     \
+  "v_bfi_b32 %[an], %[rmask4], %[a], %[an]\n"                                      \
+  "ds_read_b32 %[nq], %[an]\n"                                                     \
   "s_mov_b64 exec, -1\n"                                                           \
   "v_writelane_b32 %[res], %[sp], m0\n"                                            \
   "L" #K "_next%=:\n"                                                              \
@@ -417,10 +415,10 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "s_cbranch_scc1 L_slow%=\n"                                                      \
   "v_readlane_b32 %[s0], %[slo], m0\n"                                             \
   "v_readlane_b32 %[s1], %[shi], m0\n"                                             \
-  "v_add_u32 %[a], -4, %[off]\n"                                                   \
-  "v_and_b32 %[a], %[rmask4], %[a]\n"                                              \
-  "v_add_u32 %[a], %[base], %[a]\n"                                                \
-  "ds_read_b32 %[a], %[a] offset:8192\n"                                           \
+  "v_add_u32 %[a], -4, %[an]\n"                                                    \
+  "v_bfi_b32 %[a], %[rmask4], %[a], %[an]\n"                                       \
+  "v_add_u32 %[a], %[goff], %[a]\n"                                                \
+  "ds_read_b32 %[a], %[a]\n"                                                       \
   "s_sub_u32 %[s1], %[s1], %[s0]\n"                                                \
   "s_waitcnt lgkmcnt(0)\n"                                                         \
   "v_subrev_u32 %[a], %[s0], %[a]\n"                                               \
@@ -432,8 +430,7 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 __device__ __forceinline__ uint32_t match_fast_loop(
     uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
     uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& res, uint32_t& hq,
-    uint32_t& nq, uint32_t& cur, uint32_t off, uint32_t base, uint32_t gbase, uint32_t rmask4,
-    uint32_t steps, uint32_t pair) {
+    uint32_t& nq, uint32_t& an, uint32_t goff, uint32_t rmask4, uint32_t steps, uint32_t pair) {
   uint32_t status, c, t, c1, t1, a, mn, sp, ip, s0, s1, m0save;
   asm volatile(
       "s_mov_b32 %[m0s], m0\n"
@@ -472,11 +469,11 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b32 m0, %[m0s]\n"
       : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hq] "+v"(hq), [nq] "+v"(nq),
-        [cur] "+v"(cur), [off] "+v"(off), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
+        [an] "+v"(an), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
         [a] "=&v"(a), [mn] "=&s"(mn),
         [sp] "=&s"(sp), [ip] "=&s"(ip), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
       : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [special] "s"(special),
-        [hh] "s"(hole_hit), [hs] "s"(has_self), [base] "v"(base), [gbase] "v"(gbase), [rmask4] "s"(rmask4),
+        [hh] "s"(hole_hit), [hs] "s"(has_self), [goff] "s"(goff), [rmask4] "s"(rmask4),
         [steps] "s"(steps), [pair] "s"(pair)
       : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
   return status;
@@ -911,8 +908,10 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
 
       if constexpr (W == 1) {
         LaneClass& q = w.k[0];
+        // (The rings start at LDS address 0 — the kernel has no static LDS — so every ring is
+        // aligned to its size, which the address stepping of the loop relies on.)
+        if ((uint32_t)(uintptr_t)lds_ring & ((ring_total << 2) - 1)) __builtin_trap();
         const uint32_t base = (uint32_t)(uintptr_t)lds_ring + ((lane << rshift) << 2);
-        const uint32_t gbase = base + (ring_total << 2);
         const uint32_t rmask4 = (R << 2) - 1;
         const uint64_t my_mask = ((uint64_t)mhi[0] << 32) | mlo[0];
         uint32_t i = 0;
@@ -922,14 +921,17 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         while (i < lim) {
           const uint32_t budget = top_up();
           const uint32_t n = min(lim - i, budget);
-          const uint32_t off = ((q.cursor + 1) & w.rmask) << 2;  // ring offset of `next`
+          const uint32_t an0 = base + (((q.cursor + 1) & w.rmask) << 2);  // address of `next`
+          uint32_t an = an0;
           // Requests that need a look before the plain step: an eligible class has holes, or
           // the requestor's host runs several servants (`self` is resolved in the general step).
           const uint64_t hole_hit = (holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull) | dyn_self;
           const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
-                                              hole_hit, has_self, res, q.hq, q.nq, q.cursor, off,
-                                              base, gbase, rmask4, steps,
+                                              hole_hit, has_self, res, q.hq, q.nq, an, ring_total << 2,
+                                              rmask4, steps,
                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode));
+          // Picks of this lane's class in the call (fewer than the ring holds): how far `next` moved.
+          q.cursor += ((an - an0) & rmask4) >> 2;
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
           if (st == 1) {
