@@ -223,13 +223,35 @@ def main():
     ctx.upload_servants(pack.to_abi_columns(sv))
     group_note = None
     sharded = False
+    init_thread = None
     rccl_ranks, is_rccl = 0, False
     if use_dist:
+        # One node: RCCL's bootstrap only has to find the loopback interface (probing the other
+        # interfaces / InfiniBand takes minutes on some boxes); the data path is xGMI / P2P.
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         try:
             ids = [binding.group_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            ctx.group_init(ids[0], rank, world)
-            sharded = True
+            # The communicator bootstrap is a blocking C call: give it a deadline instead of
+            # hanging the whole scaling run (the thread is abandoned if it never returns).
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    ctx.group_init(ids[0], rank, world)
+                    box["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = e
+
+            th = init_thread = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
+            if box.get("ok"):
+                sharded = True
+            else:
+                raise RuntimeError(box.get("err") or "ncclCommInitRank did not return in time")
         except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
             group_note = "RCCL group init failed (%s): ranks ran independent batches" % e
         flags = [1 if sharded else 0]
@@ -394,9 +416,11 @@ def main():
         line = json.dumps(out)
     else:
         line = None
+    stuck = init_thread is not None and init_thread.is_alive()  # still inside ncclCommInitRank
     if sharded:
         ctx.group_destroy()
-    ctx.close()
+    if not stuck:
+        ctx.close()
     # ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C
     # stdio, which would otherwise be flushed behind it at exit. Every rank flushes before the
     # last barrier; rank 0 prints after it.
@@ -408,6 +432,8 @@ def main():
         dist.destroy_process_group()
     if line:
         print(line, flush=True)
+    if stuck:
+        os._exit(0)  # (do not tear the context down under a bootstrap that never returned)
 
 
 def pmc_traffic(kernel, config):

@@ -10,7 +10,7 @@ timeout 300 python bench.py --config cfg3 --steps 300 --warmup 20 > $O/bench_cfg
 if [ "$MODE" = full ]; then
 timeout 300 python bench.py --config cfg4 --steps 100 --warmup 10 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 timeout 300 python bench.py --config cfg5 --steps 1000 --warmup 50 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
-YDC_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 200 --warmup 20 > $O/bench_dist1.json 2> $O/bench_dist1.err
+YDC_BENCH_FORCE_DIST=1 YDC_BENCH_RCCL_TIMEOUT=60 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 200 --warmup 20 > $O/bench_dist1.json 2> $O/bench_dist1.err
 fi
 cat $O/pytest.log
 python - $O <<'PY'

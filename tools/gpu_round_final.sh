@@ -9,7 +9,7 @@ timeout 300 python bench.py --shared-ip-frac 0.05 --steps 2000 --warmup 100 --no
 timeout 300 python bench.py --config cfg3 --steps 500 --warmup 20 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 timeout 300 python bench.py --config cfg4 --steps 200 --warmup 10 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 timeout 300 python bench.py --config cfg5 --steps 1000 --warmup 50 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
-YDC_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 500 --warmup 20 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err
+YDC_BENCH_FORCE_DIST=1 YDC_BENCH_RCCL_TIMEOUT=60 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 500 --warmup 20 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err
 timeout 200 bash tools/profile.sh cfg2 > $O/profile_cfg2.log 2>&1
 timeout 300 bash tools/profile.sh cfg3 --config cfg3 > $O/profile_cfg3.log 2>&1
 (timeout 120 tools/td_native_bench 2>&1 | tail -12) > $O/td_native_bench.log
