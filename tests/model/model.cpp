@@ -91,6 +91,7 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
   L.list_g = list_g.data();
   L.cls_begin = cls_begin.data();
   L.n_classes = C;
+  L.cls_single = T.cls_single.data();
 
   // --- task classification.
   const uint32_t W = std::max<uint32_t>(1, (C + 63) / 64);

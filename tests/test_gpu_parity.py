@@ -105,6 +105,16 @@ def test_cfg2_hosts_with_several_servants(ctx, frac):
     assert st["n_chunks"] > 100  # not one sequential chunk
 
 
+def test_tiny_pool_with_huge_servants_and_own_host_traffic(ctx):
+    """Five servants with tens of thousands of slots each, one per class, a tenth of the requests
+    from their own hosts (every start state has holes: about one pass per chunk — exact, and
+    quick since a one-servant class is known to hold nothing but own slots)."""
+    sv, tk = cases.random_case(seed=2009, n_tasks=150_000, n_servants=5, n_envs=3, self_frac=0.1,
+                               unknown_env_frac=0.01, initial_running=True)
+    st = check(ctx, sv, tk)
+    assert st["n_chunks"] > 1000
+
+
 def test_cfg2_oversubscribed(ctx):
     sv, tk = synth.make_config("cfg2", oversubscribed=True)
     st = check(ctx, sv, tk)

@@ -58,3 +58,16 @@ def test_closed_form_slot_count_below_a_key():
     """first_slot_not_below (the per-servant count behind the key windows of the multi-GPU
     path) against a walk over the servant's slots, 1M random servants / keys."""
     assert M.lib().model_check_first_slot(7, 1_000_000) == 0
+
+
+def test_tiny_pool_with_huge_servants_and_own_host_traffic():
+    """Five servants with tens of thousands of slots each, one servant per class, a tenth of the
+    requests from the servants' own hosts: a request from a host whose servant IS its class
+    must not walk that servant's whole slot list to find out that nothing else is there
+    (ClassLists::cls_single) — this batch took minutes before and takes a fraction of a second."""
+    import time
+    sv, tk = cases.random_case(seed=2009, n_tasks=150_000, n_servants=5, n_envs=3, self_frac=0.1,
+                               unknown_env_frac=0.01, initial_running=True)
+    t0 = time.time()
+    _check(sv, tk, 64)
+    assert time.time() - t0 < 30

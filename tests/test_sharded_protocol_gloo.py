@@ -61,7 +61,9 @@ def _rank_main(rank, world, port, case_kw, cuts, chunk, ret):
         passes = 0
         while True:
             out_end = np.zeros(nc * 4, dtype=np.uint32)
-            bin_ = None if (rank == 0 or bounds is None) else p(bounds[rank - 1])
+            # the nearest rank below that has requests (ranks without requests are transparent)
+            pred = max([q for q in range(rank) if cuts[q + 1] > cuts[q]], default=None)
+            bin_ = None if (pred is None or bounds is None) else p(bounds[pred])
             busy = L.model_shard_pass(h, C.c_uint32(passes), p(base), bin_, p(out_end))
             rec = torch.from_numpy(np.concatenate([out_end, np.array([busy], np.uint32)]).astype(np.int64))
             got = [torch.zeros_like(rec) for _ in range(world)]

@@ -283,6 +283,7 @@ struct ClassLists {
   const uint32_t* cls_begin;  // [n_classes + 1]
   uint32_t n_classes;
   uint32_t stride = 1;
+  const uint8_t* cls_single = nullptr;  // [n_classes] the class is one servant's (nullable)
 };
 
 // Consumption state of one class: everything below `cursor` is consumed except
@@ -323,6 +324,7 @@ struct ClassRun {
   uint32_t end;     // cls_begin[c + 1]
   uint32_t head_p;  // rank / generation index of the entry at `cursor`
   uint32_t head_g;  // (kNone when the class is exhausted)
+  uint32_t single;  // the class consists of one servant (ClassLists::cls_single)
 };
 
 YDC_HD uint32_t list_rank(const ClassLists& L, uint32_t i) {
@@ -352,6 +354,7 @@ YDC_HD void class_run_init(const ClassLists& L, uint32_t c, const ClassState& st
   r.hown_lo = start.hown_lo;
   r.hown_hi = start.hown_hi;
   r.end = e;
+  r.single = L.cls_single ? L.cls_single[c] : 0u;
   class_load_head(L, r);
 }
 
@@ -381,6 +384,9 @@ YDC_HD bool class_candidate(const ClassLists& L, const ClassRun& r, uint32_t sel
   ci = r.cursor;
   cp = r.head_p;
   cg = r.head_g;
+  // One servant's class and it is the requestor's own: nothing but own slots to walk over
+  // (the reference looks at servants, not slots: task_dispatcher.cc:372-380 drops `self` once).
+  if (r.single && ci < r.end && cg >= self_lo && cg < self_hi) return false;
   while (ci < r.end && cg >= self_lo && cg < self_hi) {
     ++ci;
     if (ci < r.end) {

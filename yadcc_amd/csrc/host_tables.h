@@ -47,6 +47,9 @@ struct HostTables {
   // partitions every part is consumed at its own requests' rate, not at the global one.
   std::vector<uint32_t> cls_comp;
   uint32_t n_comp = 1;
+  // 1: the class consists of ONE servant. A request from that servant's host then has no
+  // candidate in the class at all (every entry is its own) — known without walking the list.
+  std::vector<uint8_t> cls_single;
   uint32_t cap_bits = 1;            // max over servants of bits(min(max_tasks, nproc))
   uint64_t max_slots = 0;           // sum over servants of min(max_tasks, nproc): bound on slots
 
@@ -94,6 +97,13 @@ struct HostTables {
       uint32_t top = std::min(max_tasks[s], nproc[s]);
       max_cap = std::max(max_cap, top);
       max_slots += top;
+    }
+    {
+      std::vector<uint32_t> members(cls_ver.size(), 0);
+      for (uint32_t s = 0; s < n; ++s)
+        if (class_of[s] != kNone) members[class_of[s]]++;
+      cls_single.assign(cls_ver.size(), 0);
+      for (size_t c = 0; c < members.size(); ++c) cls_single[c] = members[c] == 1;
     }
     cap_bits = 1;
     while (cap_bits < 32 && (max_cap >> cap_bits)) ++cap_bits;

@@ -1025,18 +1025,33 @@ __global__ __launch_bounds__(256) void k_release_slots(const uint32_t* servant_i
 // ---------------------------------------------------------------------------
 // Multi-GPU helpers (rank-range sharding of one batch).
 // ---------------------------------------------------------------------------
-// base[g] = consuming requests of part g on the ranks before `rank` (totals[r * n_parts + g]).
-__global__ void k_rank_base(const uint32_t* totals, uint32_t rank, uint32_t n_parts, uint32_t* base) {
+// What every rank tells the others before the batch (all-gathered, `stride` = n_parts + 1 words
+// per rank): consuming requests per part of the registry, then its number of requests.
+__global__ void k_rank_meta(const uint32_t* before_totals, uint32_t n_parts, uint32_t n_requests,
+                            uint32_t* meta) {
+  if (blockIdx.x == 0 && threadIdx.x <= n_parts)
+    meta[threadIdx.x] = threadIdx.x < n_parts ? before_totals[threadIdx.x] : n_requests;
+}
+// The nearest rank below `rank` that has requests (-1: none). Ranks without requests are
+// transparent: nobody reads what they publish, so they add no hop to the chain of end states.
+__device__ __forceinline__ int rank_predecessor(const uint32_t* meta, uint32_t stride, uint32_t rank) {
+  for (int q = (int)rank - 1; q >= 0; --q)
+    if (meta[(size_t)q * stride + stride - 1] != 0) return q;
+  return -1;
+}
+// base[g] = consuming requests of part g on the ranks before `rank` (meta[r * stride + g]).
+__global__ void k_rank_base(const uint32_t* meta, uint32_t rank, uint32_t n_parts, uint32_t stride,
+                            uint32_t* base) {
   if (threadIdx.x < n_parts && blockIdx.x == 0) {
     uint32_t acc = 0;
-    for (uint32_t r = 0; r < rank; ++r) acc += totals[(size_t)r * n_parts + threadIdx.x];
+    for (uint32_t r = 0; r < rank; ++r) acc += meta[(size_t)r * stride + threadIdx.x];
     base[threadIdx.x] = acc;
   }
 }
-// What a rank publishes after a matching pass: the end state of its last chunk (C
-// entries; a rank without requests passes its predecessor's on, rank 0 the state before
-// the first request) followed by one entry whose cursor is the number of chunks the pass
-// found inconsistent.
+// What a rank publishes after a matching pass: the end state of its last chunk (C entries; a
+// rank without requests publishes its start state, which nobody reads — such ranks are
+// transparent, see rank_predecessor) followed by one entry whose cursor is the number of
+// chunks the pass found inconsistent.
 // shift (nullable; sharded sort): list positions are local to the rank's key window; what is
 // published is the position in the whole registry's lists, local + shift[c].
 __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const ClassState* endst,
@@ -1072,9 +1087,17 @@ __global__ __launch_bounds__(256) void k_pack_boundary(ClassLists L, const Class
 // After the all-gather of a pass's records: the pass was final only if NO rank changed an end
 // state. Overwrites this rank's flag of the pass with the global one, so that the gating of
 // the pre-launched passes (and the host's single look) is the same on every rank.
-__global__ void k_global_flag(const ClassState* bounds, uint32_t rec, uint32_t n_classes,
-                              uint32_t n_ranks, uint32_t pass, DeviceParams* prm) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+// boundary_local (ranks > 0): the state this rank's first chunk continues from — the end state
+// of the nearest rank below that has requests, or the state before the first request of the
+// batch when there is none. Thread per class.
+__global__ __launch_bounds__(256) void k_global_flag(const ClassState* bounds, uint32_t rec,
+                                                     uint32_t n_classes, uint32_t n_ranks,
+                                                     uint32_t rank, uint32_t pass,
+                                                     const uint32_t* meta, uint32_t stride,
+                                                     const uint32_t* cls_begin,
+                                                     ClassState* boundary_local, DeviceParams* prm) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) {
     uint32_t any = 0, over = 0;
     for (uint32_t g = 0; g < n_ranks; ++g) {
       any |= bounds[(size_t)g * rec + n_classes].cursor;
@@ -1083,6 +1106,16 @@ __global__ void k_global_flag(const ClassState* bounds, uint32_t rec, uint32_t n
     prm->n_changed[pass & 63] = any ? 1u : 0u;
     if (over) prm->overflow = 1;
   }
+  if (c >= n_classes || rank == 0) return;
+  const int q = rank_predecessor(meta, stride, rank);
+  ClassState st;
+  if (q >= 0) {
+    st = bounds[(size_t)q * rec + c];
+  } else {
+    st.cursor = st.lo = cls_begin[c];
+    st.hown_lo = st.hown_hi = kNone;
+  }
+  boundary_local[c] = st;
 }
 // running_out[s] = running[s] + sum over ranks of delta[g][s].
 // out_a / out_b (nullable): the caller's copy and, when committing, the resident column.
@@ -1136,7 +1169,8 @@ __global__ __launch_bounds__(256) void k_key_count(ServantTable sv, uint32_t cap
 struct WindowArgs {
   const uint32_t* cum;        // k_key_count
   uint32_t cap_bits, shift;
-  const uint32_t* totals;     // consuming requests of every rank (all-gathered)
+  const uint32_t* totals;     // k_rank_meta of every rank (all-gathered), `stride` words each
+  uint32_t stride;
   uint32_t rank, n_ranks, margin;
   uint32_t max_local;         // workspace / launch bound on the slots of the window
   const uint32_t* gslot_base; // [S + 1] prefix of the slot counts of the whole registry
@@ -1163,8 +1197,8 @@ __global__ __launch_bounds__(1024) void k_window(ServantTable sv, WindowArgs a, 
     carry = 0;
     const uint32_t M = prm->n_slots;  // slots of the whole registry (k_servant_scan)
     uint32_t base = 0;
-    for (uint32_t r = 0; r < a.rank; ++r) base += a.totals[r];
-    const uint32_t n = a.totals[a.rank];
+    for (uint32_t r = 0; r < a.rank; ++r) base += a.totals[(size_t)r * a.stride];
+    const uint32_t n = a.totals[(size_t)a.rank * a.stride];
     const uint32_t want_lo = base > a.margin ? base - a.margin : 0u;
     const uint64_t want_hi64 = (uint64_t)base + n + a.margin;
     const uint32_t want_hi = want_hi64 > M ? M : (uint32_t)want_hi64;
@@ -1251,7 +1285,8 @@ __global__ __launch_bounds__(256) void k_boundary_in(const ClassState* bounds, u
                                                      uint32_t rank, uint32_t pass,
                                                      const uint32_t* winall,  // [rank][2 C]
                                                      const uint32_t* cls_begin_glob,
-                                                     const uint32_t* totals, const uint32_t* shift,
+                                                     const uint32_t* meta, uint32_t stride,
+                                                     const uint32_t* shift,
                                                      ClassState* boundary_local, DeviceParams* prm) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0) {
@@ -1266,27 +1301,47 @@ __global__ __launch_bounds__(256) void k_boundary_in(const ClassState* bounds, u
     if (wmiss) prm->window_miss = 1;
   }
   if (c >= n_classes) return;
+  // The state before rank g's first request: the end state of the nearest rank below that has
+  // requests (ranks without requests are transparent), or the start of the class's list.
+  auto start_of = [&](uint32_t g) {
+    const int q = rank_predecessor(meta, stride, g);
+    ClassState st;
+    if (q >= 0) {
+      st = bounds[(size_t)q * rec + c];
+    } else {
+      st.cursor = st.lo = cls_begin_glob[c];
+      st.hown_lo = st.hown_hi = kNone;
+    }
+    return st;
+  };
   // The verdict on the windows is taken on final states only (a pass in which no rank changed
   // anything): speculative replays may run off a window without any consequence.
   uint32_t changed = 0;
   for (uint32_t g = 0; g < n_ranks; ++g) changed |= bounds[(size_t)g * rec + n_classes].cursor;
   bool miss = false;
   for (uint32_t g = 0; g < n_ranks && !changed; ++g) {
-    if (totals[g] == 0) continue;  // consumes nothing: passes its predecessor's state on
+    if (meta[(size_t)g * stride + stride - 1] == 0) continue;  // no requests: touches nothing
     const uint32_t w0 = winall[(size_t)g * 2 * n_classes + 2 * c];
     const uint32_t w1 = winall[(size_t)g * 2 * n_classes + 2 * c + 1];
-    if (g > 0) {
-      const ClassState st = bounds[(size_t)(g - 1) * rec + c];
-      miss |= st.lo < w0 || st.cursor > w1 || st.lo > st.cursor;
-    }
+    const ClassState st = start_of(g);
+    miss |= st.lo < w0 || st.cursor > w1 || st.lo > st.cursor;
     const ClassState en = bounds[(size_t)g * rec + c];
     miss |= en.cursor >= w1 && w1 < cls_begin_glob[c + 1];
   }
   if (miss) prm->window_miss = 1;  // (benign race: everybody writes 1)
   if (rank > 0) {
-    ClassState st = bounds[(size_t)(rank - 1) * rec + c];
-    st.cursor -= shift[c];
-    st.lo -= shift[c];
+    // Into this rank's window first, then to local positions: a start state outside the
+    // window is a miss (flagged above, on the final pass) — but the state handed to the
+    // matching passes must be one they can reproduce exactly (they clamp what they are given,
+    // and a chunk whose recorded start differs from its given start is never consistent).
+    ClassState st = start_of(rank);
+    const uint32_t w0 = winall[(size_t)rank * 2 * n_classes + 2 * c];
+    const uint32_t w1 = winall[(size_t)rank * 2 * n_classes + 2 * c + 1];
+    const uint32_t cur = min(max(st.cursor, w0), w1);
+    const uint32_t lo = min(max(st.lo, w0), cur);
+    if (lo == cur) st.hown_lo = st.hown_hi = kNone;  // (what a state without holes reports)
+    st.cursor = cur - shift[c];
+    st.lo = lo - shift[c];
     boundary_local[c] = st;
   }
 }

@@ -62,10 +62,10 @@ struct MatchBuffers {
   const uint32_t* part_rank_base;  // first global rank of every part (n_parts > 1 only)
   uint32_t n_parts;
   // Multi-GPU with own guesses: the consuming-request counts of all ranks (gathered,
-  // [rank * n_parts + part]); the guesses of rank base_rank start behind those of the ranks
+  // [rank * base_stride + part]); the guesses of rank base_rank start behind those of the ranks
   // before it. NULL on one GPU.
   const uint32_t* base_totals;
-  uint32_t base_rank;
+  uint32_t base_rank, base_stride;
   ClassState* endst;         // [K * C] end state of every chunk (in place)
   ClassState* checkpoint;    // [ceil(N / 64) * C] state before each block of 64 requests
   // [K * C] state after the first kEarlyAt requests of every chunk (<= 64 classes only): a
@@ -92,6 +92,7 @@ struct LaneClass {
   uint32_t hq;      // ~rank of the entry at `cursor`     (0 past the end)
   uint32_t nq;      // ~rank of the entry at `cursor + 1` (0 past the end)
   uint32_t filled;  // ring holds list entries [cursor, filled)
+  uint32_t single;  // the class consists of one servant
 };
 
 template <int W>
@@ -114,6 +115,7 @@ struct MatchWave {
     r.hown_lo = k[j].hown_lo;
     r.hown_hi = k[j].hown_hi;
     r.end = k[j].end;
+    r.single = k[j].single;
     r.head_p = ~k[j].hq;  // 0 -> kNone
     r.head_g = k[j].cursor < k[j].end ? ring_g[at(lane + 64 * j, k[j].cursor)] : kNone;
     return r;
@@ -144,9 +146,11 @@ struct MatchWave {
       q.hown_lo = st.hown_lo;
       q.hown_hi = st.hown_hi;
       q.end = e;
+      q.single = L.cls_single ? L.cls_single[c] : 0u;
     } else {
       q.cursor = q.lo = q.end = 0;
       q.hown_lo = q.hown_hi = kNone;
+      q.single = 0;
     }
     q.hq = q.nq = 0;
     q.filled = q.cursor;
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     before1 = B.before[(size_t)(kc + 1) * G + part];
     if (B.base_totals) {
       uint32_t base = 0;
-      for (uint32_t r = 0; r < B.base_rank; ++r) base += B.base_totals[(size_t)r * G + part];
+      for (uint32_t r = 0; r < B.base_rank; ++r) base += B.base_totals[(size_t)r * B.base_stride + part];
       before0 += base;
       before1 += base;
     }

@@ -92,6 +92,7 @@ struct ydc_context {
   DevBuf<uint32_t> d_spare[6];  // ydc_remove_servants compacts into these, then swaps
   DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted, d_cls_comp, d_part_base;
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
+  DevBuf<uint8_t> d_cls_single;
 
   // Per-batch workspace.
   DevBuf<uint32_t> d_slot_base, d_cls_begin, d_vals[2], d_hist, d_row_total, d_tile_first;
@@ -117,7 +118,7 @@ struct ydc_context {
     decltype(&ncclCommCount) comm_count_fn = nullptr;
     decltype(&ncclGetErrorString) error_string_fn = nullptr;
     LocalHub* hub = nullptr;
-    DevBuf<uint32_t> d_totals, d_base, d_delta, d_deltas;
+    DevBuf<uint32_t> d_totals, d_meta, d_base, d_delta, d_deltas;
     // Sharded sort (k_window): key-count table, per-servant windows, local prefix, class lists
     // of the whole registry, local -> registry-wide list position shifts, the ranks' windows.
     DevBuf<uint32_t> d_cum, d_r_first, d_lbase, d_cls_begin_glob, d_shift, d_winrec, d_winall;
@@ -265,6 +266,10 @@ int rebuild_tables(ydc_context* c) {
   HIP_TRY(c, c->d_cls_ver.reserve(C));
   HIP_TRY(c, c->d_cls_begin.reserve(C + 1));
   HIP_TRY(c, c->d_part_base.reserve(kMaxComponents + 1));
+  HIP_TRY(c, c->d_cls_single.reserve(C ? C : 1));
+  if (C)
+    HIP_TRY(c, hipMemcpyAsync(c->d_cls_single.p, c->tables.cls_single.data(), C, hipMemcpyHostToDevice,
+                              c->stream));
   if (c->n_parts > 1) {
     HIP_TRY(c, c->d_cls_comp.reserve(C));
     HIP_TRY(c, hipMemcpyAsync(c->d_cls_comp.p, c->tables.cls_comp.data(), (size_t)C * 4,
@@ -496,6 +501,7 @@ int ydc_destroy(ydc_context* c) {
     b->release();
   for (auto* b : {&c->d_cls_env, &c->d_env_ver_mask, &c->d_keys[0], &c->d_keys[1], &c->d_mask}) b->release();
   c->d_ver_sorted.release();
+  c->d_cls_single.release();
   for (auto& b : c->d_spare) b.release();
   c->d_cls_by_g.release();
   c->d_owner.release();
@@ -861,6 +867,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   const int key_sorted = (int)((slot_bound ? p.key_passes : 0) & 1);
   p.L.n_classes = C;
   p.L.cls_begin = c->d_cls_begin.p;
+  p.L.cls_single = c->d_cls_single.p;
   if (p.packed) {
     const uint32_t* rec = (const uint32_t*)c->d_keys[cur].p;  // {rank, slot} pairs
     p.L.list_p = p.cls_passes || p.fused_cls_bits ? rec : nullptr;
@@ -1446,7 +1453,7 @@ void group_release(ydc_context* c) {
     if (last) delete g.hub;
     g.hub = nullptr;
   }
-  for (auto* b : {&g.d_totals, &g.d_base, &g.d_delta, &g.d_deltas, &g.d_pad, &g.d_gather,
+  for (auto* b : {&g.d_totals, &g.d_meta, &g.d_base, &g.d_delta, &g.d_deltas, &g.d_pad, &g.d_gather,
                   &g.d_all[0], &g.d_all[1], &g.d_all[2], &g.d_all_idx, &g.d_cum, &g.d_r_first,
                   &g.d_lbase, &g.d_cls_begin_glob, &g.d_shift, &g.d_winrec, &g.d_winall})
     b->release();
@@ -1642,7 +1649,10 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   const uint32_t G = (uint32_t)g.n_ranks, C = p.C, S = p.S, K = p.K;
   const size_t rec = (size_t)C + 1;  // ClassStates a rank publishes per pass
   const uint32_t P = c->n_parts;  // counts are exchanged per independent part of the registry
-  HIP_TRY(c, g.d_totals.reserve((size_t)G * P));
+  const uint32_t MS = P + 1;  // words of a rank's k_rank_meta record
+  HIP_TRY(c, g.d_totals.reserve((size_t)G * MS));
+  HIP_TRY(c, g.d_meta.reserve(MS));
+  HIP_TRY(c, g.d_bound_local.reserve(C ? C : 1));
   HIP_TRY(c, g.d_base.reserve(P));
   HIP_TRY(c, g.d_send.reserve(rec));
   HIP_TRY(c, g.d_bounds.reserve(rec * G));
@@ -1690,14 +1700,12 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       HIP_TRY(c, g.d_shift.reserve(C));
       HIP_TRY(c, g.d_winrec.reserve((size_t)2 * C));
       HIP_TRY(c, g.d_winall.reserve((size_t)2 * C * G));
-      HIP_TRY(c, g.d_bound_local.reserve(C));
       ++g.windowed_batches;
     }
-    // The chunks of this rank continue the previous rank's (sharded sort: the predecessor's
-    // state comes translated into this rank's local list positions, k_boundary_in).
-    p.mb.boundary_in = g.rank == 0 ? nullptr
-                       : windowed  ? g.d_bound_local.p
-                                   : g.d_bounds.p + (size_t)(g.rank - 1) * rec;
+    // The chunks of this rank continue those of the nearest rank below that has requests
+    // (k_global_flag / k_boundary_in copy its end state — sharded sort: translated into this
+    // rank's local list positions — into d_bound_local after every exchange).
+    p.mb.boundary_in = g.rank == 0 ? nullptr : g.d_bound_local.p;
 
     if (!windowed) {
       if (int rc = enqueue_front_a(c, p, tk)) return rc;
@@ -1710,15 +1718,17 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       }
     }
     if (!N) HIP_TRY(c, hipMemsetAsync(c->d_before.p, 0, (size_t)4 * P, st));  // totals row of K == 0
-    // Level guesses count the consuming requests of the ranks before this one.
-    if (int rc = group_all_gather(c, c->d_before.p + (size_t)K * P, g.d_totals.p, (size_t)4 * P)) return rc;
+    // Level guesses count the consuming requests of the ranks before this one; a rank without
+    // requests is skipped by its successor (k_rank_meta: counts per part + number of requests).
+    hipLaunchKernelGGL(k_rank_meta, dim3(1), dim3(64), 0, st, c->d_before.p + (size_t)K * P, P, N, g.d_meta.p);
+    if (int rc = group_all_gather(c, g.d_meta.p, g.d_totals.p, (size_t)4 * MS)) return rc;
     if (windowed) {
       const uint32_t log_t = 7;  // kWindowThresholds == 128
       static_assert(kWindowThresholds == 128, "threshold shift");
       const uint32_t shift = c->kf.key_bits > log_t ? c->kf.key_bits - log_t : 0;
       YDC_LAUNCH(c, "k_key_count", k_key_count, dim3(kWindowThresholds - 1), dim3(256), 0, st, p.sv,
                  c->kf.cap_bits, shift, g.d_cum.p);
-      WindowArgs wa{g.d_cum.p, c->kf.cap_bits, shift, g.d_totals.p, (uint32_t)g.rank, G, p.win_margin,
+      WindowArgs wa{g.d_cum.p, c->kf.cap_bits, shift, g.d_totals.p, MS, (uint32_t)g.rank, G, p.win_margin,
                     p.slot_bound, c->d_slot_base.p, g.d_cls_begin_glob.p, C, g.d_r_first.p,
                     g.d_lbase.p, c->d_cls_begin.p, g.d_shift.p, g.d_winrec.p};
       YDC_LAUNCH(c, "k_window", k_window, dim3(1), dim3(1024), (size_t)2 * C * 4, st, p.sv, wa, prm);
@@ -1731,9 +1741,10 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       p.mb.before = c->d_before.p;
       p.mb.base_totals = g.d_totals.p;
       p.mb.base_rank = (uint32_t)g.rank;
+      p.mb.base_stride = MS;
       if (int rc = enqueue_front_b(c, p, nullptr)) return rc;
     } else {
-      hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, P, g.d_base.p);
+      hipLaunchKernelGGL(k_rank_base, dim3(1), dim3(64), 0, st, g.d_totals.p, (uint32_t)g.rank, P, MS, g.d_base.p);
       if (int rc = enqueue_front_b(c, p, g.d_base.p)) return rc;
     }
     mark(c, 6);
@@ -1759,10 +1770,11 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
         if (windowed) {
           hipLaunchKernelGGL(k_boundary_in, dim3(ceil_div(C, 256)), dim3(256), 0, st, g.d_bounds.p,
                              (uint32_t)rec, C, G, (uint32_t)g.rank, r, g.d_winall.p,
-                             g.d_cls_begin_glob.p, g.d_totals.p, g.d_shift.p, g.d_bound_local.p, prm);
+                             g.d_cls_begin_glob.p, g.d_totals.p, MS, g.d_shift.p, g.d_bound_local.p, prm);
         } else {
-          hipLaunchKernelGGL(k_global_flag, dim3(1), dim3(64), 0, st, g.d_bounds.p, (uint32_t)rec, C,
-                             G, r, prm);
+          hipLaunchKernelGGL(k_global_flag, dim3(std::max(1u, ceil_div(C, 256))), dim3(256), 0, st,
+                             g.d_bounds.p, (uint32_t)rec, C, G, (uint32_t)g.rank, r, g.d_totals.p, MS,
+                             c->d_cls_begin.p, g.d_bound_local.p, prm);
         }
       }
       const uint32_t first = launched;
@@ -1784,8 +1796,27 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipStreamSynchronize(st));
       HIP_TRY(c, hipGetLastError());
+      if (c->debug_sim) {
+        fprintf(stderr, "[ydc sharded] rank %d/%u windowed %d launched %u n_slots %u rank_offset %u miss %u changed:",
+                g.rank, G, (int)windowed, launched, c->h_prm->n_slots, c->h_prm->rank_offset,
+                c->h_prm->window_miss);
+        for (uint32_t r = first; r < launched; ++r) fprintf(stderr, " %u", c->h_prm->n_changed[r & 63]);
+        fprintf(stderr, "\n");
+        if (g.rank == 0 && launched <= 30) {  // every rank's record of the last pass (registry-wide positions)
+          (void)hipMemcpy(g.h_bounds, g.d_bounds.p, rec * G * sizeof(ClassState), hipMemcpyDeviceToHost);
+          for (uint32_t q = 0; q < G; ++q) {
+            fprintf(stderr, "   rank %u flag %u:", q, g.h_bounds[q * rec + C].cursor);
+            for (uint32_t k = 0; k < std::min(C, 8u); ++k)
+              fprintf(stderr, " (%u,%u,%x)", g.h_bounds[q * rec + k].cursor, g.h_bounds[q * rec + k].lo,
+                      g.h_bounds[q * rec + k].hown_lo);
+            fprintf(stderr, "\n");
+          }
+        }
+      }
       if (c->h_prm->overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
-      if (c->h_prm->window_miss) {
+      // (Belt and braces: a sharded sort that has not settled after 256 passes — the same count
+      // on every rank — is treated like a missed window.)
+      if (c->h_prm->window_miss || (windowed && launched >= 256)) {
         miss = true;
         break;
       }
@@ -1800,7 +1831,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
         break;
       }
       // Worst case one chunk per pass becomes final; K differs per rank, so bound it loosely.
-      if (launched > 4u * 1024 * 1024) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
+      if (launched > 200000u) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
     }
     if (!miss) break;
     // Some rank's window did not cover what its requests reached (every rank saw the same
