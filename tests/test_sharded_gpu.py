@@ -207,6 +207,20 @@ def test_sort_is_sharded_and_a_missed_window_falls_back(monkeypatch):
     [c.close() for c in ctxs]
 
 
+def test_late_change_behind_a_rank_without_requests():
+    """configs[2]'s batch (its serial chain at the dedicated-tier boundary makes rank 0's end
+    state change as late as pass 2-3) cut so that the rank behind rank 0 has no requests: the
+    rank behind THAT one continues rank 0 directly (ranks without requests are transparent), so
+    the late change reaches it in the very next pass and cannot slip past the "no rank changed
+    anything" verdict."""
+    sv, tk = synth.make_config("cfg3")
+    n = len(tk["env_id"])
+    ctxs = make_group(4, sv)
+    res = sharded_run(ctxs, sv, tk, [0, 450_000, 450_000, 450_000, n])
+    check_against_oracle(res, sv, tk)
+    [c.close() for c in ctxs]
+
+
 def test_local_ranks_many_classes():
     """> 64 classes (two classes per lane) across 3 ranks."""
     sv, tk = cases.random_case(seed=63, n_tasks=30_000, n_servants=1500, n_envs=7,
