@@ -24,7 +24,8 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
   for (uint32_t b = 0; b < blocks; ++b) {
     // inverted ranks: class c entry e has rank e * n_classes + c
     uint32_t hq = lane < n_classes ? ~lane : 0u, nq = lane < n_classes ? ~(n_classes + lane) : 0u;
-    uint32_t cur = 0, res = kIdxTimeout;
+    const uint32_t base = (uint32_t)(uintptr_t)lds + ((lane << rshift) << 2);
+    uint32_t an = base + 4, res = kIdxTimeout;  // address of `next` (entry 1)
     uint32_t i = 0;
     const uint32_t mlo = n_classes >= 32 ? 0xFFFFFFFFu : ((1u << n_classes) - 1);
     const uint32_t mhi = n_classes > 32 ? (n_classes >= 64 ? 0xFFFFFFFFu : (1u << (n_classes - 32)) - 1) : 0;
@@ -32,9 +33,8 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
     while ((1u << steps) < n_classes) ++steps;
     const uint64_t a = __builtin_readcyclecounter();
     // 20 requests per block: at most 20 picks per class, the ring (32) never wraps.
-    uint32_t st = match_fast_loop(i, 20, mlo, mhi, kNone, kNone, 0ull, 0ull, 0ull, res, hq, nq, cur,
-                                  4u, (uint32_t)(uintptr_t)lds + ((lane << rshift) << 2), R * 4 - 1,
-                                  steps);
+    uint32_t st = match_fast_loop(i, 20, mlo, mhi, kNone, kNone, 0ull, 0ull, 0ull, res, hq, nq, an,
+                                  2048u << 2, R * 4 - 1, steps, 0u);
     t_asm += __builtin_readcyclecounter() - a;
     total_i += i + st + (res & 1);
   }
