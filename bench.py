@@ -190,12 +190,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     use_dist = world > 1 or os.environ.get("YDC_BENCH_FORCE_DIST") == "1"
     dist = torch = None
+    t_start = time.perf_counter()
+
+    def phase(what):
+        # Start-up phases of a distributed run on stderr: the rendezvous and the RCCL bootstrap
+        # are the parts whose duration depends on the box, not on this code.
+        if use_dist and rank == 0:
+            print("[bench] %6.1f s  %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+
     if use_dist:
         # Rendezvous, barriers and the max over ranks go through gloo (CPU); the data path of
         # the sharded batch is RCCL inside libydc.so (ydc_group_init / ydc_dispatch_sharded).
         import torch
         import torch.distributed as dist
+        phase("torch imported")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        phase("gloo group up (%d ranks)" % world)
 
     from yadcc_amd import binding, pack, synth
 
@@ -245,6 +256,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     box["err"] = e
 
+            phase("registry uploaded, RCCL unique id shared")
             th = init_thread = threading.Thread(target=_init, daemon=True)
             th.start()
             th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
@@ -254,6 +266,7 @@ def main():
                 raise RuntimeError(box.get("err") or "ncclCommInitRank did not return in time")
         except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
             group_note = "RCCL group init failed (%s): ranks ran independent batches" % e
+        phase(group_note or "RCCL communicator up")
         flags = [1 if sharded else 0]
         if dist:
             t = torch.tensor(flags, dtype=torch.int64)
