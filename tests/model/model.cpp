@@ -86,6 +86,29 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
       fill[c]++;
     }
   }
+  // Cross-check of the bin sort's first launch (bin_sort.h: k_servant_scan_bins): the start of
+  // every key bin in every class list, summed from per-servant closed forms, against the
+  // sorted lists themselves.
+  if (kf.exact && kf.key_bits <= 32 && M) {
+    const BinFormat bf = choose_bins(kf.key_bits, T.max_slots);
+    std::vector<uint32_t> closed(C), counted(C);
+    for (uint32_t j = 1; j <= bf.n_bins; ++j) {
+      const uint64_t K = (uint64_t)j << bf.shift;
+      std::fill(closed.begin(), closed.end(), 0u);
+      std::fill(counted.begin(), counted.end(), 0u);
+      for (uint32_t s = 0; s < S; ++s) {
+        const uint32_t c = T.class_of[s];
+        if (c == kNone) continue;
+        const uint64_t part_key = G > 1 ? (uint64_t)comp_of(c) << kf.comp_shift : 0ull;
+        closed[c] += first_slot_not_below_direct(nproc[s], load[s], max_tasks[s], running[s], flags[s],
+                                                 part_key, K, kf.cap_bits) - running[s];
+      }
+      for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t i = cls_begin[c]; i < cls_begin[c + 1]; ++i) counted[c] += key[list_g[i]] < K;
+      if (closed != counted) return -8;
+      if (j == bf.n_bins && std::accumulate(closed.begin(), closed.end(), 0u) != M) return -8;
+    }
+  }
   ClassLists L;
   L.list_p = C > 1 ? list_p.data() : nullptr;
   L.list_g = list_g.data();
@@ -491,7 +514,8 @@ extern "C" uint32_t model_check_first_slot(uint32_t seed, uint32_t iterations) {
   };
   uint32_t bad = 0;
   for (uint32_t it = 0; it < iterations; ++it) {
-    const uint32_t cap_bits = 1 + rnd() % 12, lim = (1u << cap_bits) - 1;
+    // (mostly small capacities; one in 64 up to 2^17 - 1: the 64-bit arithmetic)
+    const uint32_t cap_bits = rnd() % 64 ? 1 + rnd() % 12 : 13 + rnd() % 5, lim = (1u << cap_bits) - 1;
     const uint32_t nproc = 1 + rnd() % (lim * 2), load = rnd() % (nproc * 5 / 4 + 1);
     uint32_t mt = rnd() % (lim + 1);
     const uint32_t top = mt < nproc ? mt : nproc;
@@ -499,6 +523,9 @@ extern "C" uint32_t model_check_first_slot(uint32_t seed, uint32_t iterations) {
     const uint64_t part = (uint64_t)(rnd() % 3) << (2 * cap_bits + 1);
     uint64_t K = part | (((uint64_t)rnd() << 16 | rnd()) % (1ull << (2 * cap_bits + 1)));
     if (rnd() % 10 == 0) K = part;
+    if (rnd() % 10 == 0) K = (uint64_t)(rnd() % 4) << (2 * cap_bits + 1);  // another part's first key
+    if (rnd() % 16 == 0) K = (K & ~((1ull << (2 * cap_bits)) - 1)) | (rnd() % 4);  // tiny quotients
+    if (rnd() % 16 == 0) K |= (1ull << (2 * cap_bits)) - 1 - rnd() % 4;              // quotients near 1
     const uint32_t n = servant_slot_count(nproc, load, mt, running, flags);
     uint32_t want = running + n;
     for (uint32_t r = running; r < running + n; ++r) {
@@ -510,6 +537,7 @@ extern "C" uint32_t model_check_first_slot(uint32_t seed, uint32_t iterations) {
       }
     }
     bad += first_slot_not_below(nproc, load, mt, running, flags, part, K, cap_bits) != want;
+    bad += first_slot_not_below_direct(nproc, load, mt, running, flags, part, K, cap_bits) != want;
   }
   return bad;
 }

@@ -262,6 +262,7 @@ def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
     """<= 8 classes and room in the last key digit: the class partition rides on the last key
     pass (k_radix_scatter_classed); YDC_FUSED_CLASS=0 keeps the separate pass. Same results."""
     monkeypatch.setenv("YDC_FUSED_CLASS", str(fused))
+    monkeypatch.setenv("YDC_BINSORT", "0")  # (the radix sort is what is under test here)
     c = binding.Context(device=0)
     try:
         for seed, envs in ((61, 2), (62, 3), (63, 1)):
@@ -283,7 +284,7 @@ def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
 def test_switchable_fast_paths_off(monkeypatch):
     """The A/B switches select older, slower forms of the same steps (separate class pass,
     class gather, k_guess_init, one request per loop iteration): same results."""
-    for k in ("YDC_PACKED_CLASS", "YDC_FUSED_CLASS", "YDC_OWN_GUESS", "YDC_PAIR"):
+    for k in ("YDC_PACKED_CLASS", "YDC_FUSED_CLASS", "YDC_OWN_GUESS", "YDC_PAIR", "YDC_BINSORT"):
         monkeypatch.setenv(k, "0")
     c = binding.Context(device=0)
     try:

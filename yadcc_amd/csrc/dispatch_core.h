@@ -167,6 +167,48 @@ YDC_HD uint32_t first_slot_not_below(uint32_t nproc, uint32_t load, uint32_t max
   return hi;
 }
 
+// The same answer without a search (the bin sort evaluates it once per servant and bin boundary,
+// bin_sort.h). With cap(r) = a + r while r < g (a = nproc - load: the servant's own running
+// tasks give capacity back, task_dispatcher.cc:308-309) and cap(r) = cB = min(nproc, max_tasks)
+// from g on, "floor(r 4^b / cap(r)) >= q" turns into r (4^b - q) >= q a below g and
+// r 4^b >= q cB from g on; tier 0 holds exactly for r < t1 = ceil(nproc / 2) on a dedicated
+// servant (:404-407). The first r whose (tier, quotient) reaches K's follows from the monotone
+// key; one division (32-bit for capacities below 2^10).
+YDC_HD uint32_t first_slot_not_below_direct(uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                            uint32_t running, uint32_t flags, uint64_t part_key,
+                                            uint64_t K, uint32_t cap_bits) {
+  const uint32_t n = servant_slot_count(nproc, load, max_tasks, running, flags);
+  if (n == 0) return running;
+  const uint32_t top = running + n;
+  if (K <= part_key) return running;  // an earlier part, or the very first key of this one
+  const uint64_t k = K - part_key;
+  if (k >> (2 * cap_bits + 1)) return top;  // a later part
+  const uint32_t ktier = (uint32_t)(k >> (2 * cap_bits));
+  const uint64_t one = 1ull << (2 * cap_bits);
+  const uint64_t q = k & (one - 1);
+  const uint32_t t1 = (flags & kFlagDedicated) ? nproc / 2 + (nproc & 1u) : 0u;  // first tier-1 slot
+  uint64_t ru = 0;  // first r >= 0 whose quotient is >= q
+  if (q) {
+    const uint32_t a = nproc - load;  // > 0: the servant has slots
+    const uint32_t cB = max_tasks < nproc ? max_tasks : nproc;
+    const uint32_t g = max_tasks > a ? (load < max_tasks - a ? load : max_tasks - a) : 0u;
+    uint64_t rA = ~0ull;
+    if (g) {  // (then a < 2^cap_bits: q a < 2^(3 cap_bits))
+      const uint64_t den = one - q;
+      if (cap_bits <= 10) rA = ((uint32_t)q * a + (uint32_t)den - 1) / (uint32_t)den;
+      else rA = (q * a + den - 1) / den;
+    }
+    if (rA < g) {
+      ru = rA;
+    } else {
+      const uint64_t rB = (q * cB + one - 1) >> (2 * cap_bits);
+      ru = rB > g ? rB : g;
+    }
+  }
+  const uint64_t first = ktier ? (ru > t1 ? ru : t1) : (ru < t1 ? ru : t1);
+  return first <= running ? running : (first >= top ? top : (uint32_t)first);
+}
+
 // The sort key of slot (servant, r), exact or fp64 format, the part id in place.
 YDC_HD uint64_t slot_sort_key(uint32_t nproc, uint32_t load, uint32_t max_tasks, uint32_t flags,
                               uint32_t r, uint64_t part_key, bool exact, uint32_t cap_bits) {

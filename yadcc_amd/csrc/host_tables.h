@@ -198,5 +198,18 @@ inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 
   return f;
 }
 
+// Geometry of the bin sort (bin_sort.h): B = 2^b equal bins over the key space, at most 512
+// slots of the registry's bound per bin on average (the synthetic pools fill ~3/4 of the bound,
+// and their fullest bin holds ~3.5x the average), 16 <= B <= max_bins (and B <= 2^key_bits).
+struct BinFormat {
+  uint32_t n_bins, shift;  // bin of a slot = key >> shift
+};
+inline BinFormat choose_bins(uint32_t key_bits, uint64_t slot_bound, uint32_t max_bins = 2048) {
+  uint32_t b = 4;
+  while ((2u << b) <= max_bins && ((uint64_t)512 << b) < slot_bound) ++b;
+  if (b > key_bits) b = key_bits;
+  return BinFormat{1u << b, key_bits - b};
+}
+
 }  // namespace ydc
 #endif  // YADCC_AMD_HOST_TABLES_H_

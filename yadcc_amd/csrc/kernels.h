@@ -10,6 +10,7 @@
 //   k_radix_hist / _scan / _scatter   stable LSD radix sort of the slots by key (the chunk
 //                    prefix of the consuming counts rides in a histogram launch)
 //   k_radix_scatter_classed / class passes   per-class sorted lists (rank, slot)
+//   (bin_sort.h: the same order and lists in three launches for small and medium registries)
 //   k_match_pass (match_kernel.h)     chunk-parallel speculative replay of the greedy picks;
 //                    pass 0 makes its own level guesses (k_guess_init: > 64 classes, sharded)
 //   k_finalize                        rank -> slot -> servant index, utilisation; running_tasks in
@@ -132,12 +133,12 @@ struct PartTable {
   uint32_t* rank_base;  // [n_parts + 1] slots of the parts before g (k_servant_scan writes it)
 };
 
-__global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
-                                                       uint32_t max_slots, uint32_t* slot_base,
-                                                       uint32_t* cls_begin, uint32_t* chunk_consuming,
-                                                       uint32_t n_chunks, PartTable parts,
-                                                       uint32_t tile_size, uint32_t* tile_first,
-                                                       DeviceParams* prm) {
+__device__ __forceinline__ void servant_scan_block(const ServantTable& sv, uint32_t n_classes,
+                                                   uint32_t max_slots, uint32_t* slot_base,
+                                                   uint32_t* cls_begin, uint32_t* chunk_consuming,
+                                                   uint32_t n_chunks, const PartTable& parts,
+                                                   uint32_t tile_size, uint32_t* tile_first,
+                                                   DeviceParams* prm) {
   // Per-batch reset of the request-side counters (saves a memset launch).
   for (uint32_t k = threadIdx.x; k < n_chunks * parts.n_parts; k += blockDim.x) chunk_consuming[k] = 0;
   __shared__ uint32_t lds[17];
@@ -234,6 +235,16 @@ __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t
       parts.rank_base[parts.n_parts] = a2;
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
+                                                       uint32_t max_slots, uint32_t* slot_base,
+                                                       uint32_t* cls_begin, uint32_t* chunk_consuming,
+                                                       uint32_t n_chunks, PartTable parts,
+                                                       uint32_t tile_size, uint32_t* tile_first,
+                                                       DeviceParams* prm) {
+  servant_scan_block(sv, n_classes, max_slots, slot_base, cls_begin, chunk_consuming, n_chunks, parts,
+                     tile_size, tile_first, prm);
 }
 
 // ---------------------------------------------------------------------------
@@ -1397,6 +1408,7 @@ __global__ __launch_bounds__(256) void k_apply_tick(const uint32_t* idx, const S
 
 }  // namespace ydc
 
+#include "bin_sort.h"
 #include "match_kernel.h"
 
 #endif  // YADCC_AMD_KERNELS_H_

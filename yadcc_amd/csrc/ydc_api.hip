@@ -60,6 +60,9 @@ struct BatchPlan {
   bool key32 = true, any_shared = false, use_generic = false, wave_path = false;
   bool packed = false;  // the sort moves 8-byte (key, value) records (32-bit keys)
   bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
+  // Bin sort (bin_sort.h) instead of the radix sort: n_bins equal bins over the key space.
+  bool binsort = false;
+  uint32_t n_bins = 0, bin_shift = 0;
   ServantTable sv{};
   ClassLists L{};
   TaskTable T{};
@@ -100,6 +103,7 @@ struct ydc_context {
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
+  DevBuf<uint32_t> d_binbase, d_binfill;  // bin sort: starts of the bins per class, arrival counters
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_running_out;
@@ -206,6 +210,14 @@ struct ydc_context {
   bool opt_packed_class = true;
   bool opt_shard_sort = true;
   bool opt_packed_sort = true;  // 8-byte (key, value) sort records for 32-bit keys
+  // Bin sort (three launches, bin_sort.h) for registries that offer at most this many slots;
+  // a batch with a bin too large for LDS is repeated with the radix sort, which then stays
+  // (binsort_blocked) until the registry changes structure.
+  bool opt_binsort = true;
+  uint32_t opt_binsort_max_slots = 600000;
+  bool binsort_blocked = false;
+  bool debug_verify_binsort = false;  // YDC_BINSORT_VERIFY=1: check every bin sort against a host sort
+  uint64_t binsort_misses = 0;
   int64_t opt_shard_margin = -1;  // >= 0: margin of the key windows in slots (tests)
   uint32_t opt_rounds_per_check = 2;
   bool profiling = false;
@@ -301,6 +313,7 @@ int rebuild_tables(ydc_context* c) {
   // after a sync (the tables may be rebuilt before the next launch otherwise).
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->tables_dirty = false;
+  c->binsort_blocked = false;   // another registry: the bins get another chance
   c->stream_mode.stale = true;  // a captured streaming step bakes the table sizes in
   return YDC_OK;
 }
@@ -478,6 +491,9 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_BINSORT")) c->opt_binsort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
   if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
@@ -839,6 +855,21 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
       p.cls_bits = ceil_div(cls_bits, p.cls_passes);
     }
   }
+  // Bin sort: 32-bit exact keys, the wave path's class limit, the class above the slot bits in
+  // the value (or a single class), one GPU. Decided from the registry alone.
+  p.binsort = c->opt_binsort && !c->binsort_blocked && c->kf.exact && p.key32 && C >= 1 &&
+              C <= kMaxWaveClasses && slot_bound && slot_bound <= c->opt_binsort_max_slots &&
+              (C == 1 || p.gbits) && c->group.n_ranks == 0;
+  if (p.binsort) {
+    const BinFormat bf = choose_bins(c->kf.key_bits, slot_bound, kMaxBins);
+    p.n_bins = bf.n_bins;
+    p.bin_shift = bf.shift;
+    p.cls_passes = 0;
+    p.fused_cls_bits = 0;
+    HIP_TRY(c, c->d_binbase.reserve((size_t)(p.n_bins + 1) * (C + 1)));
+    HIP_TRY(c, c->d_binfill.reserve(p.n_bins));
+    HIP_TRY(c, c->d_rank_to_g.reserve(slot_bound));
+  }
   HIP_TRY(c, c->d_owner.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
   HIP_TRY(c, c->d_self_lo.reserve(N));
@@ -880,6 +911,15 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.L.list_g = c->d_vals[cur].p;
     p.L.stride = 1;
     p.rank_to_g = p.fused_cls_bits ? c->d_rank_to_g.p : c->d_vals[key_sorted].p;
+    p.rank_stride = 1;
+  }
+  if (p.binsort) {
+    // Staging records in d_keys[0], the class lists ({rank, slot} records) in d_keys[1].
+    const uint32_t* rec = (const uint32_t*)c->d_keys[1].p;
+    p.L.list_p = rec;
+    p.L.list_g = rec + 1;
+    p.L.stride = 2;
+    p.rank_to_g = c->d_rank_to_g.p;
     p.rank_stride = 1;
   }
   p.T = TaskTable{c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p, W};
@@ -930,6 +970,19 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
 void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
   c->ksamples_used = 0;
   mark(c, 0);
+  if (p.binsort) {
+    // + one workgroup per bin boundary: the bins' starts in closed form (bin_sort.h)
+    // (n_bins / per workgroups of `per` boundaries each: about one per CU)
+    const uint32_t per = std::min(kBinsPerGroup, std::max(1u, p.n_bins / 256));
+    YDC_LAUNCH(c, "k_servant_scan", k_servant_scan_bins, dim3(1 + p.n_bins / per), dim3(1024),
+               (size_t)per * (p.C + 1) * sizeof(uint32_t), c->stream, p.sv, p.C, p.slot_bound_glob,
+               c->d_slot_base.p, cls_begin, c->d_chunk_consuming.p, p.K,
+               PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, kSortThreads * p.sort_items,
+               c->d_tile_first.p, c->d_prm.p, c->kf.cap_bits, c->kf.comp_shift,
+               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, per);
+    mark(c, 1);
+    return;
+  }
   YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (p.C + 1) * sizeof(uint32_t),
              c->stream, p.sv, p.C, p.slot_bound_glob, c->d_slot_base.p, cls_begin,
              c->d_chunk_consuming.p, p.K, PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p},
@@ -967,6 +1020,14 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   const uint32_t* r_first = p.win ? c->group.d_r_first.p : nullptr;
   const uint32_t* gbase = p.win ? c->d_slot_base.p : nullptr;
   uint16_t* cls_by_g = C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr;
+  if (p.binsort && gen_blocks) {
+    YDC_LAUNCH(c, "k_slot_gen", k_slot_bin, dim3(gen_blocks + cls_blocks), dim3(256),
+               (size_t)8 * p.n_bins, c->stream, p.sv, c->d_slot_base.p, c->d_prm.p, c->kf.cap_bits,
+               c->d_owner.p, gen_blocks, p.sort_items, p.gbits, ca, c->kf.comp_shift, c->d_tile_first.p,
+               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, C + 1,
+               (uint2*)c->d_keys[0].p);
+    return;
+  }
   if (p.key32) {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
@@ -992,6 +1053,17 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
   PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, c->n_parts};
   const PrefixArgs* pending_prefix = N && prefix_pending ? &pa : nullptr;
   mark(c, 2);
+  if (p.binsort) {
+    // One workgroup per bin (+ one for the chunk prefix): order inside the bins, global ranks,
+    // class lists.
+    BinSortArgs ba{(const uint2*)c->d_keys[0].p, BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p},
+                   p.C, p.gbits, c->d_cls_begin.p, (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
+    YDC_LAUNCH(c, "k_bin_sort", k_bin_sort, dim3(p.n_bins + (pending_prefix ? 1 : 0)), dim3(256),
+               (size_t)kBinCap * 8, c->stream, ba, c->d_prm.p, pending_prefix ? pa : PrefixArgs{});
+    mark(c, 3);
+    mark(c, 4);
+    return YDC_OK;
+  }
   // ---- sort by key
   const uint32_t g_mask = p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu;  // strips the class again
   const uint32_t bpp = c->kf.bits_per_pass;
@@ -1156,7 +1228,12 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   return YDC_OK;
 }
 
-// Reads the batch counters back and decides: 1 converged (rounds set), 0 more passes needed.
+// Internal return code: a bin of the bin sort did not fit its LDS buffer (bin_sort.h) — the
+// batch was gated out on the device and is to be repeated with the radix sort.
+constexpr int kRetryRadix = 1 << 20;
+
+// Reads the batch counters back and decides: 1 converged (rounds set), 0 more passes needed,
+// 2 the batch has to be repeated with the radix sort.
 int read_outcome(ydc_context* c, const BatchPlan& p, uint32_t first, uint32_t launched,
                  uint32_t* rounds) {
   HIP_TRY(c, hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost,
@@ -1165,6 +1242,7 @@ int read_outcome(ydc_context* c, const BatchPlan& p, uint32_t first, uint32_t la
   HIP_TRY(c, hipGetLastError());
   if (c->h_prm->overflow)
     return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
+  if (p.binsort && c->h_prm->window_miss) return 2;
   if (c->h_prm->n_changed[(launched - 1) & 63] != 0) return 0;
   *rounds = launched;
   for (uint32_t r = first; r < launched; ++r)
@@ -1183,7 +1261,7 @@ void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   s.n_classes = p.C;
   s.n_slots = c->h_prm->n_slots;
   s.key_bits = c->kf.key_bits;
-  s.radix_passes = p.key_passes;
+  s.radix_passes = p.binsort ? 0 : p.key_passes;  // 0: the bin sort placed the slots
   s.n_chunks = p.K;
   s.rounds = rounds;
   s.chunk_sims = c->h_prm->chunk_sims;
@@ -1249,6 +1327,7 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
                                 hipMemcpyDeviceToHost, c->stream));
     int done = read_outcome(c, p, first, launched, rounds);
     if (done < 0) return done;
+    if (done == 2) return kRetryRadix;
     if (done) {
       if (c->debug_sim) {
         fprintf(stderr, "[ydc match] K=%u cs=%u R=%u fill=%u rounds=%u sims=%u pass changed ends:", p.K,
@@ -1263,19 +1342,70 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
   }
 }
 
-}  // namespace
+// Debugging aid (YDC_BINSORT_VERIFY=1): the bin sort's outputs — global order, class lists —
+// against a host sort of the very records k_slot_bin staged. Waits for the stream.
+int verify_binsort(ydc_context* c, const BatchPlan& p) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  DeviceParams prm;
+  HIP_TRY(c, hipMemcpy(&prm, c->d_prm.p, sizeof(prm), hipMemcpyDeviceToHost));
+  const uint32_t M = prm.n_slots, C = p.C, row = C + 1;
+  if (prm.window_miss) {
+    fprintf(stderr, "[ydc binsort verify] a bin overflowed (window_miss): nothing to compare\n");
+    return YDC_OK;
+  }
+  std::vector<uint2> stage(M), list(M);
+  std::vector<uint32_t> r2g(M), cls_begin(C + 1), base((size_t)(p.n_bins + 1) * row), fill(p.n_bins);
+  HIP_TRY(c, hipMemcpy(stage.data(), c->d_keys[0].p, (size_t)M * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(list.data(), c->d_keys[1].p, (size_t)M * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(r2g.data(), c->d_rank_to_g.p, (size_t)M * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(cls_begin.data(), c->d_cls_begin.p, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(base.data(), c->d_binbase.p, base.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(fill.data(), c->d_binfill.p, fill.size() * 4, hipMemcpyDeviceToHost));
+  const uint32_t gmask = p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu;
+  uint32_t bad = 0, max_bin = 0;
+  auto complain = [&](const char* what, uint32_t at, uint32_t got, uint32_t want) {
+    if (++bad <= 12) fprintf(stderr, "[ydc binsort verify] %s at %u: device %u, host %u\n", what, at, got, want);
+  };
+  if (base[(size_t)p.n_bins * row + C] != M) complain("total of the last boundary row", p.n_bins, base[(size_t)p.n_bins * row + C], M);
+  for (uint32_t j = 0; j < p.n_bins; ++j) {
+    const uint32_t n = base[(size_t)(j + 1) * row + C] - base[(size_t)j * row + C];
+    max_bin = std::max(max_bin, n);
+    if (fill[j] != n) complain("records that arrived in bin", j, fill[j], n);
+    for (uint32_t i = base[(size_t)j * row + C]; i < base[(size_t)j * row + C] + n && i < M; ++i)
+      if ((stage[i].x >> p.bin_shift) != j) complain("bin of the staged record", i, stage[i].x >> p.bin_shift, j);
+  }
+  std::vector<uint2> sorted(stage);
+  std::sort(sorted.begin(), sorted.end(), [&](const uint2& a, const uint2& b) {
+    return a.x != b.x ? a.x < b.x : (a.y & gmask) < (b.y & gmask);
+  });
+  std::vector<uint32_t> next(cls_begin.begin(), cls_begin.end() - (C ? 1 : 0));
+  for (uint32_t r = 0; r < M; ++r) {
+    const uint32_t slot = sorted[r].y & gmask, cls = p.gbits ? sorted[r].y >> p.gbits : 0u;
+    if (r2g[r] != slot) complain("rank_to_g", r, r2g[r], slot);
+    if (cls < C) {
+      const uint32_t at = next[cls]++;
+      if (at < M && (list[at].x != r || list[at].y != slot)) {
+        complain("class list rank", at, list[at].x, r);
+        complain("class list slot", at, list[at].y, slot);
+      }
+    } else {
+      complain("class of a record", r, cls, C);
+    }
+  }
+  fprintf(stderr, "[ydc binsort verify] M=%u bins=%u shift=%u classes=%u fullest bin=%u: %u mismatches\n", M,
+          p.n_bins, p.bin_shift, C, max_bin, bad);
+  return bad ? fail(c, YDC_ERR_HIP, "bin sort verification failed (%u mismatches)", bad) : YDC_OK;
+}
 
-extern "C" {
-
-int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
-                        uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running) {
-  if (!c || (N && !tk)) return YDC_ERR_INVALID_ARGUMENT;
-  if (c->max_tasks && N > c->max_tasks)
-    return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
-  HIP_TRY(c, hipSetDevice(c->device));
-  BatchPlan p;
-  if (int rc = plan_batch(c, N, &p)) return rc;
+// Front, matching passes and finalise of a planned batch; returns when the results are there.
+// kRetryRadix: the plan used the bin sort and a bin overflowed — nothing was committed.
+int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, uint32_t flags,
+                      uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running,
+                      uint32_t* rounds_out) {
+  const uint32_t N = p.N;
   if (int rc = enqueue_front(c, p, tk)) return rc;
+  if (p.binsort && c->debug_verify_binsort)
+    if (int rc = verify_binsort(c, p)) return rc;
   hipStream_t st = c->stream;
   DeviceParams* prm = c->d_prm.p;
   uint32_t rounds = 0;
@@ -1317,7 +1447,40 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
     HIP_TRY(c, hipGetLastError());
     if (c->h_prm->overflow)
       return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
+    if (p.binsort && c->h_prm->window_miss) return kRetryRadix;
   }
+  *rounds_out = rounds;
+  return YDC_OK;
+}
+
+// A bin of the bin sort overflowed: from now on (until the registry changes structure) the
+// radix sort; `p` is planned again accordingly.
+int fall_back_to_radix(ydc_context* c, uint32_t N, BatchPlan* p) {
+  c->binsort_blocked = true;
+  ++c->binsort_misses;
+  c->stream_mode.stale = true;
+  return plan_batch(c, N, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
+                        uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running) {
+  if (!c || (N && !tk)) return YDC_ERR_INVALID_ARGUMENT;
+  if (c->max_tasks && N > c->max_tasks)
+    return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
+  HIP_TRY(c, hipSetDevice(c->device));
+  BatchPlan p;
+  if (int rc = plan_batch(c, N, &p)) return rc;
+  uint32_t rounds = 0;
+  int rc = run_planned_batch(c, p, tk, flags, d_out_idx, d_out_util, d_out_running, &rounds);
+  if (rc == kRetryRadix) {
+    if (int rc2 = fall_back_to_radix(c, N, &p)) return rc2;
+    rc = run_planned_batch(c, p, tk, flags, d_out_idx, d_out_util, d_out_running, &rounds);
+  }
+  if (rc) return rc;
   fill_stats(c, p, rounds);
   ydc_stats& s = c->stats;
   if (c->profiling) {
@@ -2072,6 +2235,23 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
   if (c->h_prm->overflow)
     return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
   uint32_t rounds = sm.passes;
+  if (p.binsort && c->h_prm->window_miss) {
+    // A bin of the bin sort overflowed (bin_sort.h): the tick's registry deltas are applied,
+    // its batch was gated out. Place it eagerly with the radix sort; the step is captured
+    // again, without the bin sort, on the next tick.
+    ++sm.eager_fallbacks;
+    BatchPlan p2;
+    if (int rc = fall_back_to_radix(c, sm.max_tasks, &p2)) return rc;
+    ydc_task_soa d{sm.d_env, sm.d_minv, sm.d_ip};
+    if (int rc = run_planned_batch(c, p2, &d, YDC_DISPATCH_COMMIT, c->d_out_idx.p, nullptr, nullptr, &rounds))
+      return rc;
+    HIP_TRY(c, hipMemcpy(sm.h_out, c->d_out_idx.p, (size_t)sm.max_tasks * 4, hipMemcpyDeviceToHost));
+    fill_stats(c, p2, rounds);
+    c->stats.n_tasks = n_tasks;
+    c->stats.env_not_found -= std::min(c->stats.env_not_found, sm.max_tasks - n_tasks);  // padding
+    if (n_tasks) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
+    return YDC_OK;
+  }
   if (p.wave_path) {
     if (c->h_prm->n_changed[(sm.passes - 1) & 63] != 0) {
       // The captured passes were not enough (rare): finish eagerly and capture a longer
