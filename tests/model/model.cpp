@@ -100,8 +100,16 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
         const uint32_t c = T.class_of[s];
         if (c == kNone) continue;
         const uint64_t part_key = G > 1 ? (uint64_t)comp_of(c) << kf.comp_shift : 0ull;
-        closed[c] += first_slot_not_below_direct(nproc[s], load[s], max_tasks[s], running[s], flags[s],
-                                                 part_key, K, kf.cap_bits) - running[s];
+        // (what bin_count_block evaluates: the 32-bit form where it applies, the last boundary
+        // by the slot count)
+        if (j == bf.n_bins)
+          closed[c] += servant_slot_count(nproc[s], load[s], max_tasks[s], running[s], flags[s]);
+        else if (kf.cap_bits <= 10)
+          closed[c] += first_slot_not_below_direct32(nproc[s], load[s], max_tasks[s], running[s], flags[s],
+                                                     (uint32_t)part_key, (uint32_t)K, kf.cap_bits) - running[s];
+        else
+          closed[c] += first_slot_not_below_direct(nproc[s], load[s], max_tasks[s], running[s], flags[s],
+                                                   part_key, K, kf.cap_bits) - running[s];
       }
       for (uint32_t c = 0; c < C; ++c)
         for (uint32_t i = cls_begin[c]; i < cls_begin[c + 1]; ++i) counted[c] += key[list_g[i]] < K;
@@ -538,6 +546,9 @@ extern "C" uint32_t model_check_first_slot(uint32_t seed, uint32_t iterations) {
     }
     bad += first_slot_not_below(nproc, load, mt, running, flags, part, K, cap_bits) != want;
     bad += first_slot_not_below_direct(nproc, load, mt, running, flags, part, K, cap_bits) != want;
+    if (cap_bits <= 10 && K < (1ull << 32) && part < (1ull << 32))
+      bad += first_slot_not_below_direct32(nproc, load, mt, running, flags, (uint32_t)part, (uint32_t)K,
+                                           cap_bits) != want;
   }
   return bad;
 }

@@ -209,6 +209,42 @@ YDC_HD uint32_t first_slot_not_below_direct(uint32_t nproc, uint32_t load, uint3
   return first <= running ? running : (first >= top ? top : (uint32_t)first);
 }
 
+// ... and in 32-bit arithmetic throughout, for capacities below 2^10 and keys (part id included)
+// below 2^32 — what the bin sort meets on ordinary pools: q a and q cB stay below 2^30.
+YDC_HD uint32_t first_slot_not_below_direct32(uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                              uint32_t running, uint32_t flags, uint32_t part_key,
+                                              uint32_t K, uint32_t cap_bits) {
+  const uint32_t n = servant_slot_count(nproc, load, max_tasks, running, flags);
+  if (n == 0) return running;
+  const uint32_t top = running + n;
+  if (K <= part_key) return running;
+  const uint32_t k = K - part_key;
+  if (k >> (2 * cap_bits + 1)) return top;
+  const uint32_t ktier = k >> (2 * cap_bits);
+  const uint32_t one = 1u << (2 * cap_bits);
+  const uint32_t q = k & (one - 1);
+  const uint32_t t1 = (flags & kFlagDedicated) ? nproc / 2 + (nproc & 1u) : 0u;
+  uint32_t ru = 0;
+  if (q) {
+    const uint32_t a = nproc - load;
+    const uint32_t cB = max_tasks < nproc ? max_tasks : nproc;
+    const uint32_t g = max_tasks > a ? (load < max_tasks - a ? load : max_tasks - a) : 0u;
+    uint32_t rA = 0xFFFFFFFFu;
+    if (g) {
+      const uint32_t den = one - q;
+      rA = (q * a + den - 1) / den;
+    }
+    if (rA < g) {
+      ru = rA;
+    } else {
+      const uint32_t rB = (q * cB + one - 1) >> (2 * cap_bits);
+      ru = rB > g ? rB : g;
+    }
+  }
+  const uint32_t first = ktier ? (ru > t1 ? ru : t1) : (ru < t1 ? ru : t1);
+  return first <= running ? running : (first >= top ? top : first);
+}
+
 // The sort key of slot (servant, r), exact or fp64 format, the part id in place.
 YDC_HD uint64_t slot_sort_key(uint32_t nproc, uint32_t load, uint32_t max_tasks, uint32_t flags,
                               uint32_t r, uint64_t part_key, bool exact, uint32_t cap_bits) {

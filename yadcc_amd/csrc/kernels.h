@@ -133,6 +133,60 @@ struct PartTable {
   uint32_t* rank_base;  // [n_parts + 1] slots of the parts before g (k_servant_scan writes it)
 };
 
+// What follows the scan proper (shared by the two forms of the scan): per-batch counter
+// reset, the run end behind the last tile, class list starts, first rank of every part.
+// carry / last_with_slots / cls_cnt: the scan's LDS results; my_last: this thread's last
+// servant with slots.
+__device__ __forceinline__ void servant_scan_finish(const ServantTable& sv, uint32_t n_classes,
+                                                    uint32_t max_slots, uint32_t* slot_base,
+                                                    uint32_t* cls_begin, const PartTable& parts,
+                                                    uint32_t tile_shift, uint32_t tile_mask,
+                                                    uint32_t* tile_first, DeviceParams* prm,
+                                                    uint32_t my_last, const uint32_t& carry,
+                                                    uint32_t& last_with_slots, const uint32_t* cls_cnt) {
+  if (threadIdx.x < 64) prm->n_changed[threadIdx.x] = prm->n_sampled[threadIdx.x] = 0;
+  if (tile_first) {  // last servant that has slots: one LDS atomic per wave
+    uint32_t v = my_last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(&last_with_slots, v);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint32_t m = carry;
+    slot_base[sv.n] = m;
+    // (behind the last tile: the last servant that has slots, as the end of that tile's run)
+    if (tile_first && m <= max_slots) tile_first[(m + tile_mask) >> tile_shift] = last_with_slots;
+    prm->overflow = m > max_slots ? 1u : 0u;
+    prm->n_slots = m > max_slots ? 0u : m;
+    prm->reserved0 = 0;
+    prm->chunk_sims = 0;
+    prm->granted = 0;
+    prm->consuming = 0;
+    prm->rank_offset = 0;
+    prm->window_miss = 0;
+    prm->batch_seq += 1;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < n_classes; ++c) {
+      cls_begin[c] = acc;
+      acc += cls_cnt[c];
+    }
+    cls_begin[n_classes] = acc;
+    if (parts.n_parts > 1) {
+      // Slots per part -> first global rank of every part (slots are ordered part-major).
+      uint32_t cnt[16];  // kMaxComponents
+      for (uint32_t g = 0; g < parts.n_parts; ++g) cnt[g] = 0;
+      for (uint32_t c = 0; c < n_classes; ++c) cnt[parts.cls_comp[c]] += cls_cnt[c];
+      uint32_t a2 = 0;
+      for (uint32_t g = 0; g < parts.n_parts; ++g) {
+        parts.rank_base[g] = a2;
+        a2 += cnt[g];
+      }
+      parts.rank_base[parts.n_parts] = a2;
+    }
+  }
+}
+
 __device__ __forceinline__ void servant_scan_block(const ServantTable& sv, uint32_t n_classes,
                                                    uint32_t max_slots, uint32_t* slot_base,
                                                    uint32_t* cls_begin, uint32_t* chunk_consuming,
@@ -194,47 +248,8 @@ __device__ __forceinline__ void servant_scan_block(const ServantTable& sv, uint3
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
-  if (threadIdx.x < 64) prm->n_changed[threadIdx.x] = prm->n_sampled[threadIdx.x] = 0;
-  if (tile_first) {  // last servant that has slots: one LDS atomic per wave
-    uint32_t v = my_last;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(&last_with_slots, v);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    uint32_t m = carry;
-    slot_base[sv.n] = m;
-    // (behind the last tile: the last servant that has slots, as the end of that tile's run)
-    if (tile_first && m <= max_slots) tile_first[(m + tile_mask) >> tile_shift] = last_with_slots;
-    prm->overflow = m > max_slots ? 1u : 0u;
-    prm->n_slots = m > max_slots ? 0u : m;
-    prm->reserved0 = 0;
-    prm->chunk_sims = 0;
-    prm->granted = 0;
-    prm->consuming = 0;
-    prm->rank_offset = 0;
-    prm->window_miss = 0;
-    prm->batch_seq += 1;
-    uint32_t acc = 0;
-    for (uint32_t c = 0; c < n_classes; ++c) {
-      cls_begin[c] = acc;
-      acc += cls_cnt[c];
-    }
-    cls_begin[n_classes] = acc;
-    if (parts.n_parts > 1) {
-      // Slots per part -> first global rank of every part (slots are ordered part-major).
-      uint32_t cnt[16];  // kMaxComponents
-      for (uint32_t g = 0; g < parts.n_parts; ++g) cnt[g] = 0;
-      for (uint32_t c = 0; c < n_classes; ++c) cnt[parts.cls_comp[c]] += cls_cnt[c];
-      uint32_t a2 = 0;
-      for (uint32_t g = 0; g < parts.n_parts; ++g) {
-        parts.rank_base[g] = a2;
-        a2 += cnt[g];
-      }
-      parts.rank_base[parts.n_parts] = a2;
-    }
-  }
+  servant_scan_finish(sv, n_classes, max_slots, slot_base, cls_begin, parts, tile_shift, tile_mask,
+                      tile_first, prm, my_last, carry, last_with_slots, cls_cnt);
 }
 
 __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,

@@ -62,7 +62,7 @@ struct BatchPlan {
   bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
   // Bin sort (bin_sort.h) instead of the radix sort: n_bins equal bins over the key space.
   bool binsort = false;
-  uint32_t n_bins = 0, bin_shift = 0;
+  uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   ServantTable sv{};
   ClassLists L{};
   TaskTable T{};
@@ -864,6 +864,22 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     const BinFormat bf = choose_bins(c->kf.key_bits, slot_bound, kMaxBins);
     p.n_bins = bf.n_bins;
     p.bin_shift = bf.shift;
+    // k_bin_sort keeps a record in one LDS word: key bits below the bin | slot | class.
+    p.bin_slot_bits = 1;
+    while (p.bin_slot_bits < 32 && (slot_bound >> p.bin_slot_bits)) ++p.bin_slot_bits;
+    p.bin_cls_bits = 0;
+    while ((1u << p.bin_cls_bits) < C) ++p.bin_cls_bits;
+    // (more, narrower bins when the word is short of room for the key bits below the bin)
+    while (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 && p.n_bins < kMaxBins && p.bin_shift) {
+      p.n_bins <<= 1;
+      --p.bin_shift;
+    }
+    const uint32_t tile = kSortThreads * p.sort_items;
+    if (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 || p.n_tiles > kBinMaxTiles ||
+        (tile & (tile - 1)))
+      p.binsort = false;
+  }
+  if (p.binsort) {
     p.cls_passes = 0;
     p.fused_cls_bits = 0;
     HIP_TRY(c, c->d_binbase.reserve((size_t)(p.n_bins + 1) * (C + 1)));
@@ -972,14 +988,18 @@ void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
   mark(c, 0);
   if (p.binsort) {
     // + one workgroup per bin boundary: the bins' starts in closed form (bin_sort.h)
-    // (n_bins / per workgroups of `per` boundaries each: about one per CU)
-    const uint32_t per = std::min(kBinsPerGroup, std::max(1u, p.n_bins / 256));
-    YDC_LAUNCH(c, "k_servant_scan", k_servant_scan_bins, dim3(1 + p.n_bins / per), dim3(1024),
+    // Next to the scan's workgroup: one workgroup per `per` boundaries, its 2^sub_shift-thread
+    // parts taking them in turn. About 256 workgroups (two of them fit a CU), so that the closed
+    // forms — B x S of them, ~70 instructions each — spread over the whole chip.
+    const uint32_t n_sub = p.n_bins >= 1024 ? 4 : (p.n_bins >= 512 ? 2 : 1);
+    const uint32_t per = n_sub * ceil_div(p.n_bins, n_sub * 510);
+    const uint32_t sub_shift = n_sub == 4 ? 8 : (n_sub == 2 ? 9 : 10);
+    YDC_LAUNCH(c, "k_servant_scan", k_servant_scan_bins, dim3(1 + ceil_div(p.n_bins, per)), dim3(1024),
                (size_t)per * (p.C + 1) * sizeof(uint32_t), c->stream, p.sv, p.C, p.slot_bound_glob,
                c->d_slot_base.p, cls_begin, c->d_chunk_consuming.p, p.K,
                PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, kSortThreads * p.sort_items,
                c->d_tile_first.p, c->d_prm.p, c->kf.cap_bits, c->kf.comp_shift,
-               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, per);
+               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, per, sub_shift);
     mark(c, 1);
     return;
   }
@@ -1022,7 +1042,7 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   uint16_t* cls_by_g = C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr;
   if (p.binsort && gen_blocks) {
     YDC_LAUNCH(c, "k_slot_gen", k_slot_bin, dim3(gen_blocks + cls_blocks), dim3(256),
-               (size_t)8 * p.n_bins, c->stream, p.sv, c->d_slot_base.p, c->d_prm.p, c->kf.cap_bits,
+               (size_t)20 * p.n_bins, c->stream, p.sv, c->d_slot_base.p, c->d_prm.p, c->kf.cap_bits,
                c->d_owner.p, gen_blocks, p.sort_items, p.gbits, ca, c->kf.comp_shift, c->d_tile_first.p,
                BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, C + 1,
                (uint2*)c->d_keys[0].p);
@@ -1056,10 +1076,13 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
   if (p.binsort) {
     // One workgroup per bin (+ one for the chunk prefix): order inside the bins, global ranks,
     // class lists.
+    uint32_t tile_shift = 0;
+    while ((1u << tile_shift) < kSortThreads * p.sort_items) ++tile_shift;
     BinSortArgs ba{(const uint2*)c->d_keys[0].p, BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p},
-                   p.C, p.gbits, c->d_cls_begin.p, (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
-    YDC_LAUNCH(c, "k_bin_sort", k_bin_sort, dim3(p.n_bins + (pending_prefix ? 1 : 0)), dim3(256),
-               (size_t)kBinCap * 8, c->stream, ba, c->d_prm.p, pending_prefix ? pa : PrefixArgs{});
+                   p.C, p.gbits, p.bin_slot_bits, p.bin_cls_bits, tile_shift, p.n_tiles,
+                   c->d_cls_begin.p, (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
+    YDC_LAUNCH(c, "k_bin_sort", k_bin_sort, dim3(p.n_bins + (pending_prefix ? 1 : 0)), dim3(kBinThreads),
+               (size_t)kBinLdsWords * 4, c->stream, ba, c->d_prm.p, pending_prefix ? pa : PrefixArgs{});
     mark(c, 3);
     mark(c, 4);
     return YDC_OK;
