@@ -283,8 +283,10 @@ def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
 
 def test_switchable_fast_paths_off(monkeypatch):
     """The A/B switches select older, slower forms of the same steps (separate class pass,
-    class gather, k_guess_init, one request per loop iteration): same results."""
-    for k in ("YDC_PACKED_CLASS", "YDC_FUSED_CLASS", "YDC_OWN_GUESS", "YDC_PAIR", "YDC_BINSORT"):
+    class gather, k_guess_init, one request per loop iteration, the radix sort, a launch of
+    its own for pass 1): same results."""
+    for k in ("YDC_PACKED_CLASS", "YDC_FUSED_CLASS", "YDC_OWN_GUESS", "YDC_PAIR", "YDC_BINSORT",
+              "YDC_FUSE_PASSES"):
         monkeypatch.setenv(k, "0")
     c = binding.Context(device=0)
     try:

@@ -134,7 +134,7 @@ __device__ __forceinline__ void bin_count_block(const ServantTable& sv, uint32_t
   for (uint32_t i = threadIdx.x; i < nb * row; i += blockDim.x) bt.base[(size_t)j0 * row + i] = cls_cnt[i];
 }
 
-__global__ __launch_bounds__(1024) void k_servant_scan_bins(ServantTable sv, uint32_t n_classes,
+__global__ __launch_bounds__(1024, 8) void k_servant_scan_bins(ServantTable sv, uint32_t n_classes,
                                                             uint32_t max_slots, uint32_t* slot_base,
                                                             uint32_t* cls_begin, uint32_t* chunk_consuming,
                                                             uint32_t n_chunks, PartTable parts,

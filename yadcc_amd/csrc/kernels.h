@@ -294,6 +294,10 @@ struct ClassifyArgs {
   uint32_t* chunk_consuming;  // [chunk * n_parts + part]
   const uint32_t* cls_comp;   // part of every class (n_parts > 1 only)
   uint32_t n_parts;
+  // Nullable, one part: consuming requests among the last `tail_len` requests of every chunk
+  // that has a successor (the warm-ups of matching pass 0, match_kernel.h).
+  uint32_t* chunk_tail;
+  uint32_t tail_len;
 };
 
 __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
@@ -356,6 +360,12 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   if (a.n_parts <= 1) {
     if (consuming && (threadIdx.x & 63) == leader)
       atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
+    // The last wave of a chunk (all of its 64 requests exist: another chunk follows or the
+    // batch ends right here) leaves the count of its last tail_len requests behind.
+    const uint32_t t_wave = t - (threadIdx.x & 63);
+    if (a.chunk_tail && (t_wave + 64) % a.chunk_size == 0 && t_wave + 64 <= a.n_tasks &&
+        (threadIdx.x & 63) == leader)
+      a.chunk_tail[t / a.chunk_size] = (uint32_t)__popcll(consuming >> (64 - a.tail_len));
   } else {
     const uint32_t part = any ? a.cls_comp[first_cls] : 0xFFFFFFFFu;
     while (consuming) {

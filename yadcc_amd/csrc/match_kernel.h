@@ -18,6 +18,12 @@
 //            leaves itself to that follower — a perturbation that needs thousands
 //            of requests to die out is followed by one wave in one launch instead
 //            of one launch per chunk.
+//   pass 0 + 1 (one GPU): the launch of pass 0 does pass 1's work as well — a wave hands the
+//            end state of its pass-0 replay to its successor through tagged 8-byte granules
+//            (MatchBuffers::hand) and, where its own level guess missed its predecessor's end
+//            state, replays its chunk from that state at once. What it leaves behind (flags of
+//            pass 1, checkpoints, end states) is what a separate launch of pass 1 would have
+//            left, minus the chain following; the host goes on with pass 2 if need be.
 //   A pass in which no chunk's end state changed (pass 0: every end state equals the
 //   next chunk's level guess) proves that every chunk's last replay started from its
 //   predecessor's final end state: the result is the sequential one (chunk 0 always
@@ -82,7 +88,23 @@ struct MatchBuffers {
   uint32_t* flags;
   uint32_t* sampled;  // sampled counts of changed end states, same indexing
   uint32_t flag_mask;
+  // Non-NULL (one GPU): the launch of pass 0 is pass 1 as well. [K * C * 4] 8-byte granules
+  // {state word, batch stamp}: a wave publishes the end state of its pass-0 replay here, waits
+  // for its predecessor's, and — where its level guess was off — replays its chunk from that
+  // state at once, the way the next launch would have (k_match_pass, "pass 0 + 1").
+  unsigned long long* hand;
+  // Non-NULL (with `hand`, one part, <= 64 classes): consuming requests among the last kWarmUp
+  // requests of every chunk. Pass 0 then starts every chunk kWarmUp requests early, from the
+  // level guess of THAT point, and throws the warm-up picks away: a level guess that is off by
+  // a slot or two is back on the true track within a few requests, so the state it reaches at
+  // the chunk's first request is almost always its predecessor's end state — and the chunk
+  // needs no second replay.
+  const uint32_t* tail;
 };
+
+constexpr uint32_t kWarmUp = 16;
+
+constexpr uint32_t kHandTries = 1500;  // polls for the predecessor's granules before giving up
 
 constexpr uint32_t kEarlyAt = 16;  // requests into a chunk at which MatchBuffers::early is taken
 
@@ -486,11 +508,12 @@ __device__ __forceinline__ uint32_t match_fast_loop(
 template <int W>
 __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
-                                                   MatchBuffers B, uint32_t pass,
+                                                   MatchBuffers B, uint32_t pass_arg,
                                                    uint32_t flags, uint32_t rshift,
                                                    uint32_t init_fill, SharedIpTable shared,
                                                    DeviceParams* prm) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_ring[];
+  uint32_t pass = pass_arg;  // (becomes 1 when the launch of pass 0 goes on with pass 1)
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
   uint32_t kc = blockIdx.x;  // chunk
@@ -498,6 +521,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   const uint32_t batch_seq = prm->batch_seq;
   const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
   const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
+  const bool warm_mode = own_guess && B.hand != nullptr && B.tail != nullptr && B.n_parts <= 1 &&
+                         B.boundary_in == nullptr && chunk_size >= 64;
   // Level of this lane's class before / after the chunk: global rank of the first slot not yet
   // consumed if consumption followed the slot order of the class's part of the registry.
   uint32_t before0 = 0, before1 = 0;
@@ -506,6 +531,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     const uint32_t part = G > 1 && threadIdx.x < L.n_classes ? B.cls_comp[threadIdx.x] : 0u;
     before0 = B.before[(size_t)kc * G + part];
     before1 = B.before[(size_t)(kc + 1) * G + part];
+    if (warm_mode && kc > 0) before0 -= B.tail[kc - 1];  // the level kWarmUp requests earlier
     if (B.base_totals) {
       uint32_t base = 0;
       for (uint32_t r = 0; r < B.base_rank; ++r) base += B.base_totals[(size_t)r * B.base_stride + part];
@@ -525,7 +551,11 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   const bool multi = B.boundary_in != nullptr;
   // Unique per pass launch and ever growing (the batch counter lives on the device, so a
   // replayed graph gets fresh stamps too).
-  const unsigned long long stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
+  unsigned long long stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
+  // Pass 0 + 1 in one launch (MatchBuffers::hand).
+  const bool fuse = B.hand != nullptr && pass_arg == 0 && !multi;
+  bool fused_stage = false;   // this wave is in its pass-1 part
+  ClassState start0[W] = {};  // the state the pass-0 replay started from (as recorded: clamped)
 
   // Layout: the ranks of all rings first, the generation indexes behind them. ring_total
   // entries per array (flags >> 8; C << rshift <= ring_total): fewer entries = less LDS per
@@ -687,6 +717,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     }
   }
 
+  bool warm = warm_mode && kc > 0;  // this replay starts kWarmUp requests before the chunk
   bool ring_ready = false;
   uint64_t holes[W] = {};
   uint32_t followed = 0;  // chunks this wave has carried on into
@@ -752,13 +783,14 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         nx_shi = T.self_hi[tl];
       }
     };
-    stage(t0);
+    stage(warm ? t0 - kWarmUp : t0);
     ClassState early_cp{};
     if (W == 1 && pass != 0 && lane < C) early_cp = B.early[(size_t)kc * C + lane];
 
-    for (uint32_t tb = t0; tb < t1; tb += 64) {
+    for (uint32_t tb = warm ? t0 - kWarmUp : t0; tb < t1; tb = tb < t0 ? t0 : tb + 64) {
+      const bool warm_blk = tb < t0;  // the warm-up requests: picks are made and thrown away
       // ---- checkpoint: stop if the previous replay was in the same state here ----
-      {
+      if (!warm_blk) {
         ClassState* cp = B.checkpoint + (size_t)(tb >> 6) * C;
         bool differs = false;
 #pragma unroll
@@ -768,6 +800,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
             const ClassState s = w.state(j);
             if (pass == 0) {
               cp[c] = s;
+              if (tb == t0) start0[j] = s;  // what this chunk's replay starts from
             } else if (!class_state_equal(nx_cp[j], s)) {
               differs = true;
               cp[c] = s;
@@ -790,7 +823,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
       const uint32_t slo = nx_slo, shi = nx_shi;
       const uint32_t tl = tb + lane;
-      stage(tb + 64);
+      stage(warm_blk ? t0 : tb + 64);
 
       if (!ring_ready) {
         // First block that really runs: fill the rings.
@@ -808,7 +841,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       const uint64_t dyn_self = __ballot(shi == kSelfShared);
       uint32_t res = kIdxTimeout;
       uint32_t keep = 64;  // results of this block to store (fewer after an early stop)
-      const uint32_t cnt = min(64u, t1 - tb);
+      const uint32_t cnt = warm_blk ? kWarmUp : min(64u, t1 - tb);
 
       // General step for request i: holes, own-servant heads, last-resort self pick. The
       // shared state machine (dispatch_core.h) advances the class; its ring is topped up
@@ -1029,7 +1062,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
       // No eligible class at all: EnvironmentNotFound (task_dispatcher.cc:105-108).
       if (many == 0) res = kIdxEnvNotFound;
-      if (tl < t1 && lane < keep) B.slot_of[tl] = res;
+      if (!warm_blk && tl < t1 && lane < keep) B.slot_of[tl] = res;
       if (stopped_early) break;
     }
     if (count_sims && lane == 0) atomicAdd(&prm->chunk_sims, 1u);
@@ -1058,6 +1091,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
     }
     bool changed = __ballot(differs) != 0;
+    // With warm-ups the successor does not start from its level guess: pass 0 certifies nothing.
+    if (pass == 0 && warm_mode && kc + 1 < n_chunks) changed = true;
     // The first chunk of the next rank starts from a guess of its own in pass 0.
     if (pass == 0 && kc + 1 == n_chunks && B.has_successor) changed = true;
     // "Not final yet": everybody stores the same 1 (no same-address atomics).
@@ -1065,8 +1100,74 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       B.flags[pass & B.flag_mask] = 1;
       if ((kc & 15u) == 0) atomicAdd(&B.sampled[pass & B.flag_mask], 1u);
     }
-    if (pass == 0) return;
+    if (pass == 0) {
+      if (!fuse) return;
+      // ---- pass 1 of this chunk, in the same launch. The end state of the pass-0 replay goes
+      // out in 8-byte granules {word, batch stamp} (agent-scope atomics on both sides: every
+      // granule carries its own validity, no fence, no ordering between granules needed) ...
+      const uint32_t hstamp = batch_seq;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const uint32_t c = lane + 64 * j;
+        if (c < C) {
+          const ClassState s = w.state(j);
+          unsigned long long* g = B.hand + ((size_t)kc * C + c) * 4;
+          const unsigned long long tag = (unsigned long long)hstamp << 32;
+          __hip_atomic_store(g + 0, tag | s.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 1, tag | s.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 2, tag | s.hown_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 3, tag | s.hown_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (kc == 0) return;  // chunk 0 started from the true state
+      // ... and the predecessor's comes in the same way. Bounded: a wave that does not get it
+      // (HIP promises nothing about dispatch order) says "not final" and leaves its chunk to
+      // the next launch, which checks it like any other pass.
+      ClassState pred[W];
+      for (uint32_t tries = 0;; ++tries) {
+        bool missing = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const uint32_t c = lane + 64 * j;
+          pred[j] = ClassState{};
+          if (c < C) {
+            unsigned long long* g = B.hand + ((size_t)(kc - 1) * C + c) * 4;
+            const unsigned long long v0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            missing |= (uint32_t)(v0 >> 32) != hstamp || (uint32_t)(v1 >> 32) != hstamp ||
+                       (uint32_t)(v2 >> 32) != hstamp || (uint32_t)(v3 >> 32) != hstamp;
+            pred[j].cursor = (uint32_t)v0;
+            pred[j].lo = (uint32_t)v1;
+            pred[j].hown_lo = (uint32_t)v2;
+            pred[j].hown_hi = (uint32_t)v3;
+          }
+        }
+        if (__ballot(missing) == 0) break;
+        if (tries >= kHandTries) {
+          if (lane == 0) B.flags[1u & B.flag_mask] = 1;
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      bool off = false;  // did this chunk's level guess miss the predecessor's end state?
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (lane + 64 * j < C) off |= !class_state_equal(start0[j], pred[j]);
+      if (__ballot(off) == 0) return;  // consistent
+      pass = 1;
+      stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
+      fused_stage = true;
+#pragma unroll
+      for (int j = 0; j < W; ++j) w.set_state(j, pred[j], lane + 64 * j, C);
+      ring_ready = false;
+      warm = false;
+      continue;  // replay chunk kc from the predecessor's end state, with pass 1's early stops
+    }
     if (!changed) return;  // nothing downstream is affected
+    // (Within the launch of pass 0 every chunk belongs to its own wave: no following.)
+    if (fused_stage) return;
     // The next chunk is now inconsistent. Follow the chain unless its own wave (or
     // another follower) has it in this pass; then the next pass picks it up.
     if (kc + 1 >= n_chunks) return;

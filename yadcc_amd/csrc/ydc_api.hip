@@ -61,6 +61,7 @@ struct BatchPlan {
   bool packed = false;  // the sort moves 8-byte (key, value) records (32-bit keys)
   bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
   // Bin sort (bin_sort.h) instead of the radix sort: n_bins equal bins over the key space.
+  bool fuse01 = false;  // the launch of matching pass 0 is pass 1 as well (no launch for pass 1)
   bool binsort = false;
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   ServantTable sv{};
@@ -106,9 +107,10 @@ struct ydc_context {
   DevBuf<uint32_t> d_binbase, d_binfill;  // bin sort: starts of the bins per class, arrival counters
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
+  DevBuf<uint32_t> d_chunk_tail;  // consuming requests among the last kWarmUp of every chunk
   DevBuf<uint32_t> d_running_out;
   DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint, d_early;
-  DevBuf<unsigned long long> d_claim;
+  DevBuf<unsigned long long> d_claim, d_hand;  // d_hand: hand-off granules of the pass 0 + 1 launch
   uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
 
   // Multi-GPU group (ydc_group_*): this context is one rank of a sharded dispatcher.
@@ -213,6 +215,7 @@ struct ydc_context {
   // Bin sort (three launches, bin_sort.h) for registries that offer at most this many slots;
   // a batch with a bin too large for LDS is repeated with the radix sort, which then stays
   // (binsort_blocked) until the registry changes structure.
+  bool opt_fuse_passes = true;  // one GPU: the launch of pass 0 does pass 1 as well (match_kernel.h)
   bool opt_binsort = true;
   uint32_t opt_binsort_max_slots = 600000;
   bool binsort_blocked = false;
@@ -492,6 +495,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT")) c->opt_binsort = atoi(s) != 0;
+  if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
@@ -958,6 +962,17 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.flags = c->d_prm.p->n_changed;
     p.mb.sampled = c->d_prm.p->n_sampled;
     p.mb.flag_mask = 63;
+    p.fuse01 = c->opt_fuse_passes && c->group.n_ranks == 0;
+    if (p.fuse01) {
+      if ((size_t)K * C * 4 > c->d_hand.cap) {
+        // Granules are valid by their batch stamp (never 0): a fresh array starts at 0.
+        HIP_TRY(c, c->d_hand.reserve((size_t)K * C * 4));
+        HIP_TRY(c, hipMemsetAsync(c->d_hand.p, 0, c->d_hand.cap * 8, c->stream));
+      }
+      p.mb.hand = c->d_hand.p;
+      HIP_TRY(c, c->d_chunk_tail.reserve((size_t)K + 1));
+      p.mb.tail = c->n_parts <= 1 && p.mb.before ? c->d_chunk_tail.p : nullptr;
+    }
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
     p.ring_total = c->opt_ring_total;
@@ -1024,7 +1039,8 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       c->tables.env_ver_mask.empty() ? nullptr : c->d_env_ver_mask.p,
                       (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
-                      c->d_chunk_consuming.p, c->d_cls_comp.p, c->n_parts};
+                      c->d_chunk_consuming.p, c->d_cls_comp.p, c->n_parts,
+                      p.mb.tail ? c->d_chunk_tail.p : nullptr, kWarmUp};
   }
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
@@ -1196,6 +1212,7 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
 // One matching pass (match_kernel.h). device_check: return at once when the previous pass
 // found every chunk consistent.
 void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t device_check) {
+  if (p.fuse01 && pass == 1) return;  // (the launch of pass 0 did it)
   const size_t lds = (size_t)p.ring_total * 8;
   device_check |= c->debug_sim ? 2u : 0u;
   device_check |= c->opt_pair ? 4u : 0u;
