@@ -33,6 +33,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kIdxTimeout = 0xFFFFFFFFu;      // WaitStatus::Timeout
 constexpr uint32_t kIdxEnvNotFound = 0xFFFFFFFEu;  // WaitStatus::EnvironmentNotFound
 constexpr uint32_t kSelfShared = 0xFFFFFFFEu;      // TaskInfo::self_hi marker: resolve `self` at run time
+constexpr uint32_t kSelfServant = 0xFFFFFFFDu;     // TaskInfo::self_hi marker: self_lo is a servant index
 constexpr uint32_t kFlagDedicated = 1u;
 constexpr uint32_t kFlagLowMemory = 2u;
 constexpr uint32_t kMaxWaveClasses = 256;  // lane-per-class kernel: 4 classes per lane
@@ -293,6 +294,9 @@ YDC_HD uint32_t servant_slots_before(uint32_t nproc, uint32_t load, uint32_t max
 //     requestor's own servant (kNone, kNone: none). self_hi == kSelfShared: several
 //     servants share the requestor's host and self_lo is the first entry of the
 //     host's group in the ip table (resolved at run time, see SharedIpTable).
+//     self_hi == kSelfServant: self_lo is the index of the requestor's own servant; the
+//     matching kernel turns it into the slot range when it stages the request (the bin sort's
+//     front classifies requests in the launch that computes slot_base, bin_sort.h).
 struct TaskTable {
   const uint64_t* mask;
   const uint32_t* self_lo;

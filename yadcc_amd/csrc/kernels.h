@@ -298,6 +298,11 @@ struct ClassifyArgs {
   // that has a successor (the warm-ups of matching pass 0, match_kernel.h).
   uint32_t* chunk_tail;
   uint32_t tail_len;
+  // The bin sort's front (bin_sort.h) classifies in the launch that computes slot_base, so:
+  // by_servant != 0: an own servant is left as its index (self_hi = kSelfServant); per_wave != 0:
+  // chunk_consuming is indexed by WAVE of 64 requests ([wave * n_parts + part], plain stores,
+  // every entry written — nothing to reset) and the chunk prefix adds the waves of a chunk up.
+  uint32_t by_servant, per_wave;
 };
 
 __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
@@ -342,6 +347,9 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
     if (i + 1 < a.n_servants && a.ip_sorted[i + 1] == rip) {
       lo = i;  // several servants on the host: `self` is resolved at replay time
       hi = kSelfShared;
+    } else if (a.by_servant) {
+      lo = a.ip_servant[i];
+      hi = kSelfServant;
     } else {
       const uint32_t s = a.ip_servant[i];
       const uint32_t b = a.slot_base[s], e = a.slot_base[s + 1];
@@ -357,7 +365,19 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   // lanes of a wave fall into the same chunk: one atomic per wave (and part).
   uint64_t consuming = __ballot(any != 0);
   const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(true));
-  if (a.n_parts <= 1) {
+  if (a.per_wave) {
+    // One entry per wave and part, written whatever the count.
+    const uint32_t G = a.n_parts ? a.n_parts : 1u;
+    const uint32_t part = G > 1 && any ? a.cls_comp[first_cls] : 0u;
+    for (uint32_t g = 0; g < G; ++g) {
+      const uint64_t m = __ballot(any != 0 && part == g);
+      if ((threadIdx.x & 63) == leader) a.chunk_consuming[(size_t)(t >> 6) * G + g] = (uint32_t)__popcll(m);
+    }
+    const uint32_t t_wave = t - (threadIdx.x & 63);
+    if (G == 1 && a.chunk_tail && (t_wave + 64) % a.chunk_size == 0 && t_wave + 64 <= a.n_tasks &&
+        (threadIdx.x & 63) == leader)
+      a.chunk_tail[t / a.chunk_size] = (uint32_t)__popcll(consuming >> (64 - a.tail_len));
+  } else if (a.n_parts <= 1) {
     if (consuming && (threadIdx.x & 63) == leader)
       atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
     // The last wave of a chunk (all of its 64 requests exist: another chunk follows or the
@@ -386,6 +406,9 @@ struct PrefixArgs {
   uint32_t n_chunks;
   uint32_t* before;                 // [(n_chunks + 1) * n_parts], row n_chunks: the totals
   uint32_t n_parts;
+  // != 0: chunk_consuming holds one entry per wave of 64 requests (ClassifyArgs::per_wave),
+  // n_waves of them, waves_per_chunk to a chunk.
+  uint32_t waves_per_chunk, n_waves;
 };
 
 __device__ __forceinline__ void chunk_prefix_block(const PrefixArgs& a, DeviceParams* prm) {
@@ -396,14 +419,22 @@ __device__ __forceinline__ void chunk_prefix_block(const PrefixArgs& a, DevicePa
   const uint32_t per = (a.n_chunks + blockDim.x - 1) / blockDim.x;
   const uint32_t b = min(a.n_chunks, threadIdx.x * per), e = min(a.n_chunks, b + per);
   uint32_t all = 0;
+  // Consuming requests of chunk k, part g.
+  auto count = [&](uint32_t k, uint32_t g) {
+    if (!a.waves_per_chunk) return a.chunk_consuming[(size_t)k * G + g];
+    uint32_t c = 0;
+    for (uint32_t w = k * a.waves_per_chunk; w < min(a.n_waves, (k + 1) * a.waves_per_chunk); ++w)
+      c += a.chunk_consuming[(size_t)w * G + g];
+    return c;
+  };
   for (uint32_t g = 0; g < G; ++g) {  // (one part almost always)
     uint32_t sum = 0;
-    for (uint32_t k = b; k < e; ++k) sum += a.chunk_consuming[(size_t)k * G + g];
+    for (uint32_t k = b; k < e; ++k) sum += count(k, g);
     uint32_t total;
     uint32_t acc = block_exclusive_scan(sum, lds, &total);
     for (uint32_t k = b; k < e; ++k) {
       a.before[(size_t)k * G + g] = acc;
-      acc += a.chunk_consuming[(size_t)k * G + g];
+      acc += count(k, g);
     }
     if (threadIdx.x == 0) a.before[(size_t)a.n_chunks * G + g] = total;
     all += total;

@@ -781,6 +781,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       if (tl < t1) {
         nx_slo = T.self_lo[tl];
         nx_shi = T.self_hi[tl];
+        if (nx_shi == kSelfServant) {
+          // The request's own servant by index (bin_sort.h): its slot range, if it offers any.
+          const uint32_t b = shared.slot_base[nx_slo], e = shared.slot_base[nx_slo + 1];
+          nx_slo = e > b ? b : kNone;
+          nx_shi = e > b ? e : kNone;
+        }
       }
     };
     stage(warm ? t0 - kWarmUp : t0);

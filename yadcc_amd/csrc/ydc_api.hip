@@ -64,6 +64,7 @@ struct BatchPlan {
   bool fuse01 = false;  // the launch of matching pass 0 is pass 1 as well (no launch for pass 1)
   bool binsort = false;
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
+  uint32_t bin_group = 0, bin_tiles = 0;  // servants per slot tile, slot tiles (k_front_bins)
   ServantTable sv{};
   ClassLists L{};
   TaskTable T{};
@@ -104,7 +105,7 @@ struct ydc_context {
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
-  DevBuf<uint32_t> d_binbase, d_binfill;  // bin sort: starts of the bins per class, arrival counters
+  DevBuf<uint32_t> d_binbase, d_binruns;  // bin sort: starts of the bins per class, run table of the slot tiles
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_chunk_tail;  // consuming requests among the last kWarmUp of every chunk
@@ -863,7 +864,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
   // the value (or a single class), one GPU. Decided from the registry alone.
   p.binsort = c->opt_binsort && !c->binsort_blocked && c->kf.exact && p.key32 && C >= 1 &&
               C <= kMaxWaveClasses && slot_bound && slot_bound <= c->opt_binsort_max_slots &&
-              (C == 1 || p.gbits) && c->group.n_ranks == 0;
+              (C == 1 || p.gbits) && c->group.n_ranks == 0 && p.S <= kBinMaxServants &&
+              c->kf.cap_bits <= 11;
   if (p.binsort) {
     const BinFormat bf = choose_bins(c->kf.key_bits, slot_bound, kMaxBins);
     p.n_bins = bf.n_bins;
@@ -878,17 +880,19 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
       p.n_bins <<= 1;
       --p.bin_shift;
     }
-    const uint32_t tile = kSortThreads * p.sort_items;
-    if (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 || p.n_tiles > kBinMaxTiles ||
-        (tile & (tile - 1)))
-      p.binsort = false;
+    // Slot tiles: G consecutive servants, at most 2048 slots (a servant offers < 2^cap_bits).
+    p.bin_group = std::min(kBinMaxGroup, std::max(1u, 2048u >> c->kf.cap_bits));
+    p.bin_tiles = ceil_div(p.S, p.bin_group);
+    if (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 || p.bin_tiles > kBinMaxTiles) p.binsort = false;
   }
   if (p.binsort) {
     p.cls_passes = 0;
     p.fused_cls_bits = 0;
     HIP_TRY(c, c->d_binbase.reserve((size_t)(p.n_bins + 1) * (C + 1)));
-    HIP_TRY(c, c->d_binfill.reserve(p.n_bins));
+    HIP_TRY(c, c->d_binruns.reserve((size_t)p.bin_tiles * p.n_bins));
     HIP_TRY(c, c->d_rank_to_g.reserve(slot_bound));
+    // (consuming counts per wave of 64 requests instead of per chunk)
+    HIP_TRY(c, c->d_chunk_consuming.reserve(((size_t)ceil_div(std::max(N, 1u), 64) + 1) * c->n_parts));
   }
   HIP_TRY(c, c->d_owner.reserve(slot_bound));
   HIP_TRY(c, c->d_mask.reserve((size_t)N * W));
@@ -1001,20 +1005,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
 void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
   c->ksamples_used = 0;
   mark(c, 0);
-  if (p.binsort) {
-    // + one workgroup per bin boundary: the bins' starts in closed form (bin_sort.h)
-    // Next to the scan's workgroup: one workgroup per `per` boundaries, its 2^sub_shift-thread
-    // parts taking them in turn. About 256 workgroups (two of them fit a CU), so that the closed
-    // forms — B x S of them, ~70 instructions each — spread over the whole chip.
-    const uint32_t n_sub = p.n_bins >= 1024 ? 4 : (p.n_bins >= 512 ? 2 : 1);
-    const uint32_t per = n_sub * ceil_div(p.n_bins, n_sub * 510);
-    const uint32_t sub_shift = n_sub == 4 ? 8 : (n_sub == 2 ? 9 : 10);
-    YDC_LAUNCH(c, "k_servant_scan", k_servant_scan_bins, dim3(1 + ceil_div(p.n_bins, per)), dim3(1024),
-               (size_t)per * (p.C + 1) * sizeof(uint32_t), c->stream, p.sv, p.C, p.slot_bound_glob,
-               c->d_slot_base.p, cls_begin, c->d_chunk_consuming.p, p.K,
-               PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, kSortThreads * p.sort_items,
-               c->d_tile_first.p, c->d_prm.p, c->kf.cap_bits, c->kf.comp_shift,
-               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, per, sub_shift);
+  if (p.binsort) {  // (no scan: k_front_bins does without, see enqueue_gen)
     mark(c, 1);
     return;
   }
@@ -1040,7 +1031,8 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
                       c->d_chunk_consuming.p, c->d_cls_comp.p, c->n_parts,
-                      p.mb.tail ? c->d_chunk_tail.p : nullptr, kWarmUp};
+                      p.mb.tail ? c->d_chunk_tail.p : nullptr, kWarmUp,
+                      p.binsort ? 1u : 0u, p.binsort ? 1u : 0u};
   }
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
@@ -1056,12 +1048,14 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   const uint32_t* r_first = p.win ? c->group.d_r_first.p : nullptr;
   const uint32_t* gbase = p.win ? c->d_slot_base.p : nullptr;
   uint16_t* cls_by_g = C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr;
-  if (p.binsort && gen_blocks) {
-    YDC_LAUNCH(c, "k_slot_gen", k_slot_bin, dim3(gen_blocks + cls_blocks), dim3(256),
-               (size_t)20 * p.n_bins, c->stream, p.sv, c->d_slot_base.p, c->d_prm.p, c->kf.cap_bits,
-               c->d_owner.p, gen_blocks, p.sort_items, p.gbits, ca, c->kf.comp_shift, c->d_tile_first.p,
-               BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p}, C + 1,
-               (uint2*)c->d_keys[0].p);
+  if (p.binsort && gen) {
+    // Bin boundaries | slot tiles | requests: one launch, no workgroup waits for another.
+    const BinTable bt{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles};
+    const size_t lds_words = std::max<size_t>((size_t)5 * p.n_bins + 7 * p.bin_group + 1, C + 1);
+    YDC_LAUNCH(c, "k_front_bins", k_front_bins, dim3(p.n_bins + p.bin_tiles + cls_blocks), dim3(256),
+               lds_words * 4, c->stream, p.sv, C, p.slot_bound_glob, c->d_slot_base.p, c->d_cls_begin.p,
+               PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p}, c->d_prm.p, c->kf.cap_bits,
+               c->kf.comp_shift, p.gbits, bt, c->d_owner.p, (uint2*)c->d_keys[0].p, ca);
     return;
   }
   if (p.key32) {
@@ -1079,24 +1073,29 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   }
 }
 
+// What the chunk prefix reads: counts per chunk, or (bin sort) per wave of 64 requests.
+PrefixArgs prefix_args(ydc_context* c, const BatchPlan& p) {
+  return PrefixArgs{c->d_chunk_consuming.p, p.K, c->d_before.p, c->n_parts,
+                    p.binsort ? p.cs / 64 : 0u, p.binsort ? ceil_div(p.N, 64) : 0u};
+}
+
 // Sort by key + class lists. prefix_pending: the chunk prefix of the consuming counts still
 // has to be computed — it goes with the first histogram launch (one more workgroup).
 int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
-  const uint32_t N = p.N, K = p.K;
+  const uint32_t N = p.N;
   void* keys[2] = {c->d_keys[0].p, c->d_keys[1].p};
   uint32_t* vals[2] = {c->d_vals[0].p, c->d_vals[1].p};
   int cur = 0;
-  PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, c->n_parts};
+  const PrefixArgs pa = prefix_args(c, p);
   const PrefixArgs* pending_prefix = N && prefix_pending ? &pa : nullptr;
   mark(c, 2);
   if (p.binsort) {
     // One workgroup per bin (+ one for the chunk prefix): order inside the bins, global ranks,
     // class lists.
-    uint32_t tile_shift = 0;
-    while ((1u << tile_shift) < kSortThreads * p.sort_items) ++tile_shift;
-    BinSortArgs ba{(const uint2*)c->d_keys[0].p, BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binfill.p},
-                   p.C, p.gbits, p.bin_slot_bits, p.bin_cls_bits, tile_shift, p.n_tiles,
-                   c->d_cls_begin.p, (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
+    BinSortArgs ba{(const uint2*)c->d_keys[0].p,
+                   BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles},
+                   p.C, p.gbits, p.bin_slot_bits, p.bin_cls_bits, c->d_slot_base.p, c->d_cls_begin.p,
+                   (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
     YDC_LAUNCH(c, "k_bin_sort", k_bin_sort, dim3(p.n_bins + (pending_prefix ? 1 : 0)), dim3(kBinThreads),
                (size_t)kBinLdsWords * 4, c->stream, ba, c->d_prm.p, pending_prefix ? pa : PrefixArgs{});
     mark(c, 3);
@@ -1201,7 +1200,7 @@ int enqueue_front(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
     if (int rc = enqueue_sort(c, p, false)) return rc;
     if (int rc = stage_host_requests(c)) return rc;
     enqueue_gen(c, p, tk, false, true);
-    PrefixArgs pa{c->d_chunk_consuming.p, p.K, c->d_before.p, c->n_parts};
+    const PrefixArgs pa = prefix_args(c, p);
     YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, c->stream, pa, c->d_prm.p);
     return enqueue_front_b(c, p, nullptr);
   }
@@ -1383,7 +1382,7 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
 }
 
 // Debugging aid (YDC_BINSORT_VERIFY=1): the bin sort's outputs — global order, class lists —
-// against a host sort of the very records k_slot_bin staged. Waits for the stream.
+// against a host sort of the very records k_front_bins staged. Waits for the stream.
 int verify_binsort(ydc_context* c, const BatchPlan& p) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   DeviceParams prm;
@@ -1394,25 +1393,28 @@ int verify_binsort(ydc_context* c, const BatchPlan& p) {
     return YDC_OK;
   }
   std::vector<uint2> stage(M), list(M);
-  std::vector<uint32_t> r2g(M), cls_begin(C + 1), base((size_t)(p.n_bins + 1) * row), fill(p.n_bins);
+  std::vector<uint32_t> r2g(M), cls_begin(C + 1), base((size_t)(p.n_bins + 1) * row);
   HIP_TRY(c, hipMemcpy(stage.data(), c->d_keys[0].p, (size_t)M * 8, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(list.data(), c->d_keys[1].p, (size_t)M * 8, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(r2g.data(), c->d_rank_to_g.p, (size_t)M * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(cls_begin.data(), c->d_cls_begin.p, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(base.data(), c->d_binbase.p, base.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(fill.data(), c->d_binfill.p, fill.size() * 4, hipMemcpyDeviceToHost));
   const uint32_t gmask = p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu;
   uint32_t bad = 0, max_bin = 0;
   auto complain = [&](const char* what, uint32_t at, uint32_t got, uint32_t want) {
     if (++bad <= 12) fprintf(stderr, "[ydc binsort verify] %s at %u: device %u, host %u\n", what, at, got, want);
   };
   if (base[(size_t)p.n_bins * row + C] != M) complain("total of the last boundary row", p.n_bins, base[(size_t)p.n_bins * row + C], M);
-  for (uint32_t j = 0; j < p.n_bins; ++j) {
-    const uint32_t n = base[(size_t)(j + 1) * row + C] - base[(size_t)j * row + C];
-    max_bin = std::max(max_bin, n);
-    if (fill[j] != n) complain("records that arrived in bin", j, fill[j], n);
-    for (uint32_t i = base[(size_t)j * row + C]; i < base[(size_t)j * row + C] + n && i < M; ++i)
-      if ((stage[i].x >> p.bin_shift) != j) complain("bin of the staged record", i, stage[i].x >> p.bin_shift, j);
+  {
+    // The closed-form bin starts against a count over the staged records (tile-major, any order).
+    std::vector<uint32_t> cnt(p.n_bins + 1, 0);
+    for (uint32_t i = 0; i < M; ++i) cnt[std::min(stage[i].x >> p.bin_shift, p.n_bins)]++;
+    uint32_t acc = 0;
+    for (uint32_t j = 0; j < p.n_bins; ++j) {
+      if (base[(size_t)j * row + C] != acc) complain("start of bin", j, base[(size_t)j * row + C], acc);
+      max_bin = std::max(max_bin, cnt[j]);
+      acc += cnt[j];
+    }
   }
   std::vector<uint2> sorted(stage);
   std::sort(sorted.begin(), sorted.end(), [&](const uint2& a, const uint2& b) {
@@ -1916,7 +1918,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       enqueue_scan(c, p, g.d_cls_begin_glob.p);
       enqueue_gen(c, p, tk, false, true);  // classification only
       if (N) {
-        PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, P};
+        PrefixArgs pa{c->d_chunk_consuming.p, K, c->d_before.p, P, 0u, 0u};
         YDC_LAUNCH(c, "k_chunk_prefix", k_chunk_prefix, dim3(1), dim3(1024), 0, st, pa, prm);
       }
     }
