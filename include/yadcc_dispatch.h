@@ -96,7 +96,7 @@ typedef struct ydc_stats {
   uint32_t n_tasks, n_servants, n_classes;
   uint32_t n_slots;        /* free (servant, running) slots generated */
   uint32_t key_bits;       /* significant bits of the slot sort key */
-  uint32_t radix_passes;
+  uint32_t radix_passes;   /* key passes of the radix sort; 0: the bin sort ordered the slots */
   uint32_t n_chunks;       /* task chunks simulated in parallel */
   uint32_t rounds;         /* speculation rounds until the chunk states were consistent */
   uint32_t chunk_sims;     /* chunk simulations executed over all rounds */

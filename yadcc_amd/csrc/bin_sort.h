@@ -80,11 +80,11 @@ __device__ __forceinline__ void front_bin_boundary(const ServantTable& sv, uint3
   const uint64_t K = (uint64_t)j << bt.shift;
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, all = 0;
 #pragma unroll 1
-  for (uint32_t s0 = threadIdx.x; s0 < sv.n; s0 += 2 * blockDim.x) {
-    // Two servants per round, their column loads in flight together (clamped index).
-    uint32_t cls[2], run[2], nproc[2], load[2], mt[2], fl[2];
+  for (uint32_t s0 = threadIdx.x; s0 < sv.n; s0 += 4 * blockDim.x) {
+    // Four servants per round, their column loads in flight together (clamped index).
+    uint32_t cls[4], run[4], nproc[4], load[4], mt[4], fl[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const uint32_t s = min(s0 + u * blockDim.x, sv.n - 1);
       cls[u] = sv.class_of[s];
       run[u] = sv.running[s];
@@ -94,7 +94,7 @@ __device__ __forceinline__ void front_bin_boundary(const ServantTable& sv, uint3
       fl[u] = sv.flags[s];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 4; ++u) {
       if (s0 + u * blockDim.x >= sv.n || cls[u] == kNone) continue;
       uint32_t cnt;
       if (j == bt.n_bins) {  // everything is below the end of the key space
@@ -183,26 +183,7 @@ __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t
   uint32_t* col = fsm + 5 * B;        // [6][G] the tile's servants: class, nproc, load, max_tasks, running, flags
   uint32_t* lbase = col + 6 * G;      // [G + 1] local prefix of their slot counts
   const uint32_t s0 = tile * G, ns = min(G, sv.n - s0);
-  // Slots of the servants before the tile (its first generation index).
-  uint32_t mine = 0;
-#pragma unroll 1
-  for (uint32_t sa = threadIdx.x; sa < s0; sa += 2 * blockDim.x) {
-    uint32_t cls[2], run[2], nproc[2], load[2], mt[2], fl[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const uint32_t s = min(sa + u * blockDim.x, sv.n - 1);
-      cls[u] = sv.class_of[s];
-      run[u] = sv.running[s];
-      nproc[u] = sv.nproc[s];
-      load[u] = sv.load[s];
-      mt[u] = sv.max_tasks[s];
-      fl[u] = sv.flags[s];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (sa + u * blockDim.x < s0 && cls[u] != kNone)
-        mine += servant_slot_count(nproc[u], load[u], mt[u], run[u], fl[u]);
-  }
+  // The tile's own servants (loads issued ahead of the long loop below).
   if (threadIdx.x < ns) {
     const uint32_t s = s0 + threadIdx.x;
     const uint32_t cls = sv.class_of[s], nproc = sv.nproc[s], load = sv.load[s], mt = sv.max_tasks[s],
@@ -214,6 +195,26 @@ __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t
     col[4 * G + threadIdx.x] = run;
     col[5 * G + threadIdx.x] = fl;
     lbase[threadIdx.x] = cls == kNone ? 0u : servant_slot_count(nproc, load, mt, run, fl);
+  }
+  // Slots of the servants before the tile (its first generation index).
+  uint32_t mine = 0;
+#pragma unroll 1
+  for (uint32_t sa = threadIdx.x; sa < s0; sa += 8 * blockDim.x) {
+    uint32_t cls[8], run[8], nproc[8], load[8], mt[8], fl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t s = min(sa + u * blockDim.x, sv.n - 1);
+      cls[u] = sv.class_of[s];
+      run[u] = sv.running[s];
+      nproc[u] = sv.nproc[s];
+      load[u] = sv.load[s];
+      mt[u] = sv.max_tasks[s];
+      fl[u] = sv.flags[s];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (sa + u * blockDim.x < s0 && cls[u] != kNone)
+        mine += servant_slot_count(nproc[u], load[u], mt[u], run[u], fl[u]);
   }
   for (uint32_t d = threadIdx.x; d < 4 * B; d += blockDim.x) wcnt_all[d] = 0;
   uint32_t base;
@@ -321,14 +322,15 @@ __global__ __launch_bounds__(256) void k_front_bins(ServantTable sv, uint32_t n_
                                                     PartTable parts, DeviceParams* prm, uint32_t cap_bits,
                                                     uint32_t comp_shift, uint32_t gbits, BinTable bt,
                                                     uint32_t* owner, uint2* stage, ClassifyArgs ca) {
-  if (blockIdx.x < bt.n_bins) {
-    front_bin_boundary(sv, n_classes, parts, cap_bits, comp_shift, bt, blockIdx.x + 1, max_slots, slot_base,
+  const uint32_t blk = blockIdx.x;
+  if (blk < bt.n_bins) {
+    front_bin_boundary(sv, n_classes, parts, cap_bits, comp_shift, bt, blk + 1, max_slots, slot_base,
                        cls_begin, prm);
-  } else if (blockIdx.x < bt.n_bins + bt.n_tiles) {
-    front_slot_tile(sv, blockIdx.x - bt.n_bins, cap_bits, comp_shift, gbits, parts.cls_comp, parts.n_parts,
+  } else if (blk < bt.n_bins + bt.n_tiles) {
+    front_slot_tile(sv, blk - bt.n_bins, cap_bits, comp_shift, gbits, parts.cls_comp, parts.n_parts,
                     bt, max_slots, slot_base, owner, stage);
   } else {
-    task_classify_block(ca, blockIdx.x - bt.n_bins - bt.n_tiles, prm);
+    task_classify_block(ca, blk - bt.n_bins - bt.n_tiles, prm);
   }
 }
 

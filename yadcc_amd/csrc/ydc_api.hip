@@ -881,6 +881,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
       --p.bin_shift;
     }
     // Slot tiles: G consecutive servants, at most 2048 slots (a servant offers < 2^cap_bits).
+    // (Smaller tiles were measured: more workgroups that each add up the servants before them
+    // cost more than the fullest tile's shorter loop saves.)
     p.bin_group = std::min(kBinMaxGroup, std::max(1u, 2048u >> c->kf.cap_bits));
     p.bin_tiles = ceil_div(p.S, p.bin_group);
     if (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 || p.bin_tiles > kBinMaxTiles) p.binsort = false;
