@@ -18,6 +18,15 @@
 
 using namespace ydc;
 
+// Analysis hook (tests/tools): per chunk, how far the level guess was from the start state the
+// chunk really has — summed over the classes, and the largest single class (list positions).
+static uint32_t* g_dev_sum = nullptr;
+static uint32_t* g_dev_max = nullptr;
+extern "C" void model_set_deviation_out(uint32_t* sum, uint32_t* mx) {
+  g_dev_sum = sum;
+  g_dev_max = mx;
+}
+
 extern "C" {
 
 struct model_stats {
@@ -186,6 +195,7 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
       for (uint32_t c = 0; c < C; ++c)
         guess[(size_t)k * C + c] =
             level_guess(L, c, comp_rank_base[comp_of(c)] + before[(size_t)k * G + comp_of(c)]);
+    const std::vector<ClassState> guess_level(guess);
     std::vector<uint8_t> dirty(K, 1);
     for (;;) {
       ++rounds;
@@ -215,6 +225,18 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
       if (rounds > K + 2) return -6;
     }
     for (uint32_t c = 0; c < C; ++c) final_state[c] = endst[(size_t)(K - 1) * C + c];
+    if (g_dev_sum)
+      for (uint32_t k = 0; k < K; ++k) {
+        uint32_t sum = 0, mx = 0;
+        for (uint32_t c = 0; c < C; ++c) {
+          const uint32_t a = guess_level[(size_t)k * C + c].cursor, b = guess[(size_t)k * C + c].cursor;
+          const uint32_t d = a > b ? a - b : b - a;
+          sum += d;
+          mx = std::max(mx, d);
+        }
+        g_dev_sum[k] = sum;
+        if (g_dev_max) g_dev_max[k] = mx;
+      }
   }
 
   // --- finalise.
