@@ -10,7 +10,9 @@
 //   k_radix_hist / _scan / _scatter   stable LSD radix sort of the slots by key (the chunk
 //                    prefix of the consuming counts rides in a histogram launch)
 //   k_radix_scatter_classed / class passes   per-class sorted lists (rank, slot)
-//   (bin_sort.h: the same order and lists in three launches for small and medium registries)
+//   (bin_sort.h: registries up to 600k slots get the same order and lists from two launches —
+//    k_front_bins: bin starts in closed form | slot tiles | request classification, no scan;
+//    k_bin_sort: counting passes per bin in LDS — instead of everything above this line)
 //   k_match_pass (match_kernel.h)     chunk-parallel speculative replay of the greedy picks;
 //                    pass 0 makes its own level guesses (k_guess_init: > 64 classes, sharded)
 //   k_finalize                        rank -> slot -> servant index, utilisation; running_tasks in

@@ -24,6 +24,10 @@
 //            state, replays its chunk from that state at once. What it leaves behind (flags of
 //            pass 1, checkpoints, end states) is what a separate launch of pass 1 would have
 //            left, minus the chain following; the host goes on with pass 2 if need be.
+//            With <= 64 classes and one part, pass 0 also starts every chunk kWarmUp requests
+//            early (from the level guess of that point; picks thrown away): a guess that is off
+//            by a slot or two is back on track by the chunk's first request, and hardly any
+//            chunk needs the second replay.
 //   A pass in which no chunk's end state changed (pass 0: every end state equals the
 //   next chunk's level guess) proves that every chunk's last replay started from its
 //   predecessor's final end state: the result is the sequential one (chunk 0 always
