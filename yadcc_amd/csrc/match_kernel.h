@@ -104,6 +104,7 @@ struct MatchBuffers {
   // the chunk's first request is almost always its predecessor's end state — and the chunk
   // needs no second replay.
   const uint32_t* tail;
+  uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
 };
 
 constexpr uint32_t kWarmUp = 16;
@@ -793,11 +794,11 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
       }
     };
-    stage(warm ? t0 - kWarmUp : t0);
+    stage(warm ? t0 - B.warm_len : t0);
     ClassState early_cp{};
     if (W == 1 && pass != 0 && lane < C) early_cp = B.early[(size_t)kc * C + lane];
 
-    for (uint32_t tb = warm ? t0 - kWarmUp : t0; tb < t1; tb = tb < t0 ? t0 : tb + 64) {
+    for (uint32_t tb = warm ? t0 - B.warm_len : t0; tb < t1; tb = tb < t0 ? t0 : tb + 64) {
       const bool warm_blk = tb < t0;  // the warm-up requests: picks are made and thrown away
       // ---- checkpoint: stop if the previous replay was in the same state here ----
       if (!warm_blk) {
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       const uint64_t dyn_self = __ballot(shi == kSelfShared);
       uint32_t res = kIdxTimeout;
       uint32_t keep = 64;  // results of this block to store (fewer after an early stop)
-      const uint32_t cnt = warm_blk ? kWarmUp : min(64u, t1 - tb);
+      const uint32_t cnt = warm_blk ? B.warm_len : min(64u, t1 - tb);
 
       // General step for request i: holes, own-servant heads, last-resort self pick. The
       // shared state machine (dispatch_core.h) advances the class; its ring is topped up

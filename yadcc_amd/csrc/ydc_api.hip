@@ -217,6 +217,7 @@ struct ydc_context {
   // a batch with a bin too large for LDS is repeated with the radix sort, which then stays
   // (binsort_blocked) until the registry changes structure.
   bool opt_fuse_passes = true;  // one GPU: the launch of pass 0 does pass 1 as well (match_kernel.h)
+  uint32_t opt_warm_up = kWarmUp;  // requests a chunk of pass 0 starts early (1 .. 64)
   bool opt_binsort = true;
   uint32_t opt_binsort_max_slots = 600000;
   bool binsort_blocked = false;
@@ -497,6 +498,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT")) c->opt_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
+  if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
@@ -978,6 +980,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
       p.mb.hand = c->d_hand.p;
       HIP_TRY(c, c->d_chunk_tail.reserve((size_t)K + 1));
       p.mb.tail = c->n_parts <= 1 && p.mb.before ? c->d_chunk_tail.p : nullptr;
+      p.mb.warm_len = c->opt_warm_up;
     }
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
@@ -1033,7 +1036,7 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       (uint32_t)c->tables.ver_sorted.size(), c->d_ip_sorted.p, c->d_ip_servant.p, S,
                       c->d_slot_base.p, cs, c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p,
                       c->d_chunk_consuming.p, c->d_cls_comp.p, c->n_parts,
-                      p.mb.tail ? c->d_chunk_tail.p : nullptr, kWarmUp,
+                      p.mb.tail ? c->d_chunk_tail.p : nullptr, p.mb.warm_len,
                       p.binsort ? 1u : 0u, p.binsort ? 1u : 0u};
   }
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
