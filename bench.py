@@ -421,7 +421,13 @@ def main():
                                "traffic": pmc_traffic(dom, args.config),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_us": avg_launch_s * 1e6,
-                               "launches_per_step": launches / n_prof}
+                               "launches_per_step": launches / n_prof,
+                               # The same bytes against the whole step (all kernels + host
+                               # turn-around): what a batch achieves, whatever the launch count.
+                               "per_step_GBps": alg_bytes / (elapsed / args.steps) / 1e9,
+                               "note": "k_match_pass: matching passes 0 + 1 are one launch on one "
+                                       "GPU (two until round 2: half the duration per launch, the "
+                                       "same per batch); dependency-bound, see DESIGN.md 3.4"}
         if world == 1 and not args.no_cpu_baseline:
             ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
             out["cpu_baseline"] = base
