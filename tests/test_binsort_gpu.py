@@ -16,15 +16,19 @@ pytestmark = pytest.mark.gpu
 
 
 def _context(binsort):
-    old = os.environ.get("YDC_BINSORT")
-    os.environ["YDC_BINSORT"] = "1" if binsort else "0"
+    """A context with the bin sort on (and every bin sort checked against a host sort of the
+    staged records, YDC_BINSORT_VERIFY) or off. The switches are read at ydc_create."""
+    want = {"YDC_BINSORT": "1" if binsort else "0", "YDC_BINSORT_VERIFY": "1" if binsort else "0"}
+    old = {k: os.environ.get(k) for k in want}
+    os.environ.update(want)
     try:
         return binding.Context(device=0)
     finally:
-        if old is None:
-            del os.environ["YDC_BINSORT"]
-        else:
-            os.environ["YDC_BINSORT"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
