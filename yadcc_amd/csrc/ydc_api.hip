@@ -217,7 +217,7 @@ struct ydc_context {
   // a batch with a bin too large for LDS is repeated with the radix sort, which then stays
   // (binsort_blocked) until the registry changes structure.
   bool opt_fuse_passes = true;  // one GPU: the launch of pass 0 does pass 1 as well (match_kernel.h)
-  uint32_t opt_warm_up = kWarmUp;  // requests a chunk of pass 0 starts early (1 .. 64)
+  uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
   bool opt_binsort = true;
   uint32_t opt_binsort_max_slots = 600000;
   bool binsort_blocked = false;
@@ -980,7 +980,10 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
       p.mb.hand = c->d_hand.p;
       HIP_TRY(c, c->d_chunk_tail.reserve((size_t)K + 1));
       p.mb.tail = c->n_parts <= 1 && p.mb.before ? c->d_chunk_tail.p : nullptr;
-      p.mb.warm_len = c->opt_warm_up;
+      // Warm-up length: an eighth of the chunk, 16 .. 64 requests (cfg2's chunks of 64: 16 is
+      // enough for every chunk; cfg3's chunks of 512: 706 / 300 / 51 chunks still need a second
+      // replay with 16 / 32 / 64, and the launch lasts as long as its slowest wave).
+      p.mb.warm_len = c->opt_warm_up ? c->opt_warm_up : std::min(64u, std::max(kWarmUp, p.cs / 8));
     }
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
