@@ -281,6 +281,25 @@ def test_class_partition_fused_into_last_sort_pass(fused, monkeypatch):
         c.close()
 
 
+def test_hand_off_that_never_arrives(monkeypatch):
+    """The launch of passes 0 + 1 waits for its predecessor's end state a bounded number of polls
+    (HIP promises nothing about dispatch order). With no patience at all (YDC_HAND_TRIES=0) most
+    waves give up, say "not final" and leave their chunk to the next launch: more passes, same
+    placement."""
+    monkeypatch.setenv("YDC_HAND_TRIES", "0")
+    c = binding.Context(device=0)
+    try:
+        for seed, envs, n in ((74, 1, 30_000), (75, 3, 60_000)):
+            sv, tk = cases.random_case(seed=seed, n_tasks=n, n_servants=700, n_envs=envs,
+                                       self_frac=0.2, unknown_env_frac=0.001)
+            st = check(c, sv, tk)
+            assert st["rounds"] >= 2
+        sv, tk = synth.make_config("cfg2")
+        check(c, sv, tk)
+    finally:
+        c.close()
+
+
 def test_switchable_fast_paths_off(monkeypatch):
     """The A/B switches select older, slower forms of the same steps (separate class pass,
     class gather, k_guess_init, one request per loop iteration, the radix sort, a launch of

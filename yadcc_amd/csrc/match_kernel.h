@@ -105,6 +105,7 @@ struct MatchBuffers {
   // needs no second replay.
   const uint32_t* tail;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
+  uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
 };
 
 constexpr uint32_t kWarmUp = 16;
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           }
         }
         if (__ballot(missing) == 0) break;
-        if (tries >= kHandTries) {
+        if (tries >= B.hand_tries) {
           if (lane == 0) B.flags[1u & B.flag_mask] = 1;
           return;
         }

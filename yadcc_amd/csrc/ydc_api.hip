@@ -218,6 +218,7 @@ struct ydc_context {
   // (binsort_blocked) until the registry changes structure.
   bool opt_fuse_passes = true;  // one GPU: the launch of pass 0 does pass 1 as well (match_kernel.h)
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
+  uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
   uint32_t opt_binsort_max_slots = 600000;
   bool binsort_blocked = false;
@@ -499,6 +500,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_BINSORT")) c->opt_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
+  if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
@@ -978,6 +980,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
         HIP_TRY(c, hipMemsetAsync(c->d_hand.p, 0, c->d_hand.cap * 8, c->stream));
       }
       p.mb.hand = c->d_hand.p;
+      p.mb.hand_tries = c->opt_hand_tries;
       HIP_TRY(c, c->d_chunk_tail.reserve((size_t)K + 1));
       p.mb.tail = c->n_parts <= 1 && p.mb.before ? c->d_chunk_tail.p : nullptr;
       // Warm-up length: an eighth of the chunk, 16 .. 64 requests (cfg2's chunks of 64: 16 is
