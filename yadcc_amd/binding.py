@@ -297,13 +297,17 @@ class Context:
         self._check(lib().ydc_get_running(self._h, out.ctypes.data, len(out)), "ydc_get_running")
         return out
 
-    def dispatch(self, tasks, commit=False, want_util=True, want_running=True):
-        """Host numpy columns in, numpy out: (servant_idx, utilization|None, running_after|None)."""
+    def dispatch(self, tasks, commit=False, want_util=True, want_running=True, out_idx=None):
+        """Host numpy columns in, numpy out: (servant_idx, utilization|None, running_after|None).
+        out_idx: a uint32 array of the batch's length to write the placement into (a caller that
+        dispatches batch after batch reuses its buffer; a fresh 400 KB array per call is page
+        faults, not dispatch)."""
         keep = [np.ascontiguousarray(tasks[k], dtype=np.uint32)
                 for k in ("env_id", "min_version", "requestor_ip")]
         n = len(keep[0])
         soa = TaskSoA(*[a.ctypes.data for a in keep])
-        out = np.empty(n, np.uint32)
+        out = out_idx if out_idx is not None else np.empty(n, np.uint32)
+        assert out.dtype == np.uint32 and out.size == n and out.flags.c_contiguous
         util = np.empty(n, np.float64) if want_util else None
         run = np.empty(self.n_servants, np.uint32) if want_running else None
         self._check(lib().ydc_dispatch(self._h, C.byref(soa), n, DISPATCH_COMMIT if commit else 0,
