@@ -145,6 +145,55 @@ def heartbeat_wakes_nobody(make):
     td.close()
 
 
+def _join_or_release(td, th, seconds=10):
+    """Joins a waiter thread; one that is still parked is released through its (fake-clock)
+    deadline, so a regression fails the assertion that follows instead of hanging the suite."""
+    th.join(seconds)
+    if th.is_alive():
+        td.clock_advance_ms(4 * 3600000)
+        th.join(seconds)
+
+
+def timer_tick_wakes_parked_waiters(make):
+    """OnExpirationTimer ends in UnsafeSweepOrphans -> UnsafeFreeTasks(sweeping) on EVERY tick
+    (task_dispatcher.cc:478-496,518-520), and UnsafeFreeTasks notifies all waiters even for an
+    empty list (:187): a parked waiter re-runs its loop at least once a second. So it is
+    granted a servant that registered meanwhile, and gets EnvironmentNotFound once the last
+    eligible servant has expired — without any FreeTask."""
+    import threading
+    import time
+    td = make(fake_clock=True)
+    td.keep_servant_alive("10.0.0.1:1", ["d"], 1, 8, 0, memory_available=G50, expires_in_ms=1000)
+    st, tid, _ = td.wait_for_starting_new_task("9.9.9.9", "d", expires_in_ms=600000)
+    assert st == D.GRANTED
+    out = {}
+
+    def waiter(key, digest):
+        out[key] = td.wait_for_starting_new_task("9.9.9.9", digest, timeout_in_ms=3600000)
+
+    # (1) parked, then a second servant registers: the heartbeat alone wakes nobody, the tick does
+    th = threading.Thread(target=waiter, args=("a", "d"))
+    th.start()
+    time.sleep(0.2)
+    td.keep_servant_alive("10.0.0.2:1", ["d"], 1, 8, 0, memory_available=G50, expires_in_ms=600000)
+    time.sleep(0.15)
+    assert "a" not in out
+    td.on_expiration_timer()
+    _join_or_release(td, th)
+    assert out["a"][0] == D.GRANTED and out["a"][2] == "10.0.0.2:1"
+    # (2) parked on a full pool; both servants expire: the tick turns the wait into
+    # EnvironmentNotFound (:105-108) instead of leaving it asleep until its deadline
+    th = threading.Thread(target=waiter, args=("b", "d"))
+    th.start()
+    time.sleep(0.2)
+    assert "b" not in out
+    td.clock_advance_ms(700000)
+    td.on_expiration_timer()
+    _join_or_release(td, th)
+    assert out["b"][0] == D.ENV_NOT_FOUND
+    td.close()
+
+
 def concurrent_callers_are_combined(make):
     """Many threads calling WaitForStartingNewTask at once: every grant is distinct, the pool
     fills exactly, the rest time out — whatever the interleaving."""

@@ -64,6 +64,10 @@ def test_heartbeat_wakes_nobody():
     S.heartbeat_wakes_nobody(make)
 
 
+def test_timer_tick_wakes_parked_waiters():
+    S.timer_tick_wakes_parked_waiters(make)
+
+
 def test_concurrent_callers_are_combined():
     S.concurrent_callers_are_combined(make)
 

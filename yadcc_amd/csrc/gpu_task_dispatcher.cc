@@ -413,8 +413,12 @@ void GpuTaskDispatcher::OnExpirationTimer() {
     row_is_dirty_.assign(servants_.size(), 0);
   }
   // UnsafeSweepOrphans (:478-496): tasks of vanished servants are forgotten at
-  // once. Their ids are exactly the grant sets of the servants removed above.
-  if (!orphans.empty()) UnsafeFreeTasks(orphans);
+  // once. Their ids are exactly the grant sets of the servants removed above. Called on every
+  // tick, like the reference's (:518-520): UnsafeFreeTasks ends in notify_all even for an empty
+  // list, so every parked waiter re-runs its loop at least once a second — that is how it gets
+  // to see a new servant, a lighter load, or EnvironmentNotFound after the last eligible
+  // servant expired (a heartbeat alone wakes nobody, :190-220).
+  UnsafeFreeTasks(orphans);
 
   // Expired leases become zombies; they keep their slot until the servant's
   // next heartbeat no longer lists them (:523-535, task_dispatcher.h:207-214).

@@ -1158,7 +1158,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
         if (__ballot(missing) == 0) break;
         if (tries >= B.hand_tries) {
-          if (lane == 0) B.flags[1u & B.flag_mask] = 1;
+          // Not verified: pass 1 is "not final", and counts as a changed end state for the
+          // next pass's choice between parallel replays and chain following (sampled like one).
+          if (lane == 0) {
+            B.flags[1u & B.flag_mask] = 1;
+            if ((kc & 15u) == 0) atomicAdd(&B.sampled[1u & B.flag_mask], 1u);
+          }
           return;
         }
         __builtin_amdgcn_s_sleep(2);

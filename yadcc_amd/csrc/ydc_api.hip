@@ -25,10 +25,30 @@ using namespace ydc;
 
 namespace {
 
+// Owns one device allocation (freed with the context: `delete c` releases whatever
+// ydc_destroy did not name).
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) {
+    o.p = nullptr;
+    o.cap = 0;
+  }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      cap = o.cap;
+      o.p = nullptr;
+      o.cap = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -609,6 +629,11 @@ int ydc_update_servants_wide(ydc_context* c, const uint32_t* idx, const ydc_serv
   if (!c || (n && (!idx || !rows))) return YDC_ERR_INVALID_ARGUMENT;
   if (env_masks && (env_words == 0 || env_words > YDC_MAX_ENV_WORDS))
     return fail(c, YDC_ERR_INVALID_ARGUMENT, "env_words %u out of range", env_words);
+  // A row carries one mask word: on a wider table it would silently clear the servant's other
+  // environments (KeepServantAlive replaces the whole set, task_dispatcher.cc:195-201).
+  if (!env_masks && n && c->env_words > 1)
+    return fail(c, YDC_ERR_INVALID_ARGUMENT,
+                "the table holds %u mask words per servant: use ydc_update_servants_wide", c->env_words);
   HIP_TRY(c, hipSetDevice(c->device));
   // Appends first (they may need bigger buffers).
   uint32_t new_n = c->n_servants;
