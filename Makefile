@@ -15,6 +15,12 @@ yadcc_amd/libydc.so: $(HIP_SRCS) $(HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
 	    -Iinclude -I$(CSRC) -o $@ $(HIP_SRCS)
 
+# Measurement build: the matching kernel leaves phase stamps behind (tools/phase_probe.py).
+probe: yadcc_amd/libydc_probe.so
+yadcc_amd/libydc_probe.so: $(HIP_SRCS) $(HDRS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+	    -DYDC_PHASE_PROBE -Iinclude -I$(CSRC) -o $@ $(HIP_SRCS)
+
 oracle:
 	$(MAKE) -s -C oracle
 model:
@@ -38,4 +44,4 @@ clean:
 	rm -f yadcc_amd/libydc.so tests/model/libmodel.so
 	$(MAKE) -C tests/native clean
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle model native tsan asan clean
+.PHONY: all lib probe oracle model native tsan asan clean

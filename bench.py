@@ -181,6 +181,11 @@ def main():
     ap.add_argument("--shared-ip-frac", type=float, default=0.0,
                     help="fraction of servants that share a host with an earlier one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", choices=("auto", "rccl", "ipc", "ipc-host"), default="auto",
+                    help="N > 1: how the ranks exchange boundary states and slot deltas. auto = RCCL "
+                         "(the default transport), and if its communicator does not come up in time "
+                         "the RCCL-free mailbox transport of libydc.so (HIP IPC device memory, then "
+                         "the shared host segment) instead of giving the sharded run up")
     args = ap.parse_args()
     if args.config == "cfg5":
         return stream_main(args)
@@ -205,6 +210,13 @@ def main():
         import torch.distributed as dist
         phase("torch imported")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if world == 1:  # (YDC_BENCH_FORCE_DIST=1 without a launcher: a group of one rank)
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         dist.init_process_group("gloo", rank=rank, world_size=world)
         phase("gloo group up (%d ranks)" % world)
 
@@ -236,47 +248,88 @@ def main():
     sharded = False
     init_thread = None
     rccl_ranks, is_rccl = 0, False
+    transport = "none"
+    abandoned = []  # contexts stuck inside a communicator bootstrap: never torn down
     if use_dist:
-        # One node: RCCL's bootstrap only has to find the loopback interface (probing the other
-        # interfaces / InfiniBand takes minutes on some boxes); the data path is xGMI / P2P.
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        try:
-            ids = [binding.group_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            # The communicator bootstrap is a blocking C call: give it a deadline instead of
-            # hanging the whole scaling run (the thread is abandoned if it never returns).
-            import threading
-            box = {}
-
-            def _init():
-                try:
-                    ctx.group_init(ids[0], rank, world)
-                    box["ok"] = True
-                except Exception as e:  # noqa: BLE001
-                    box["err"] = e
-
-            phase("registry uploaded, RCCL unique id shared")
-            th = init_thread = threading.Thread(target=_init, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
-            if box.get("ok"):
-                sharded = True
-            else:
-                raise RuntimeError(box.get("err") or "ncclCommInitRank did not return in time")
-        except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
-            group_note = "RCCL group init failed (%s): ranks ran independent batches" % e
-        phase(group_note or "RCCL communicator up")
-        flags = [1 if sharded else 0]
-        if dist:
-            t = torch.tensor(flags, dtype=torch.int64)
+        def everybody(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t[0]) == 0 and sharded:
-                ctx.group_destroy()
-                sharded = False
+            return int(t[0]) == 1
+
+        if args.transport in ("auto", "rccl"):
+            # One node: RCCL's bootstrap only has to find the loopback interface (probing the
+            # other interfaces / InfiniBand takes minutes on some boxes); the data path is xGMI.
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
+            ok = False
+            try:
+                ids = [binding.group_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                # The communicator bootstrap is a blocking C call: give it a deadline instead
+                # of hanging the whole scaling run (the thread is abandoned if it never returns).
+                import threading
+                box = {}
+
+                def _init():
+                    try:
+                        ctx.group_init(ids[0], rank, world)
+                        box["ok"] = True
+                    except Exception as e:  # noqa: BLE001
+                        box["err"] = e
+
+                phase("registry uploaded, RCCL unique id shared")
+                th = init_thread = threading.Thread(target=_init, daemon=True)
+                t_rccl = time.perf_counter()
+                th.start()
+                th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
+                ok = bool(box.get("ok"))
+                if not ok:
+                    group_note = "RCCL group init failed after %.0f s (%s)" % (
+                        time.perf_counter() - t_rccl,
+                        box.get("err") or "ncclCommInitRank did not return in time")
+            except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
+                group_note = "RCCL group init failed (%s)" % e
+            all_ok = everybody(ok)
+            if all_ok:
+                sharded, transport = True, "rccl"
+                rccl_ranks, is_rccl = ctx.group_size()  # ncclCommCount of the communicator
+            else:
                 group_note = group_note or "another rank could not join the RCCL group"
-        if sharded:
-            rccl_ranks, is_rccl = ctx.group_size()  # ncclCommCount of the communicator
+                if init_thread is not None and init_thread.is_alive():
+                    # still inside ncclCommInitRank: leave that context alone, take a fresh one
+                    abandoned.append(ctx)
+                    ctx = binding.Context(device=local_rank)
+                    ctx.upload_servants(pack.to_abi_columns(sv))
+                elif ok:
+                    ctx.group_destroy()
+            phase(group_note or "RCCL communicator up")
+        if not sharded and args.transport != "rccl":
+            # The RCCL-free transport: mailboxes written by the peers' kernels (ydc_group_ipc_export
+            # / ydc_group_init_ipc), handles all-gathered over gloo. Same protocol, same results.
+            # (every rank takes part in every collective below, whatever happened to it locally)
+            try:
+                mine = ctx.group_ipc_export(rank, world)
+            except binding.YdcError as e:
+                mine = None
+                group_note = (group_note + "; " if group_note else "") + str(e)
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            kinds = [binding.TRANSPORT_IPC_DEVICE, binding.TRANSPORT_IPC_HOST]
+            if args.transport == "ipc-host":
+                kinds = kinds[1:]
+            for kind in kinds if all(h is not None for h in handles) else []:
+                try:
+                    ctx.group_init_ipc(handles, rank, world, kind)
+                    ok = True
+                except binding.YdcError as e:
+                    ok = False
+                    group_note = (group_note + "; " if group_note else "") + str(e)
+                if everybody(ok):
+                    sharded, transport = True, binding.TRANSPORT_NAMES[kind]
+                    break
+            phase("mailbox transport: %s" % (transport if sharded else "unavailable"))
+        if not sharded:
+            group_note = (group_note or "no transport") + ": ranks ran independent batches"
     DA = binding.DeviceArray
     d_env = DA.from_numpy(tk["env_id"], local_rank)
     d_minv = DA.from_numpy(tk["min_version"], local_rank)
@@ -393,8 +446,10 @@ def main():
                            if args.shared_ip_frac else "", st["n_classes"]),
                        "parallelism": "1 GPU" if world == 1 else
                                       ("one global batch of %d requests x %d servants sharded by "
-                                       "rank range over %d GPUs, RCCL all-gather of boundary states "
-                                       "and servant-slot deltas" % (n_all, n_serv, world)
+                                       "rank range over %d GPUs, %s all-gather of boundary states "
+                                       "and servant-slot deltas" % (
+                                           n_all, n_serv, world,
+                                           "RCCL" if transport == "rccl" else "mailbox (%s)" % transport)
                                        if sharded else group_note),
                        "inputs": "request columns + servant table resident in HBM; results in HBM"},
             "p99_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.99),
@@ -409,6 +464,11 @@ def main():
             out["end_to_end"] = e2e
             out["host_buffers_assignments_per_s"] = e2e["assignments_per_s"]
         if use_dist:
+            # sharded: the N ranks placed ONE global batch through ydc_dispatch_sharded (false:
+            # no transport came up and every rank placed its own batch — not a scaling result).
+            out["sharded"] = bool(sharded)
+            out["transport"] = {"ipc-host": "ipc"}.get(transport, transport)
+            out["transport_detail"] = transport + ("" if not group_note else " (%s)" % group_note)
             out["rccl_ranks"] = rccl_ranks
             out["rccl"] = is_rccl
             out["parity_vs_oracle"] = parity_oracle
@@ -441,9 +501,10 @@ def main():
         line = None
     stuck = init_thread is not None and init_thread.is_alive()  # still inside ncclCommInitRank
     if sharded:
+        if dist:
+            dist.barrier()  # nobody unmaps a mailbox a peer may still be writing to
         ctx.group_destroy()
-    if not stuck:
-        ctx.close()
+    ctx.close()
     # ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C
     # stdio, which would otherwise be flushed behind it at exit. Every rank flushes before the
     # last barrier; rank 0 prints after it.

@@ -203,6 +203,28 @@ int ydc_group_init(ydc_context* ctx, const void* id128, int rank, int n_ranks);
  * device copies instead of RCCL (each rank's calls must come from its own thread): how the
  * sharding protocol is exercised on a single-GPU machine. */
 int ydc_group_init_local(ydc_context** ctxs, int n);
+/* The same protocol without RCCL, between processes of one node (one process per GPU, or several
+ * processes sharing a GPU — RCCL refuses two ranks on one device): every rank owns a mailbox its
+ * peers write into and its own kernels poll, in-stream, with a bounded wait. Every rank calls
+ * ydc_group_ipc_export (allocates the mailbox, fills YDC_IPC_HANDLE_BYTES of out_handle), the
+ * launcher all-gathers the handles over any side channel, every rank calls ydc_group_init_ipc with
+ * all n_ranks handles in rank order and the SAME transport:
+ *   YDC_TRANSPORT_IPC_DEVICE  mailboxes in device memory, opened through HIP IPC handles — peer
+ *                             writes travel over xGMI (or stay on the device the ranks share);
+ *   YDC_TRANSPORT_IPC_HOST    mailboxes in a shared host segment mapped by every rank (PCIe): for
+ *                             boxes where HIP IPC is not available.
+ * A failed init leaves the export in place, so the launcher can agree on the other flavour and
+ * call ydc_group_init_ipc again. RCCL stays the default transport (ydc_group_init). */
+#define YDC_IPC_HANDLE_BYTES 256
+#define YDC_TRANSPORT_NONE 0
+#define YDC_TRANSPORT_RCCL 1
+#define YDC_TRANSPORT_LOCAL 2
+#define YDC_TRANSPORT_IPC_DEVICE 3
+#define YDC_TRANSPORT_IPC_HOST 4
+int ydc_group_ipc_export(ydc_context* ctx, int rank, int n_ranks, void* out_handle);
+int ydc_group_init_ipc(ydc_context* ctx, const void* handles, int rank, int n_ranks, int transport);
+/* YDC_TRANSPORT_* of the group this context belongs to. */
+int ydc_group_transport(ydc_context* ctx);
 int ydc_group_destroy(ydc_context* ctx);
 /* Ranks of the group this context belongs to (0: none). For an RCCL group the number comes
  * from the communicator (ncclCommCount) and *out_is_rccl (nullable) is 1. */

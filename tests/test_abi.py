@@ -38,7 +38,7 @@ def test_error_strings(libydc):
     libydc.ydc_strerror.restype = ctypes.c_char_p
     assert libydc.ydc_strerror(0) == b"ok"
     assert b"no CPU fallback" in libydc.ydc_strerror(-3)
-    assert libydc.ydc_abi_version() == 2
+    assert libydc.ydc_abi_version() == binding.ABI_VERSION
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful without a GPU")

@@ -1,9 +1,14 @@
-"""The bench line the driver parses: the committed round bench lines (profiles/r*_bench_cfg2.json,
-produced by `python bench.py` on the GPU box) carry every field of the contract, with the
-roofline and cpu_baseline objects next to them. Runs on CPU (reads the committed JSON)."""
+"""The bench line the driver parses. The -m gpu tests RUN bench.py on the GPU box (a few steps
+of cfg2, the streaming ticks of cfg5, the group path of one rank) and validate the line that
+comes out — a change that breaks the contract fails here. The CPU part checks what can be
+checked without a device: BASELINE.json and the validator itself on the committed lines."""
 import glob
 import json
 import os
+import subprocess
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -13,46 +18,85 @@ ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic")
 CPU = ("value", "unit", "cores", "kind", "sample")
 
 
-def test_committed_bench_line_has_every_contract_field():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cfg2.json")))
-    assert files, "no committed bench line"
-    j = json.load(open(files[-1]))
+def validate(j, steps=None, streaming=False, cpu_baseline=True):
     for k in REQUIRED:
         assert k in j, k
     assert j["metric"].startswith("task-to-servant assignments/sec")
     assert j["unit"] == "assignments/s" and j["higher_is_better"] is True
-    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
     assert j["data"] == "synthetic" and j["dtype"] in ("u32", "u64")
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert abs(j["value"] - j["stats"]["granted"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    if steps is not None:
+        assert j["steps"] == steps
+    assert j["value"] > 0 and j["ms_per_step"] > 0
     r = j["roofline"]
     for k in ROOFLINE:
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    c = j["cpu_baseline"]
-    for k in CPU:
-        assert k in c, k
-    assert c["kind"] in ("reference", "port") and c["cores"] == 1
-    assert j["parity_vs_cpu_baseline"] is True
-    if files[-1].endswith("r01_bench_cfg2.json"):
-        return
-    # round 2 on: which rate `value` is, the SURVEY 8(d) end-to-end figure beside it, p99 over
-    # at least 100 batches
-    assert "HBM-resident" in j["value_definition"]
+    assert 0 < r["frac"] < 1
+    if cpu_baseline:
+        c = j["cpu_baseline"]
+        for k in CPU:
+            assert k in c, k
+        assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
+        assert j["parity_vs_cpu_baseline"] is True
+    if not streaming:
+        # value = granted requests x steps / wall time of the timed region
+        assert abs(j["value"] - j["stats"]["granted"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+        assert "HBM-resident" in j["value_definition"]
+        assert j["latency_samples"] >= 100
+        assert j["p99_dispatch_latency_ms"] >= j["p50_dispatch_latency_ms"] > 0
+
+
+def run_bench(*args, env=None, timeout=420):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT,
+                         env=dict(os.environ, **(env or {})), capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-800:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly ONE JSON line: %r" % out.stdout[-800:]
+    assert out.stdout.strip().splitlines()[-1] == lines[0]  # ... and it is the last thing on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_cfg2_line():
+    j = run_bench("--steps", "3", "--warmup", "2")
+    validate(j, steps=3)
+    assert j["n_gpus"] == 1 and j["warmup"] == 2
+    assert "cfg2: 100000 pending requests x 2000 servants" in j["config"]["workload"]
+    assert j["stats"]["granted"] + j["stats"]["timeouts"] + j["stats"]["env_not_found"] == 100000
     e = j["end_to_end"]
     assert e["batches"] >= 100 and e["p99_ms"] >= e["p50_ms"] > 0
-    assert abs(e["assignments_per_s"] - j["stats"]["granted"] / (e["ms_per_batch"] * 1e-3)) < 1e-6 * e["assignments_per_s"]
-    assert j["latency_samples"] >= 100
+    assert abs(e["assignments_per_s"] - j["stats"]["granted"] / (e["ms_per_batch"] * 1e-3)) < 1e-6 * e[
+        "assignments_per_s"]
+    assert j["roofline"]["kernel"] in j["kernels_us_per_step"]
 
 
-def test_streaming_bench_line_has_reference_beside_it():
+@pytest.mark.gpu
+def test_bench_cfg5_streaming_line():
+    j = run_bench("--config", "cfg5", "--steps", "40", "--warmup", "5")
+    validate(j, steps=40, streaming=True)
+    assert j["parity_ticks"] >= 20 and "hipGraph" in j["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_group_of_one_rank_line():
+    """The N > 1 code path of bench.py with one rank and the RCCL-free transport: the line says
+    whether the batch went through ydc_dispatch_sharded and over which transport."""
+    j = run_bench("--steps", "3", "--warmup", "2", "--transport", "ipc", "--no-cpu-baseline",
+                  env={"YDC_BENCH_FORCE_DIST": "1"})
+    validate(j, steps=3, cpu_baseline=False)
+    assert j["sharded"] is True and j["transport"] == "ipc" and j["parity_vs_oracle"] is True
+
+
+def test_validator_accepts_the_committed_lines():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cfg2.json")))
+    assert files, "no committed bench line"
+    validate(json.load(open(files[-1])))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cfg5.json")))
-    j = json.load(open(files[-1]))
-    if files[-1].endswith("r01_bench_cfg5.json"):
-        return
-    assert j["cpu_baseline"]["kind"] == "reference" and j["parity_vs_cpu_baseline"] is True
-    assert j["parity_ticks"] >= 20 and "roofline" in j
+    validate(json.load(open(files[-1])), streaming=True)
 
 
 def test_bench_baseline_json_agrees():

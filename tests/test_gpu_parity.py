@@ -51,6 +51,44 @@ def test_handmade_cases(ctx, name, sv, tk):
     check(ctx, sv, tk, "scan")
 
 
+@pytest.mark.parametrize("shape", ["cfg2", "ragged", "oversubscribed"])
+def test_dispatch_device_caller_owned_outputs(ctx, shape):
+    """ydc_dispatch_device — the entry point bench.py times — called directly: request columns
+    and all three outputs in caller-owned device buffers (poisoned first), against the oracle.
+    cfg2 = BASELINE.json configs[1]; a ragged size (not a multiple of a wave, a chunk or a sort
+    tile) with self requests; a pool half the size of the batch (Timeout tail)."""
+    DA = binding.DeviceArray
+    if shape == "cfg2":
+        sv, tk = synth.make_config("cfg2")
+    elif shape == "ragged":
+        sv, tk = cases.random_case(seed=91, n_tasks=33_337, n_servants=777, n_envs=3, self_frac=0.2,
+                                   unknown_env_frac=0.003)
+    else:
+        sv, tk = cases.random_case(seed=92, n_tasks=50_001, n_servants=400, n_envs=2,
+                                   oversubscribed=True)
+    n, S = len(tk["env_id"]), len(sv["version"])
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    cols = [DA.from_numpy(tk[k]) for k in ("env_id", "min_version", "requestor_ip")]
+    d_idx = DA.from_numpy(np.full(n, 0xDEADBEEF, np.uint32))
+    d_util = DA.from_numpy(np.full(n, -7.0, np.float64))
+    d_run = DA.from_numpy(np.full(S, 0xDEADBEEF, np.uint32))
+    want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+    for rep in range(2):  # the second call reuses the workspace and the same output buffers
+        ctx.dispatch_device(cols[0], cols[1], cols[2], d_idx, d_util, d_run)
+        got = d_idx.numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (rep, bad[:5], got[bad[:5]], want[bad[:5]], ctx.stats())
+        assert np.array_equal(d_util.numpy(), wutil) and np.array_equal(d_run.numpy(), wrun)
+    # outputs are optional: placement only, then the resident column is still untouched (no COMMIT)
+    ctx.dispatch_device(cols[0], cols[1], cols[2], d_idx)
+    assert np.array_equal(d_idx.numpy(), want)
+    assert np.array_equal(ctx.get_running(), np.asarray(sv["running_tasks"], np.uint32))
+    ctx.dispatch_device(cols[0], cols[1], cols[2], d_idx, None, None, commit=True)
+    assert np.array_equal(ctx.get_running(), wrun)
+    if shape == "oversubscribed":
+        assert (want == O.IDX_TIMEOUT).sum() > 1000
+
+
 def test_golden_load_balance(ctx):
     """task_dispatcher_test.cc:216-298 through the GPU path, one request per batch with the
     chosen servant re-heartbeated at load + 1, like the reference test."""

@@ -10,8 +10,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libydc.so")
+# (YDC_LIB: a measurement build of the same library, e.g. libydc_probe.so — tools/phase_probe.py)
+LIB_PATH = os.environ.get("YDC_LIB") or os.path.join(_HERE, "libydc.so")
 
+ABI_VERSION = 3
+IPC_HANDLE_BYTES = 256
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_LOCAL, TRANSPORT_IPC_DEVICE, TRANSPORT_IPC_HOST = range(5)
+TRANSPORT_NAMES = ("none", "rccl", "local", "ipc", "ipc-host")
 IDX_TIMEOUT = 0xFFFFFFFF
 IDX_ENV_NOT_FOUND = 0xFFFFFFFE
 DISPATCH_COMMIT = 1
@@ -28,7 +33,7 @@ ABI_SYMBOLS = (
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
     "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_end",
     "ydc_group_unique_id", "ydc_group_init", "ydc_group_init_local", "ydc_group_destroy",
-    "ydc_group_size",
+    "ydc_group_size", "ydc_group_ipc_export", "ydc_group_init_ipc", "ydc_group_transport",
     "ydc_dispatch_sharded",
     # host class wrapper (yadcc_amd/dispatcher.py types them)
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
@@ -118,6 +123,9 @@ def lib():
         L.ydc_group_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.ydc_group_destroy.argtypes = [C.c_void_p]
         L.ydc_group_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ydc_group_ipc_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ydc_group_init_ipc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ydc_group_transport.argtypes = [C.c_void_p]
         L.ydc_dispatch_sharded.argtypes = L.ydc_dispatch.argtypes
         L.ydc_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ydc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -338,6 +346,28 @@ class Context:
         n, r = C.c_int(0), C.c_int(0)
         self._check(lib().ydc_group_size(self._h, C.byref(n), C.byref(r)), "ydc_group_size")
         return n.value, bool(r.value)
+
+    def group_ipc_export(self, rank, n_ranks):
+        """This rank's mailbox handle (IPC_HANDLE_BYTES bytes) for the RCCL-free inter-process
+        transport; the launcher all-gathers the handles and every rank calls group_init_ipc."""
+        buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+        self._check(lib().ydc_group_ipc_export(self._h, rank, n_ranks, buf), "ydc_group_ipc_export")
+        return buf.raw
+
+    def group_init_ipc(self, handles, rank, n_ranks, transport=TRANSPORT_IPC_DEVICE):
+        """handles: the n_ranks exported handles in rank order. Every rank passes the same
+        transport (TRANSPORT_IPC_DEVICE: HIP IPC device memory; TRANSPORT_IPC_HOST: shared host
+        segment). Raises if a peer's mailbox cannot be mapped — the export stays, so the
+        launcher may agree on the other flavour and call again."""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == n_ranks * IPC_HANDLE_BYTES
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(lib().ydc_group_init_ipc(self._h, buf, rank, n_ranks, transport),
+                    "ydc_group_init_ipc")
+
+    def group_transport(self):
+        """TRANSPORT_* of the group this context is a rank of."""
+        return int(lib().ydc_group_transport(self._h))
 
     def group_destroy(self):
         self._check(lib().ydc_group_destroy(self._h), "ydc_group_destroy")

@@ -53,6 +53,9 @@ struct DeviceParams {
   // requests reached (every rank sets it alike; the batch is repeated with the full sort).
   uint32_t rank_offset;
   uint32_t window_miss;
+  // Multi-GPU over the inter-process mailbox transport (k_mailbox_all_gather): a peer's data
+  // did not arrive in time. Never reset by a batch: the group is broken.
+  uint32_t exchange_timeout;
 };
 
 struct ServantTable {
@@ -1413,6 +1416,63 @@ __global__ __launch_bounds__(256) void k_boundary_in(const ClassState* bounds, u
     st.lo = lo - shift[c];
     boundary_local[c] = st;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Inter-process all-gather without RCCL (ydc_group_init_ipc): every rank owns a MAILBOX — device
+// memory opened by its peers through HIP IPC handles, or a shared host segment mapped by all of
+// them — with one slot per (parity, sender). A sender writes its words into its slot of every
+// peer's mailbox as 8-byte granules {word, exchange stamp} (system-scope atomic stores: every
+// granule carries its own validity, so there is no flag, no fence and no ordering between
+// granules — the hand-off pattern of match_kernel.h, across processes), a receiver polls the
+// granules of its own mailbox until they carry the stamp of this exchange. Exchanges alternate
+// between two sets of slots: a rank can only be two exchanges ahead of a peer that has not yet
+// read the older one (it needs that peer's data of the exchange in between), so a slot is never
+// overwritten before it was read. Bounded: a peer that does not deliver within `timeout_ticks`
+// of the 100 MHz wall clock flags DeviceParams::exchange_timeout (and the words read as 0).
+// Workgroup b serves peer b / blocks_per_peer: writes this rank's words to that peer, reads that
+// peer's words from this rank's mailbox into recv (rank-major, like ncclAllGather; recv_stride
+// words per rank: a long exchange is cut into pieces of at most slot_words words).
+// ---------------------------------------------------------------------------
+struct MailboxPeers {
+  unsigned long long* box[16];  // mailbox of rank q as mapped into THIS process (own: box[rank])
+};
+constexpr uint32_t kMailboxMaxRanks = 16;
+
+__global__ __launch_bounds__(256) void k_mailbox_all_gather(MailboxPeers peers, uint32_t rank,
+                                                            uint32_t n_ranks, const uint32_t* send,
+                                                            uint32_t* recv, uint32_t n_words,
+                                                            uint32_t recv_stride,
+                                                            uint32_t slot_words, uint32_t parity,
+                                                            uint32_t stamp, uint32_t blocks_per_peer,
+                                                            unsigned long long timeout_ticks,
+                                                            DeviceParams* prm) {
+  const uint32_t q = blockIdx.x / blocks_per_peer, part = blockIdx.x % blocks_per_peer;
+  if (q >= n_ranks) return;
+  const uint32_t stride = blocks_per_peer * blockDim.x;
+  const uint32_t first = part * blockDim.x + threadIdx.x;
+  if (q == rank) {  // own words: straight across
+    for (uint32_t w = first; w < n_words; w += stride) recv[(size_t)rank * recv_stride + w] = send[w];
+    return;
+  }
+  // Slot of sender r in a mailbox: [(parity * n_ranks + r) * slot_words, + slot_words).
+  unsigned long long* out = peers.box[q] + ((size_t)parity * n_ranks + rank) * slot_words;
+  const unsigned long long tag = (unsigned long long)stamp << 32;
+  for (uint32_t w = first; w < n_words; w += stride)
+    __hip_atomic_store(out + w, tag | send[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  unsigned long long* in = peers.box[rank] + ((size_t)parity * n_ranks + q) * slot_words;
+  const unsigned long long t0 = wall_clock64();
+  bool late = false;
+  for (uint32_t w = first; w < n_words; w += stride) {
+    unsigned long long v = __hip_atomic_load(in + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    while ((uint32_t)(v >> 32) != stamp && !late) {
+      __builtin_amdgcn_s_sleep(8);
+      v = __hip_atomic_load(in + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((uint32_t)(v >> 32) != stamp && wall_clock64() - t0 > timeout_ticks) late = true;
+    }
+    recv[(size_t)q * recv_stride + w] = (uint32_t)(v >> 32) == stamp ? (uint32_t)v : 0u;
+  }
+  if (late) prm->exchange_timeout = 1;
 }
 
 // Heartbeats of known servants (KeepServantAlive replaces the personality and keeps

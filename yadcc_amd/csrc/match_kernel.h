@@ -62,6 +62,21 @@ namespace ydc {
 
 constexpr uint32_t kPassSlots = 64;  // DeviceParams::n_changed is indexed by pass & 63
 
+// Phase stamps of the matching kernel (measurement builds only: `make probe`,
+// tools/phase_probe.py): lane 0 of every wave leaves the 100 MHz wall clock at its phase
+// boundaries. Compiled out of the product library.
+#ifdef YDC_PHASE_PROBE
+constexpr uint32_t kProbeSlots = 12, kProbeChunks = 8192;
+__device__ unsigned long long ydc_phase_probe[kProbeChunks * kProbeSlots];
+#define YDC_PROBE(chunk, slot)                                                          \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && (chunk) < kProbeChunks)                                     \
+      ydc_phase_probe[(size_t)(chunk) * kProbeSlots + (slot)] = wall_clock64();         \
+  } while (0)
+#else
+#define YDC_PROBE(chunk, slot) do { (void)(chunk); } while (0)
+#endif
+
 struct MatchBuffers {
   const ClassState* guess0;  // [K * C] level guesses (start states of pass 0)
   // Non-NULL (<= 64 classes, single GPU): pass 0 works its level guesses out itself from the
@@ -523,6 +538,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
   uint32_t kc = blockIdx.x;  // chunk
+  const uint32_t probe_kc = blockIdx.x;
+  if (pass_arg == 0) YDC_PROBE(probe_kc, 0);  // entry
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
   const uint32_t batch_seq = prm->batch_seq;
   const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
@@ -723,6 +740,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     }
   }
 
+  if (pass_arg == 0) YDC_PROBE(probe_kc, 1);  // start state known (level guesses done)
   bool warm = warm_mode && kc > 0;  // this replay starts kWarmUp requests before the chunk
   bool ring_ready = false;
   uint64_t holes[W] = {};
@@ -847,6 +865,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           holes[j] = __ballot(w.k[j].lo < w.k[j].cursor);
         }
         ring_ready = true;
+        if (pass_arg == 0 && !fused_stage) YDC_PROBE(probe_kc, 2);  // requests staged, rings filled
       }
 
       const uint64_t has_self = __ballot(slo != kNone);
@@ -1072,6 +1091,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           budget = 0;
         }
       }
+      if (pass_arg == 0 && !fused_stage) YDC_PROBE(probe_kc, warm_blk ? 3 : 4);  // warm-up / block done
       // No eligible class at all: EnvironmentNotFound (task_dispatcher.cc:105-108).
       if (many == 0) res = kIdxEnvNotFound;
       if (!warm_blk && tl < t1 && lane < keep) B.slot_of[tl] = res;
@@ -1112,6 +1132,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       B.flags[pass & B.flag_mask] = 1;
       if ((kc & 15u) == 0) atomicAdd(&B.sampled[pass & B.flag_mask], 1u);
     }
+    if (pass_arg == 0 && !fused_stage) YDC_PROBE(probe_kc, 5);  // results + end state stored
+    if (pass_arg == 0 && fused_stage) YDC_PROBE(probe_kc, 9);   // second replay done
     if (pass == 0) {
       if (!fuse) return;
       // ---- pass 1 of this chunk, in the same launch. The end state of the pass-0 replay goes
@@ -1131,6 +1153,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           __hip_atomic_store(g + 3, tag | s.hown_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      YDC_PROBE(probe_kc, 6);  // hand-off published
       if (kc == 0) return;  // chunk 0 started from the true state
       // ... and the predecessor's comes in the same way. Bounded: a wave that does not get it
       // (HIP promises nothing about dispatch order) says "not final" and leaves its chunk to
@@ -1168,11 +1191,13 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
         __builtin_amdgcn_s_sleep(2);
       }
+      YDC_PROBE(probe_kc, 7);  // predecessor's granules arrived
       bool off = false;  // did this chunk's level guess miss the predecessor's end state?
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (lane + 64 * j < C) off |= !class_state_equal(start0[j], pred[j]);
       if (__ballot(off) == 0) return;  // consistent
+      YDC_PROBE(probe_kc, 8);  // second replay starts
       pass = 1;
       stamp = ((unsigned long long)batch_seq << 16) | (pass + 1);
       fused_stage = true;

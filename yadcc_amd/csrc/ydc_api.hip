@@ -3,6 +3,9 @@
 // no CPU fallback — without a device every call fails with YDC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types and prototypes only: librccl is resolved with dlopen at ydc_group_init
 
 #include <algorithm>
@@ -145,6 +148,26 @@ struct ydc_context {
     decltype(&ncclCommCount) comm_count_fn = nullptr;
     decltype(&ncclGetErrorString) error_string_fn = nullptr;
     LocalHub* hub = nullptr;
+    // Inter-process mailbox transport (ydc_group_ipc_export / ydc_group_init_ipc): this rank's
+    // mailbox in both flavours — device memory behind a HIP IPC handle, a shared host segment —
+    // and the peers' as mapped into this process (kernels.h: k_mailbox_all_gather).
+    struct Mailbox {
+      int kind = 0;  // 0: not in use; YDC_TRANSPORT_IPC_DEVICE / YDC_TRANSPORT_IPC_HOST once initialised
+      int exported_ranks = 0, exported_rank = -1;
+      void* own_dev = nullptr;        // device flavour
+      bool own_dev_fine = false;
+      bool have_handle = false;
+      hipIpcMemHandle_t handle{};
+      void* own_host = nullptr;       // host flavour (mmap of the shm segment, registered)
+      char shm_name[64] = {};
+      size_t bytes = 0;
+      uint32_t slot_words = 0;
+      MailboxPeers peers{};
+      void* opened_dev[kMailboxMaxRanks] = {};   // hipIpcOpenMemHandle results to close
+      void* opened_host[kMailboxMaxRanks] = {};  // peers' segments mapped here
+      uint32_t seq = 0;                           // exchanges so far (the stamp; never 0)
+      unsigned long long timeout_ticks = 30ull * 100000000ull;
+    } box;
     DevBuf<uint32_t> d_totals, d_meta, d_base, d_delta, d_deltas;
     // Sharded sort (k_window): key-count table, per-servant windows, local prefix, class lists
     // of the whole registry, local -> registry-wide list position shifts, the ranks' windows.
@@ -467,7 +490,7 @@ int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
 }
-uint32_t ydc_abi_version(void) { return 2; }
+uint32_t ydc_abi_version(void) { return 3; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
                void* stream, ydc_context** out) {
@@ -825,8 +848,11 @@ int ydc_get_running(ydc_context* c, uint32_t* out, uint32_t n) {
 // ---------------------------------------------------------------------------
 namespace {
 
-int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
+// for_window: the plan of a multi-GPU batch whose slot sort is sharded (k_window generates only a
+// key window of the slots: radix pipeline).
+int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = false) {
   BatchPlan& p = *out;
+  p = BatchPlan{};
   if (c->tables_dirty)
     if (int rc = rebuild_tables(c)) return rc;
   p.N = N;
@@ -890,10 +916,11 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     }
   }
   // Bin sort: 32-bit exact keys, the wave path's class limit, the class above the slot bits in
-  // the value (or a single class), one GPU. Decided from the registry alone.
+  // the value (or a single class), the whole slot order (a rank of a group takes it as well
+  // unless it only sorts a key window). Decided from the registry alone.
   p.binsort = c->opt_binsort && !c->binsort_blocked && c->kf.exact && p.key32 && C >= 1 &&
               C <= kMaxWaveClasses && slot_bound && slot_bound <= c->opt_binsort_max_slots &&
-              (C == 1 || p.gbits) && c->group.n_ranks == 0 && p.S <= kBinMaxServants &&
+              (C == 1 || p.gbits) && !for_window && p.S <= kBinMaxServants &&
               c->kf.cap_bits <= 11;
   if (p.binsort) {
     const BinFormat bf = choose_bins(c->kf.key_bits, slot_bound, kMaxBins);
@@ -997,7 +1024,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out) {
     p.mb.flags = c->d_prm.p->n_changed;
     p.mb.sampled = c->d_prm.p->n_sampled;
     p.mb.flag_mask = 63;
-    p.fuse01 = c->opt_fuse_passes && c->group.n_ranks == 0;
+    // (a group of one rank is a single GPU with the exchanges of the protocol around it)
+    p.fuse01 = c->opt_fuse_passes && c->group.n_ranks <= 1;
     if (p.fuse01) {
       if ((size_t)K * C * 4 > c->d_hand.cap) {
         // Granules are valid by their batch stamp (never 0): a fresh array starts at 0.
@@ -1659,6 +1687,24 @@ namespace {
 
 int group_all_gather(ydc_context* c, const void* send, void* recv, size_t bytes) {
   auto& g = c->group;
+  if (g.n_ranks == 1 && !g.hub) {
+    // A group of one: the gather is a copy (the communicator / mailbox exists, nothing to wait for).
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return YDC_OK;
+  }
+  if (g.box.kind) {
+    if (bytes % 4) return fail(c, YDC_ERR_INVALID_ARGUMENT, "mailbox exchange of %zu bytes", bytes);
+    const uint32_t words = (uint32_t)(bytes / 4), G = (uint32_t)g.n_ranks;
+    for (uint32_t off = 0; off < words; off += g.box.slot_words) {
+      const uint32_t n = std::min(g.box.slot_words, words - off);
+      if (++g.box.seq == 0) ++g.box.seq;
+      const uint32_t bpp = std::min(16u, std::max(1u, ceil_div(n, 1024)));
+      YDC_LAUNCH(c, "k_mailbox_all_gather", k_mailbox_all_gather, dim3(G * bpp), dim3(256), 0, c->stream,
+                 g.box.peers, (uint32_t)g.rank, G, (const uint32_t*)send + off, (uint32_t*)recv + off, n,
+                 words, g.box.slot_words, g.box.seq & 1u, g.box.seq, bpp, g.box.timeout_ticks, c->d_prm.p);
+    }
+    return YDC_OK;
+  }
   if (g.comm) {
     ncclResult_t r = g.all_gather_fn(send, recv, bytes, ncclUint8, g.comm, c->stream);
     if (r != ncclSuccess)
@@ -1679,8 +1725,51 @@ int group_all_gather(ydc_context* c, const void* send, void* recv, size_t bytes)
   return fail(c, YDC_ERR_INVALID_ARGUMENT, "context is not part of a group");
 }
 
+// What a rank hands its peers (ydc_group_ipc_export; YDC_IPC_HANDLE_BYTES).
+struct MailboxBlob {
+  uint32_t magic, abi;
+  int32_t rank, n_ranks;
+  uint32_t slot_words, have_device, have_host, device_fine;
+  int32_t device, pid;
+  uint64_t bytes, raw_dev, raw_host;  // raw_*: the owner's own pointers (peers inside the owner's process)
+  hipIpcMemHandle_t handle;
+  char shm_name[64];
+};
+static_assert(sizeof(MailboxBlob) <= YDC_IPC_HANDLE_BYTES, "blob must fit the published size");
+constexpr uint32_t kMailboxMagic = 0x79646362u;  // "ydcb"
+
+void mailbox_release(ydc_context* c) {
+  auto& b = c->group.box;
+  for (uint32_t q = 0; q < kMailboxMaxRanks; ++q) {
+    if (b.opened_dev[q]) (void)hipIpcCloseMemHandle(b.opened_dev[q]);
+    b.opened_dev[q] = nullptr;
+    if (b.opened_host[q]) {
+      (void)hipHostUnregister(b.opened_host[q]);
+      (void)munmap(b.opened_host[q], b.bytes);
+    }
+    b.opened_host[q] = nullptr;
+    b.peers.box[q] = nullptr;
+  }
+  if (b.own_dev) (void)hipFree(b.own_dev);
+  b.own_dev = nullptr;
+  b.have_handle = false;
+  if (b.own_host) {
+    (void)hipHostUnregister(b.own_host);
+    (void)munmap(b.own_host, b.bytes);
+    (void)shm_unlink(b.shm_name);
+  }
+  b.own_host = nullptr;
+  b.shm_name[0] = 0;
+  b.kind = 0;
+  b.exported_ranks = 0;
+  b.exported_rank = -1;
+  b.bytes = 0;
+  b.seq = 0;
+}
+
 void group_release(ydc_context* c) {
   auto& g = c->group;
+  mailbox_release(c);
   if (g.comm && g.comm_destroy_fn) (void)g.comm_destroy_fn(g.comm);
   g.comm = nullptr;
   if (g.rccl) (void)dlclose(g.rccl);
@@ -1803,6 +1892,181 @@ int ydc_group_init_local(ydc_context** ctxs, int n) {
   return YDC_OK;
 }
 
+int ydc_group_ipc_export(ydc_context* c, int rank, int n_ranks, void* out_handle) {
+  if (!c || !out_handle || n_ranks < 1 || n_ranks > (int)kMailboxMaxRanks || rank < 0 || rank >= n_ranks)
+    return YDC_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  group_release(c);
+  auto& b = c->group.box;
+  // Slots of 64 KB of payload (a configs[3] registry's slot deltas: 16k servants x 4 B) unless
+  // tuned; two sets of n_ranks slots of 8-byte granules.
+  uint32_t slot_words = 16384;
+  if (const char* e = getenv("YDC_IPC_SLOT_WORDS")) slot_words = (uint32_t)std::max(64, atoi(e));
+  if (const char* e = getenv("YDC_IPC_TIMEOUT_MS"))
+    b.timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ull;  // 100 MHz wall clock
+  b.slot_words = slot_words;
+  b.bytes = (size_t)2 * n_ranks * slot_words * 8;
+  MailboxBlob blob{};
+  blob.magic = kMailboxMagic;
+  blob.abi = ydc_abi_version();
+  blob.rank = rank;
+  blob.n_ranks = n_ranks;
+  blob.slot_words = slot_words;
+  blob.device = c->device;
+  blob.pid = (int32_t)getpid();
+  blob.bytes = b.bytes;
+  // Device flavour: fine-grained device memory where the runtime exports it (peer writes have to
+  // be visible to a kernel that is running — across devices that takes fine-grained memory), plain
+  // device memory otherwise (enough between processes that share one device).
+  const char* coarse = getenv("YDC_IPC_COARSE");
+  if (!(coarse && atoi(coarse))) {
+    if (hipExtMallocWithFlags(&b.own_dev, b.bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      if (hipIpcGetMemHandle(&b.handle, b.own_dev) == hipSuccess) {
+        b.have_handle = true;
+        b.own_dev_fine = true;
+      } else {
+        (void)hipFree(b.own_dev);
+        b.own_dev = nullptr;
+      }
+    }
+    (void)hipGetLastError();
+  }
+  if (!b.own_dev) {
+    if (hipMalloc(&b.own_dev, b.bytes) == hipSuccess) {
+      b.have_handle = hipIpcGetMemHandle(&b.handle, b.own_dev) == hipSuccess;
+      b.own_dev_fine = false;
+    } else {
+      b.own_dev = nullptr;
+    }
+    (void)hipGetLastError();
+  }
+  if (b.own_dev) HIP_TRY(c, hipMemset(b.own_dev, 0, b.bytes));
+  blob.have_device = b.own_dev != nullptr;  // (without a handle: peers inside this process only)
+  blob.device_fine = b.own_dev_fine;
+  blob.raw_dev = (uint64_t)(uintptr_t)b.own_dev;
+  if (b.have_handle) blob.handle = b.handle;
+  // Host flavour: a POSIX shared-memory segment, page-locked and mapped into the device's
+  // address space by every process that opens it.
+  snprintf(b.shm_name, sizeof(b.shm_name), "/ydc_box_%d_%llx", (int)getpid(),
+           (unsigned long long)(uintptr_t)c & 0xFFFFFFFFFFull);
+  (void)shm_unlink(b.shm_name);
+  int fd = shm_open(b.shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd >= 0) {
+    void* m = MAP_FAILED;
+    if (ftruncate(fd, (off_t)b.bytes) == 0) m = mmap(nullptr, b.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void)close(fd);
+    if (m != MAP_FAILED) {
+      std::memset(m, 0, b.bytes);
+      if (hipHostRegister(m, b.bytes, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+        b.own_host = m;
+      } else {
+        (void)hipGetLastError();
+        (void)munmap(m, b.bytes);
+      }
+    }
+    if (!b.own_host) (void)shm_unlink(b.shm_name);
+  }
+  blob.have_host = b.own_host != nullptr;
+  blob.raw_host = (uint64_t)(uintptr_t)b.own_host;
+  std::memcpy(blob.shm_name, b.shm_name, sizeof(blob.shm_name));
+  if (!blob.have_device && !blob.have_host) {
+    mailbox_release(c);
+    return fail(c, YDC_ERR_HIP, "neither a device nor a host mailbox could be set up");
+  }
+  b.exported_ranks = n_ranks;
+  b.exported_rank = rank;
+  std::memset(out_handle, 0, YDC_IPC_HANDLE_BYTES);
+  std::memcpy(out_handle, &blob, sizeof(blob));
+  return YDC_OK;
+}
+
+int ydc_group_init_ipc(ydc_context* c, const void* handles, int rank, int n_ranks, int transport) {
+  if (!c || !handles || n_ranks < 1 || n_ranks > (int)kMailboxMaxRanks || rank < 0 || rank >= n_ranks)
+    return YDC_ERR_INVALID_ARGUMENT;
+  if (transport != YDC_TRANSPORT_IPC_DEVICE && transport != YDC_TRANSPORT_IPC_HOST)
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "transport %d is not a mailbox transport", transport);
+  auto& g = c->group;
+  auto& b = g.box;
+  if (b.exported_ranks != n_ranks || b.exported_rank != rank)
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "ydc_group_ipc_export(rank %d of %d) first", rank, n_ranks);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool host = transport == YDC_TRANSPORT_IPC_HOST;
+  // (a second attempt with the other flavour: drop what the first one mapped)
+  for (uint32_t q = 0; q < kMailboxMaxRanks; ++q) {
+    if (b.opened_dev[q]) (void)hipIpcCloseMemHandle(b.opened_dev[q]);
+    b.opened_dev[q] = nullptr;
+    if (b.opened_host[q]) {
+      (void)hipHostUnregister(b.opened_host[q]);
+      (void)munmap(b.opened_host[q], b.bytes);
+    }
+    b.opened_host[q] = nullptr;
+    b.peers.box[q] = nullptr;
+  }
+  b.kind = 0;
+  for (int q = 0; q < n_ranks; ++q) {
+    MailboxBlob pb;
+    std::memcpy(&pb, (const char*)handles + (size_t)q * YDC_IPC_HANDLE_BYTES, sizeof(pb));
+    if (pb.magic != kMailboxMagic || pb.rank != q || pb.n_ranks != n_ranks || pb.slot_words != b.slot_words ||
+        pb.bytes != b.bytes)
+      return fail(c, YDC_ERR_INVALID_ARGUMENT, "handle %d does not describe rank %d of %d with %u-word slots",
+                  q, q, n_ranks, b.slot_words);
+    void* dev_ptr = nullptr;
+    if (!host) {
+      if (!pb.have_device) return fail(c, YDC_ERR_HIP, "rank %d exported no device mailbox", q);
+      if (q == rank) {
+        dev_ptr = b.own_dev;
+      } else if (pb.pid == (int32_t)getpid()) {
+        dev_ptr = (void*)(uintptr_t)pb.raw_dev;  // a peer inside this process: its own pointer
+      } else {
+        hipError_t e = hipIpcOpenMemHandle(&dev_ptr, pb.handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          return fail(c, YDC_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
+        }
+        b.opened_dev[q] = dev_ptr;
+      }
+    } else {
+      if (!pb.have_host) return fail(c, YDC_ERR_HIP, "rank %d exported no host mailbox", q);
+      void* m = nullptr;
+      if (q == rank) {
+        m = b.own_host;
+      } else if (pb.pid == (int32_t)getpid()) {
+        m = (void*)(uintptr_t)pb.raw_host;
+      } else {
+        int fd = shm_open(pb.shm_name, O_RDWR, 0600);
+        if (fd < 0) return fail(c, YDC_ERR_HIP, "shm_open(%s) of rank %d failed", pb.shm_name, q);
+        m = mmap(nullptr, b.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        (void)close(fd);
+        if (m == MAP_FAILED) return fail(c, YDC_ERR_HIP, "mmap of rank %d's mailbox failed", q);
+        hipError_t e = hipHostRegister(m, b.bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          (void)munmap(m, b.bytes);
+          return fail(c, YDC_ERR_HIP, "hipHostRegister of rank %d's mailbox: %s", q, hipGetErrorString(e));
+        }
+        b.opened_host[q] = m;
+      }
+      HIP_TRY(c, hipHostGetDevicePointer(&dev_ptr, m, 0));
+    }
+    b.peers.box[q] = (unsigned long long*)dev_ptr;
+  }
+  b.kind = transport;
+  b.seq = 0;
+  g.rank = rank;
+  g.n_ranks = n_ranks;
+  return YDC_OK;
+}
+
+int ydc_group_transport(ydc_context* c) {
+  if (!c) return YDC_ERR_INVALID_ARGUMENT;
+  auto& g = c->group;
+  if (g.n_ranks < 1) return YDC_TRANSPORT_NONE;
+  if (g.comm) return YDC_TRANSPORT_RCCL;
+  if (g.hub) return YDC_TRANSPORT_LOCAL;
+  return g.box.kind ? g.box.kind : YDC_TRANSPORT_NONE;
+}
+
 int ydc_group_size(ydc_context* c, int* out_ranks, int* out_is_rccl) {
   if (!c || !out_ranks) return YDC_ERR_INVALID_ARGUMENT;
   auto& g = c->group;
@@ -1832,8 +2096,9 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   auto& g = c->group;
   if (g.n_ranks < 1) return fail(c, YDC_ERR_INVALID_ARGUMENT, "ydc_group_init first");
   HIP_TRY(c, hipSetDevice(c->device));
-  BatchPlan p;
-  if (int rc = plan_batch(c, N, &p)) return rc;
+  BatchPlan full_plan;
+  if (int rc = plan_batch(c, N, &full_plan)) return rc;
+  BatchPlan p = full_plan;
   if (p.use_generic) {
     // Registries the sharded matching does not take (> 256 classes: thread-per-chunk path):
     // every rank gathers the whole batch, places it redundantly with the single-GPU pipeline
@@ -1907,7 +2172,6 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   }
   hipStream_t st = c->stream;
   DeviceParams* prm = c->d_prm.p;
-  p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
 
   // Sharded sort (kernels.h: k_key_count / k_window): this rank generates and
   // sorts only the key window its rank range can reach. Taken for integer keys, one part, a
@@ -1917,10 +2181,13 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   // (Decided from the registry alone — every rank must take the same branch, whatever its slice.)
   bool windowed = G > 1 && c->opt_shard_sort && c->kf.exact && P == 1 && !p.use_generic && C >= 2 &&
                   !p.any_shared;
-  const BatchPlan full_plan = p;
+  BatchPlan win_plan;
+  if (windowed)
+    if (int rc = plan_batch(c, N, &win_plan, true)) return rc;
   uint32_t rounds = 0;
   for (;;) {
-    p = full_plan;
+    p = windowed ? win_plan : full_plan;
+    p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
     if (windowed) {
       // Slots of the window: this rank's requests + a margin on both sides (classes run ahead
       // of or behind the global level) + the granularity of the thresholds.
@@ -1928,7 +2195,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
                                   ? (uint64_t)c->opt_shard_margin
                                   : (uint64_t)g.margin_scale * std::max<uint64_t>(N / 8, 8192);
       const uint64_t bound = std::min<uint64_t>(
-          full_plan.slot_bound, (uint64_t)N + 2 * margin + full_plan.slot_bound / 8 + 65536);
+          win_plan.slot_bound, (uint64_t)N + 2 * margin + win_plan.slot_bound / 8 + 65536);
       p.win = true;
       p.win_margin = (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu);
       p.slot_bound = (uint32_t)bound;
@@ -2055,6 +2322,9 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
         }
       }
       if (c->h_prm->overflow) return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow on some rank");
+      if (c->h_prm->exchange_timeout)
+        return fail(c, YDC_ERR_HIP, "a peer's data did not arrive within the mailbox time-out (rank %d of %u)",
+                    g.rank, G);
       // (Belt and braces: a sharded sort that has not settled after 256 passes — the same count
       // on every rank — is treated like a missed window.)
       if (c->h_prm->window_miss || (windowed && launched >= 256)) {
@@ -2075,6 +2345,13 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       if (launched > 200000u) return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint");
     }
     if (!miss) break;
+    if (!windowed && p.binsort) {
+      // A bin of the bin sort overflowed (bin_sort.h; the registry decides, so every rank met
+      // the same): once more with the radix pipeline, which then stays.
+      if (int rc = fall_back_to_radix(c, N, &full_plan)) return rc;
+      continue;
+    }
+    if (!windowed) return fail(c, YDC_ERR_NOT_CONVERGED, "window miss flagged without a window");
     // Some rank's window did not cover what its requests reached (every rank saw the same
     // flag): once more with the full sort everywhere, and wider margins from now on.
     ++g.window_misses;
@@ -2384,6 +2661,20 @@ int ydc_set_profiling(ydc_context* c, int on) {
 const char* ydc_kernel_profile(const ydc_context* c) {
   return c ? c->kprofile_json.c_str() : "{}";
 }
+
+#ifdef YDC_PHASE_PROBE
+// Measurement builds only (`make probe`): the matching kernel's phase stamps, kProbeSlots per chunk.
+int ydc_debug_phase_probe(unsigned long long* out, size_t n_words, int clear) {
+  const size_t all = (size_t)kProbeChunks * kProbeSlots;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ydc_phase_probe), std::min(n_words, all) * 8) != hipSuccess)
+    return YDC_ERR_HIP;
+  if (clear) {
+    std::vector<unsigned long long> z(all, 0);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ydc_phase_probe), z.data(), all * 8) != hipSuccess) return YDC_ERR_HIP;
+  }
+  return YDC_OK;
+}
+#endif
 
 int ydc_get_stats(const ydc_context* c, ydc_stats* out) {
   if (!c || !out) return YDC_ERR_INVALID_ARGUMENT;
