@@ -147,6 +147,13 @@ int ydc_update_servants(ydc_context* ctx, const uint32_t* idx, const ydc_servant
  * A table that was uploaded with fewer words is widened (the missing words are zero). */
 int ydc_update_servants_wide(ydc_context* ctx, const uint32_t* idx, const ydc_servant_row* rows,
                              const uint64_t* env_masks, uint32_t env_words, uint32_t n);
+/* A servant answers to EVERY requestor address that is a prefix of its observed_location ending
+ * right before a ':' (IsNetworkAddressEqual, task_dispatcher.cc:66-69) — "[::1]:8335" to "[::1]",
+ * but also to "[:" and "[". ip_id carries one of them; the others are given here as further
+ * (host id, servant row) pairs of the lookup table (replaces the previous list; n == 0 clears).
+ * ydc_upload_servants and ydc_remove_servants drop the list (rows change), heartbeats keep it. */
+int ydc_set_host_aliases(ydc_context* ctx, const uint32_t* ip_id, const uint32_t* servant_idx,
+                         uint32_t n);
 /* OnExpirationTimer's erase (task_dispatcher.cc:503-516): removes the rows idx[0..n) (strictly
  * ascending) from the resident table; the servants behind them move up, keeping their order
  * (registry order decides ties) and their running_tasks. Done on the device: no table upload. */
@@ -166,6 +173,17 @@ int ydc_get_running(ydc_context* ctx, uint32_t* out_running, uint32_t n);
 int ydc_dispatch(ydc_context* ctx, const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t flags,
                  uint32_t* out_servant_idx, double* out_utilization, uint32_t* out_running);
 
+/* Page-locked host memory for ydc_dispatch: request columns and result arrays that lie in a
+ * range registered here (or allocated here, or pinned by the caller's own hipHostMalloc /
+ * hipHostRegister) are handed to the kernels as they are — the classification reads the
+ * columns and the final kernel writes the results through the range's device address; no
+ * staging copy and no copy command. A scheduler registers the buffers it reuses from batch to
+ * batch once. Process-wide (not per context). */
+int ydc_host_register(void* p, size_t bytes);
+int ydc_host_unregister(void* p);
+int ydc_host_alloc(size_t bytes, void** out);
+int ydc_host_free(void* p);
+
 /* Same with DEVICE pointers (task columns and outputs already in HBM);
  * asynchronous on the context stream except for one 16-byte convergence
  * read-back. out_* may be NULL. */
@@ -182,13 +200,21 @@ int ydc_dispatch_device(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t 
  * capacities given here. Host buffers in, host results out, synchronous.
  * Heartbeats that add a servant or change its environments / version / host / capacity
  * bound are applied eagerly (ydc_update_servants) and the step is captured again. With
- * env_words > 1 a tick's rows cannot carry a mask: upd_rows[i].env_mask is ignored and the
- * servant keeps its environments (change them with ydc_update_servants_wide). */
+ * env_words > 1 a tick's rows cannot carry a mask: upd_rows[i].env_mask is ignored and a known
+ * servant keeps its environments — ydc_stream_tick_wide carries the masks. */
 int ydc_stream_begin(ydc_context* ctx, uint32_t max_updates, uint32_t max_releases,
                      uint32_t max_tasks);
 int ydc_stream_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
                     uint32_t n_upd, const uint32_t* release_servant_idx, uint32_t n_rel,
                     const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx);
+/* The same tick for registries with more than 64 interned digests: upd_env_masks holds env_words
+ * words per heartbeat row (upd_rows[i].env_mask is ignored), so a heartbeat may change what a
+ * servant advertises — or add a servant — inside a tick (applied eagerly; the step is captured
+ * again). ydc_stream_tick on such a table refuses a tick that adds a servant. */
+int ydc_stream_tick_wide(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                         const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
+                         const uint32_t* release_servant_idx, uint32_t n_rel,
+                         const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx);
 int ydc_stream_end(ydc_context* ctx);
 
 /* ---- multi-GPU group: one batch sharded by rank range (BASELINE.json configs[3]) ------

@@ -34,15 +34,19 @@ struct model_stats {
 };
 
 // env_mask: env_words words per servant. Returns 0, or -6 if the rounds do not converge.
-int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
-                        const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
-                        const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id, uint32_t N,
-                        const uint32_t* env_id, const uint32_t* min_version,
-                        const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
-                        uint32_t* out_idx, double* out_util, uint32_t* out_running,
-                        model_stats* stats) {
+// n_alias further (host id, servant) entries of the requestor-address lookup table
+// (ydc_set_host_aliases).
+int model_dispatch_alias(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
+                         const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
+                         const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id, uint32_t N,
+                         const uint32_t* env_id, const uint32_t* min_version,
+                         const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
+                         uint32_t* out_idx, double* out_util, uint32_t* out_running,
+                         model_stats* stats, uint32_t n_alias, const uint32_t* alias_ip,
+                         const uint32_t* alias_servant) {
   HostTables T;
-  T.build(S, env_mask, version, max_tasks, nproc, ip_id, env_words);
+  T.build(S, env_mask, version, max_tasks, nproc, ip_id, env_words, n_alias, alias_ip, alias_servant);
+  const uint32_t NI = (uint32_t)T.ip_sorted.size();
   const uint32_t C = T.n_classes();
   uint32_t G = T.n_comp;  // independent parts of the registry (host_tables.h)
   KeyFormat kf = choose_key_format(force_fp64 ? 32 : T.cap_bits, 11, &G);
@@ -141,9 +145,9 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
   for (uint32_t t = 0; t < N; ++t) {
     task_class_mask(env_id[t], min_version[t], T.cls_env.data(), T.cls_ver.data(), C, W,
                     &tmask[(size_t)t * W], T.env_words);
-    uint32_t i = lower_bound_u32(T.ip_sorted.data(), S, requestor_ip[t]);
-    if (i < S && T.ip_sorted[i] == requestor_ip[t]) {
-      if (i + 1 < S && T.ip_sorted[i + 1] == requestor_ip[t]) {
+    uint32_t i = lower_bound_u32(T.ip_sorted.data(), NI, requestor_ip[t]);
+    if (i < NI && T.ip_sorted[i] == requestor_ip[t]) {
+      if (i + 1 < NI && T.ip_sorted[i + 1] == requestor_ip[t]) {
         tself_lo[t] = i;
         tself_hi[t] = kSelfShared;
         need_shared = true;
@@ -170,7 +174,7 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
     const uint32_t g = list_g[i], s = owner_of_slot(base.data(), S, g);
     if (g + 1 == base[s + 1]) pos_last[s] = i;
   }
-  SharedIpTable sh{T.ip_sorted.data(), T.ip_servant.data(), S, T.class_of.data(),
+  SharedIpTable sh{T.ip_sorted.data(), T.ip_servant.data(), NI, T.class_of.data(),
                    base.data(),        S,                   pos_last.data()};
   uint32_t rounds = 0, sims = 0;
   std::vector<ClassState> final_state(C);
@@ -292,6 +296,18 @@ int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* npr
   return 0;
 }
 
+
+int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
+                        const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,
+                        const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id, uint32_t N,
+                        const uint32_t* env_id, const uint32_t* min_version,
+                        const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
+                        uint32_t* out_idx, double* out_util, uint32_t* out_running,
+                        model_stats* stats) {
+  return model_dispatch_alias(S, version, nproc, load, max_tasks, running, flags, env_mask, env_words,
+                              ip_id, N, env_id, min_version, requestor_ip, chunk_size, force_fp64,
+                              out_idx, out_util, out_running, stats, 0, nullptr, nullptr);
+}
 
 int model_dispatch(uint32_t S, const uint32_t* version, const uint32_t* nproc, const uint32_t* load,
                    const uint32_t* max_tasks, const uint32_t* running, const uint32_t* flags,

@@ -9,25 +9,28 @@
 // the product has no CPU placement: without a device ydc_create fails with YDC_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/yadcc_dispatch.h"
 
-extern "C" int model_dispatch_wide(uint32_t S, const uint32_t* version, const uint32_t* nproc,
-                                   const uint32_t* load, const uint32_t* max_tasks,
-                                   const uint32_t* running, const uint32_t* flags,
-                                   const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id,
-                                   uint32_t N, const uint32_t* env_id, const uint32_t* min_version,
-                                   const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
-                                   uint32_t* out_idx, double* out_util, uint32_t* out_running,
-                                   void* stats);
+extern "C" int model_dispatch_alias(uint32_t S, const uint32_t* version, const uint32_t* nproc,
+                                    const uint32_t* load, const uint32_t* max_tasks,
+                                    const uint32_t* running, const uint32_t* flags,
+                                    const uint64_t* env_mask, uint32_t env_words, const uint32_t* ip_id,
+                                    uint32_t N, const uint32_t* env_id, const uint32_t* min_version,
+                                    const uint32_t* requestor_ip, uint32_t chunk_size, int force_fp64,
+                                    uint32_t* out_idx, double* out_util, uint32_t* out_running,
+                                    void* stats, uint32_t n_alias, const uint32_t* alias_ip,
+                                    const uint32_t* alias_servant);
 
 struct ydc_context {
   uint32_t env_words = 1;
   std::vector<uint32_t> version, nproc, load, max_tasks, running, flags, ip;
   std::vector<uint64_t> env;
+  std::vector<uint32_t> alias_ip, alias_servant;
   std::string last_error;
   uint32_t n() const { return (uint32_t)version.size(); }
   void resize(uint32_t m) {
@@ -66,6 +69,8 @@ int ydc_destroy(ydc_context* c) {
 
 int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   c->env_words = sv && sv->env_words ? sv->env_words : 1;
+  c->alias_ip.clear();
+  c->alias_servant.clear();
   c->resize(0);
   c->resize(n);
   for (uint32_t s = 0; s < n; ++s) {
@@ -126,6 +131,25 @@ int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
   }
   if (next != n) return YDC_ERR_INVALID_ARGUMENT;
   c->resize(w);
+  c->alias_ip.clear();
+  c->alias_servant.clear();
+  return YDC_OK;
+}
+
+int ydc_set_host_aliases(ydc_context* c, const uint32_t* ip_id, const uint32_t* servant_idx, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i)
+    if (servant_idx[i] >= c->n()) return YDC_ERR_INVALID_ARGUMENT;
+  c->alias_ip.assign(ip_id, ip_id + n);
+  c->alias_servant.assign(servant_idx, servant_idx + n);
+  return YDC_OK;
+}
+
+int ydc_host_alloc(size_t bytes, void** out) {  // (no device: plain memory)
+  *out = std::malloc(bytes ? bytes : 1);
+  return *out ? YDC_OK : YDC_ERR_HIP;
+}
+int ydc_host_free(void* p) {
+  std::free(p);
   return YDC_OK;
 }
 
@@ -138,11 +162,12 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
 int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
   std::vector<uint32_t> run(c->n());
-  int rc = model_dispatch_wide(c->n(), c->version.data(), c->nproc.data(), c->load.data(),
-                               c->max_tasks.data(), c->running.data(), c->flags.data(), c->env.data(),
-                               c->env_words, c->ip.data(), N, tk ? tk->env_id : nullptr,
-                               tk ? tk->min_version : nullptr, tk ? tk->requestor_ip : nullptr, 256, 0,
-                               out_idx, out_util, run.data(), nullptr);
+  int rc = model_dispatch_alias(c->n(), c->version.data(), c->nproc.data(), c->load.data(),
+                                c->max_tasks.data(), c->running.data(), c->flags.data(), c->env.data(),
+                                c->env_words, c->ip.data(), N, tk ? tk->env_id : nullptr,
+                                tk ? tk->min_version : nullptr, tk ? tk->requestor_ip : nullptr, 256, 0,
+                                out_idx, out_util, run.data(), nullptr, (uint32_t)c->alias_ip.size(),
+                                c->alias_ip.data(), c->alias_servant.data());
   if (rc) return YDC_ERR_NOT_CONVERGED;
   if (out_running) std::copy(run.begin(), run.end(), out_running);
   if (flags & YDC_DISPATCH_COMMIT) c->running = run;

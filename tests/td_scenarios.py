@@ -265,6 +265,72 @@ def address_forms(make):
         ref.close()
 
 
+def address_prefix_forms(make, seed=5):
+    """Locations with several ':' answer to EVERY prefix that ends right before one of them
+    (task_dispatcher.cc:66-69): "[::1]:8335" — what scheduler_service_impl.cc:102-103 builds for
+    an IPv6 peer — to "[::1]", but also to "[:" and "[". First the fixed cases, then a random
+    stream of requests from such prefixes (and near misses) with heartbeats, frees and an expiry
+    in between, answer for answer against the reference class."""
+    td = make()
+    ref = R.RefDispatcher()
+    both = (ref, td)
+
+    def ask(ip, digest="d"):
+        rst, rid, rloc = ref.wait_for_starting_new_task(ip, digest)
+        st, tid, loc = td.wait_for_starting_new_task(ip, digest)
+        assert (int(st), loc or None) == (rst, rloc), (ip, st, loc, rst, rloc)
+        return rst, rid, rloc
+
+    for d in both:
+        d.keep_servant_alive("[::1]:8335", ["d"], 2, 8, 0, memory_available=G50)
+        d.keep_servant_alive("[::2]:8335", ["d"], 2, 8, 1, memory_available=G50)
+    assert ask("[::1]")[2] == "[::2]:8335"   # its own servant is avoided although it is emptier
+    assert ask("[::2]")[2] == "[::1]:8335"
+    assert ask("::1")[2] == "[::1]:8335"     # what EndpointGetIp yields: matches nobody
+    for d in both:
+        d.keep_servant_alive("a:b:1", ["d"], 3, 8, 0, memory_available=G50)
+        d.keep_servant_alive("a:c:2", ["d"], 3, 8, 0, memory_available=G50)
+        d.keep_servant_alive("a:9", ["d"], 3, 8, 0, memory_available=G50)
+    ids = []
+    for ip in ["a:b", "a", "[", "a:c", "[:", "a:b:1", "a:", "[::1", "", "a"]:
+        rst, rid, _ = ask(ip)
+        if rst == R.OK:
+            ids.append(rid)
+    # random stream
+    rng = np.random.default_rng(seed)
+    locs = ["[::1]:8335", "[::2]:8335", "[::2]:9000", "a:b:1", "a:c:2", "a:9", "b:b:b:b", "b:b:7",
+            "10.0.0.1:8335", "10.0.0.1:8336", ":5", "::6", "plain"]
+    ips = sorted({loc[:i] for loc in locs for i in range(len(loc) + 1)})  # every prefix, matching or not
+    live = list(ids)
+    for step in range(400):
+        ev = rng.random()
+        if ev < 0.2:
+            loc = locs[int(rng.integers(len(locs)))]
+            kw = dict(max_tasks=int(rng.integers(0, 4)), num_processors=8,
+                      current_load=int(rng.integers(0, 6)), memory_available=G50,
+                      expires_in_ms=int(rng.integers(2000, 9000)))
+            envs = ["d"] if rng.random() < 0.9 else ["e"]
+            for d in both:
+                d.keep_servant_alive(loc, envs, **kw)
+        elif ev < 0.75:
+            rst, rid, _ = ask(ips[int(rng.integers(len(ips)))], "d" if rng.random() < 0.9 else "e")
+            if rst == R.OK:
+                live.append(rid)
+        elif ev < 0.93 and live:
+            tid = live.pop(int(rng.integers(len(live))))
+            for d in both:
+                d.free_task(tid)
+        else:
+            ms = int(rng.integers(500, 3000))
+            R.clock_advance_ms(ms)
+            td.clock_advance_ms(ms)
+            R.fire_timers()
+            td.on_expiration_timer()
+    assert_same_dump(td.dump_internals(), ref.dump_internals())
+    ref.close()
+    td.close()
+
+
 def _random_personality(rng, i, digests):
     k = len(digests)
     if k <= 8:

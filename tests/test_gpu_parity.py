@@ -89,6 +89,55 @@ def test_dispatch_device_caller_owned_outputs(ctx, shape):
         assert (want == O.IDX_TIMEOUT).sum() > 1000
 
 
+@pytest.mark.parametrize("host_in", ["map", "copy"])
+def test_dispatch_zero_copy_pinned_buffers(host_in, monkeypatch):
+    """ydc_dispatch with page-locked caller buffers (ydc_host_alloc / ydc_host_register): the
+    kernels read the request columns and write idx / utilisation / running_tasks through the
+    buffers' device addresses (YDC_HOST_IN=map), or DMA straight from them (copy) — no staging.
+    Same answers as with pageable buffers and as the oracle; mixed pinned / pageable arguments
+    take the staged path."""
+    monkeypatch.setenv("YDC_HOST_IN", host_in)
+    c = binding.Context(device=0)
+    sv, tk = cases.random_case(seed=93, n_tasks=70_001, n_servants=1500, n_envs=4, self_frac=0.2,
+                               unknown_env_frac=0.002)
+    n, S = len(tk["env_id"]), len(sv["version"])
+    c.upload_servants(pack.to_abi_columns(sv))
+    want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+    # (1) everything allocated page-locked
+    pin = {k: binding.pinned_empty(n, np.uint32) for k in tk}
+    for k in tk:
+        pin[k][:] = tk[k]
+    out = binding.pinned_empty(n, np.uint32)
+    out[:] = 0xDEADBEEF
+    for rep in range(2):
+        got, util, run = c.dispatch(pin, out_idx=out)
+        assert got is out and np.array_equal(out, want), (rep, c.stats())
+        assert np.array_equal(util, wutil) and np.array_equal(run, wrun)
+    # (2) the caller's own arrays registered in place; results into a registered array too
+    reg = {k: np.ascontiguousarray(tk[k], dtype=np.uint32).copy() for k in tk}
+    out2 = np.full(n, 0xDEADBEEF, np.uint32)
+    for a in list(reg.values()) + [out2]:
+        binding.host_register(a)
+    try:
+        c.dispatch(reg, want_util=False, want_running=False, out_idx=out2)
+        assert np.array_equal(out2, want)
+        # a batch that is a prefix of the registered columns (pointer inside a registered range)
+        half = {k: v[:n // 2] for k, v in reg.items()}
+        w2, _, _ = O.dispatch(sv, {k: tk[k][:n // 2] for k in tk}, "sorted")
+        c.dispatch(half, want_util=False, want_running=False, out_idx=out2[:n // 2])
+        assert np.array_equal(out2[:n // 2], w2)
+        # (3) mixed: pinned columns, pageable result array -> staged results, same answer
+        got3, _, _ = c.dispatch(reg, want_util=False, want_running=False)
+        assert np.array_equal(got3, want)
+    finally:
+        for a in list(reg.values()) + [out2]:
+            binding.host_unregister(a)
+    # (4) after unregistering the very same arrays go through the staging path again
+    got4, _, _ = c.dispatch(reg, want_util=False, want_running=False, out_idx=out2)
+    assert np.array_equal(got4, want)
+    c.close()
+
+
 def test_golden_load_balance(ctx):
     """task_dispatcher_test.cc:216-298 through the GPU path, one request per batch with the
     chosen servant re-heartbeated at load + 1, like the reference test."""

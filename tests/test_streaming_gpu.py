@@ -127,3 +127,60 @@ def test_stream_new_servant_appends():
     assert np.array_equal(ctx.get_running(), wrun)
     ctx.stream_end()
     ctx.close()
+
+
+def test_stream_wide_masks_env_change_and_append_inside_a_tick():
+    """A registry with 150 digests (three mask words): ydc_stream_tick_wide carries the
+    heartbeats' environment sets, so a servant may change what it advertises — or join — inside
+    a tick (KeepServantAlive replaces the personality wholesale, task_dispatcher.cc:195-210).
+    The narrow tick on such a table keeps a known servant's environments and refuses a new one."""
+    n_envs = 150
+    sv = synth.make_servants(200, n_tasks_hint=4000, n_envs=n_envs, seed=21)
+    es = streaming.EventStream(sv, 800, 500, n_envs=n_envs)
+    assert es.abi["env_mask"].ndim == 2 and es.abi["env_mask"].shape[1] == 3
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.stream_begin(es.hb + 8, 500, 800)
+    for t in range(7):
+        who, rows, rel, tk = es.next_tick()
+        if t == 2:
+            # who[0] drops every digest of its second mask word and gains digest 5
+            es.sv["env_mask"][who[0], 1] = 0
+            es.sv["env_mask"][who[0], 0] |= np.uint64(1 << 5)
+            es.abi = pack.to_abi_columns(es.sv)
+        if t == 4:
+            # a new servant that advertises digests 3, 70 and 140 joins in this tick
+            for k in es.sv:
+                add = es.sv[k][:1].copy()
+                es.sv[k] = np.concatenate([es.sv[k], add])
+            s = es.n
+            es.sv["env_mask"][s] = 0
+            for d in (3, 70, 140):
+                es.sv["env_mask"][s, d // 64] |= np.uint64(1) << np.uint64(d % 64)
+            es.sv["ip"][s] = (10 << 24) + 77777
+            es.sv["num_processors"][s], es.sv["max_tasks"][s] = 128, 120
+            es.sv["current_load"][s], es.sv["running_tasks"][s], es.sv["priority"][s] = 0, 0, 1
+            es.n += 1
+            es.foreign = np.append(es.foreign, 0)
+            es.running = np.append(es.running, 0)
+            es.abi = pack.to_abi_columns(es.sv)
+            who = np.append(who, np.uint32(s)).astype(np.uint32)
+            rows = np.concatenate([rows, np.zeros(1, dtype=binding.ROW_DTYPE)])
+            for k in ("version", "num_processors", "current_load", "max_tasks"):
+                rows[k][-1] = es.sv[k][s]
+            rows["flags"][-1], rows["ip_id"][-1] = es.abi["flags"][s], es.abi["ip_id"][s]
+            tk = synth.make_tasks(800, es.sv, n_envs=n_envs, seed=5000)
+        masks = es.abi["env_mask"][who]
+        want, _, wrun = O.dispatch(es.registry_snapshot(), tk, "sorted")
+        if t == 4:
+            with pytest.raises(binding.YdcError, match="ydc_stream_tick_wide"):
+                ctx.stream_tick(who, rows, rel, tk)  # narrow rows cannot introduce a servant here
+        got = ctx.stream_tick(who, rows, rel, tk, env_masks=masks)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (t, bad[:5], got[bad[:5]], want[bad[:5]])
+        es.commit(got)
+        assert np.array_equal(ctx.get_running(), wrun), t
+        if t == 4:
+            assert (got == es.n - 1).sum() > 0  # the newcomer takes requests at once
+    ctx.stream_end()
+    ctx.close()

@@ -81,6 +81,12 @@ def test_address_forms():
 
 
 @needs_ref
+@pytest.mark.parametrize("seed", [5, 6])
+def test_address_prefix_forms(seed):
+    S.address_prefix_forms(make, seed)
+
+
+@needs_ref
 @pytest.mark.parametrize("seed", [1, 2])
 def test_event_stream_matches_reference(seed):
     S.event_stream_matches_reference(make, seed)

@@ -27,11 +27,12 @@ STAGES = ("servant_scan", "slot_gen", "sort", "class_lists", "task_classify", "m
 ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
     "ydc_upload_servants", "ydc_update_servants", "ydc_update_servants_wide",
-    "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
+    "ydc_set_host_aliases", "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
-    "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_end",
+    "ydc_host_register", "ydc_host_unregister", "ydc_host_alloc", "ydc_host_free",
+    "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_tick_wide", "ydc_stream_end",
     "ydc_group_unique_id", "ydc_group_init", "ydc_group_init_local", "ydc_group_destroy",
     "ydc_group_size", "ydc_group_ipc_export", "ydc_group_init_ipc", "ydc_group_transport",
     "ydc_dispatch_sharded",
@@ -106,6 +107,7 @@ def lib():
                                           C.c_uint32]
         L.ydc_update_servants_wide.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ServantRow),
                                                C.c_void_p, C.c_uint32, C.c_uint32]
+        L.ydc_set_host_aliases.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_remove_servants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_release_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_set_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -117,6 +119,9 @@ def lib():
         L.ydc_stream_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ydc_stream_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                       C.c_uint32, C.POINTER(TaskSoA), C.c_uint32, C.c_void_p]
+        L.ydc_stream_tick_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(TaskSoA),
+                                           C.c_uint32, C.c_void_p]
         L.ydc_stream_end.argtypes = [C.c_void_p]
         L.ydc_group_unique_id.argtypes = [C.c_void_p]
         L.ydc_group_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -136,6 +141,10 @@ def lib():
         L.ydc_device_free.argtypes = [C.c_void_p]
         L.ydc_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ydc_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ydc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.ydc_host_unregister.argtypes = [C.c_void_p]
+        L.ydc_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ydc_host_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -158,6 +167,38 @@ def device_count():
         return int(lib().ydc_device_count())
     except (YdcError, OSError):
         return 0
+
+
+def pinned_empty(n, dtype):
+    """A numpy array in page-locked host memory the device can address (ydc_host_alloc): request
+    columns and result arrays of this kind go through ydc_dispatch without any staging copy.
+    The memory is freed when the array (and every view of it) is gone."""
+    dt = np.dtype(dtype)
+    p = C.c_void_p()
+    rc = lib().ydc_host_alloc(int(n) * dt.itemsize, C.byref(p))
+    if rc:
+        raise YdcError("ydc_host_alloc: %s (%s)" % (lib().ydc_strerror(rc).decode(),
+                                                    lib().ydc_last_error(None).decode()))
+    buf = (C.c_char * max(1, int(n) * dt.itemsize)).from_address(p.value)
+    import weakref
+    weakref.finalize(buf, lib().ydc_host_free, p.value)  # numpy keeps `buf` alive through .base
+    return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
+def host_register(a):
+    """Page-locks the memory of a contiguous numpy array in place (ydc_host_register); the array
+    must stay alive and unmoved until host_unregister(a)."""
+    assert a.flags.c_contiguous
+    rc = lib().ydc_host_register(a.ctypes.data, a.nbytes)
+    if rc:
+        raise YdcError("ydc_host_register: %s (%s)" % (lib().ydc_strerror(rc).decode(),
+                                                       lib().ydc_last_error(None).decode()))
+
+
+def host_unregister(a):
+    rc = lib().ydc_host_unregister(a.ctypes.data)
+    if rc:
+        raise YdcError("ydc_host_unregister: %s" % lib().ydc_strerror(rc).decode())
 
 
 def group_unique_id():
@@ -285,6 +326,14 @@ class Context:
         if len(idx):
             self.n_servants = max(self.n_servants, int(idx.max()) + 1)
 
+    def set_host_aliases(self, ip_id, servant_idx):
+        """Further (host id, servant row) entries of the requestor-address lookup table."""
+        a = np.ascontiguousarray(ip_id, dtype=np.uint32)
+        b = np.ascontiguousarray(servant_idx, dtype=np.uint32)
+        assert len(a) == len(b)
+        self._check(lib().ydc_set_host_aliases(self._h, a.ctypes.data, b.ctypes.data, len(a)),
+                    "ydc_set_host_aliases")
+
     def remove_servants(self, idx):
         """Servant expiry: rows idx (ascending) leave, the rest keeps its order."""
         a = np.ascontiguousarray(idx, dtype=np.uint32)
@@ -387,11 +436,15 @@ class Context:
         self._check(lib().ydc_stream_begin(self._h, max_updates, max_releases, max_tasks),
                     "ydc_stream_begin")
 
-    def stream_tick(self, upd_idx, upd_rows, release_idx, tasks):
+    def stream_tick(self, upd_idx, upd_rows, release_idx, tasks, env_masks=None):
         """upd_rows: numpy structured array of ROW_DTYPE (one heartbeat per entry of upd_idx);
         release_idx: servant index of every freed grant; tasks: dict of request columns.
+        env_masks: optional (len(upd_idx), env_words) uint64 array — the heartbeats' environment
+        sets on a registry with more than 64 digests (ydc_stream_tick_wide).
         Returns the servant index (or IDX_*) of every request."""
         ui = np.ascontiguousarray(upd_idx, dtype=np.uint32)
+        if len(ui):
+            self.n_servants = max(self.n_servants, int(ui.max()) + 1)
         ur = np.ascontiguousarray(upd_rows, dtype=ROW_DTYPE)
         rel = np.ascontiguousarray(release_idx, dtype=np.uint32)
         keep = [np.ascontiguousarray(tasks[k], dtype=np.uint32)
@@ -399,9 +452,16 @@ class Context:
         n = len(keep[0])
         soa = TaskSoA(*[a.ctypes.data for a in keep])
         out = np.empty(n, np.uint32)
-        self._check(lib().ydc_stream_tick(self._h, ui.ctypes.data, ur.ctypes.data, len(ui),
-                                          rel.ctypes.data, len(rel), C.byref(soa), n,
-                                          out.ctypes.data), "ydc_stream_tick")
+        if env_masks is None:
+            self._check(lib().ydc_stream_tick(self._h, ui.ctypes.data, ur.ctypes.data, len(ui),
+                                              rel.ctypes.data, len(rel), C.byref(soa), n,
+                                              out.ctypes.data), "ydc_stream_tick")
+        else:
+            em = np.ascontiguousarray(env_masks, dtype=np.uint64).reshape(len(ui), -1)
+            self._check(lib().ydc_stream_tick_wide(self._h, ui.ctypes.data, ur.ctypes.data,
+                                                   em.ctypes.data, em.shape[1], len(ui),
+                                                   rel.ctypes.data, len(rel), C.byref(soa), n,
+                                                   out.ctypes.data), "ydc_stream_tick_wide")
         return out
 
     def stream_end(self):

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 
@@ -39,20 +40,20 @@ bool ParseSize(const std::string& s, std::size_t* out) {
   return true;
 }
 
-// Host part of a location for the requestor-is-the-servant test
-// (IsNetworkAddressEqual, task_dispatcher.cc:66-69: `location` starts with
-// `requestor_ip` followed by ':'). The servant is keyed by the text before its
-// FIRST ':': exact for "a.b.c.d:port" endpoints (what scheduler_service_impl.cc:102-103
-// produces for IPv4) and for bracketed IPv6 locations "[..]:port" against address
-// literals (which never match in the reference either). A requestor string that
-// itself contains ':' and equals a longer prefix of a location would match in the
-// reference and does not here ("address forms").
-// A location without any ':' equals no requestor address in the reference
-// (`ip_port[ip2.size()] == ':'` can never hold); *has_host is false then.
-std::string HostOf(const std::string& location, bool* has_host) {
-  auto p = location.find(':');
-  *has_host = p != std::string::npos;
-  return *has_host ? location.substr(0, p) : std::string();
+// The requestor-is-the-servant test (IsNetworkAddressEqual, task_dispatcher.cc:66-69):
+// `location` is longer than `requestor_ip`, has a ':' right behind it and starts with it. So a
+// location answers to exactly the prefixes that end right before one of its ':' characters —
+// "10.0.0.1:8335" to "10.0.0.1"; "[::1]:8335" (what scheduler_service_impl.cc:102-103 builds
+// for IPv6 peers) to "[::1]", and also to "[:" and "[". Returns them longest first; empty for a
+// location without any ':' (which equals no requestor address in the reference:
+// `ip_port[ip2.size()] == ':'` can never hold).
+std::vector<std::string> RequestorPrefixes(const std::string& location) {
+  std::vector<std::string> out;
+  for (std::size_t p = location.rfind(':'); p != std::string::npos; p = p ? location.rfind(':', p - 1) : p) {
+    out.push_back(location.substr(0, p));
+    if (p == 0) break;
+  }
+  return out;
 }
 
 std::uint32_t Clamp32(std::size_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (std::uint32_t)v; }
@@ -196,6 +197,22 @@ std::uint32_t GpuTaskDispatcher::InternIp(const std::string& ip, bool create) {
   return id;
 }
 
+std::uint32_t GpuTaskDispatcher::RequestorId(const std::string& ip) {
+  if (!shorter_prefix_refs_.empty()) {
+    // Some location answers to `ip` through one of its shorter prefixes: from now on that is an
+    // entry of the device's lookup table (next UnsafeSyncDevice).
+    auto a = alias_ids_.find(ip);
+    if (a != alias_ids_.end()) return a->second;
+    if (shorter_prefix_refs_.count(ip)) {
+      const std::uint32_t id = InternIp(ip, true);
+      alias_ids_.emplace(ip, id);
+      aliases_dirty_ = true;
+      return id;
+    }
+  }
+  return InternIp(ip, false);
+}
+
 std::uint32_t GpuTaskDispatcher::LookupEnv(const std::string& digest) const {
   auto it = env_ids_.find(digest);
   return it == env_ids_.end() ? 0xFFFFFFFFu : it->second.first;  // unknown: nobody has it
@@ -267,11 +284,16 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
     added->expires_at = now + expires_in;
     added->running_tasks = 0;  // :210
     added->env_bits = AcquireEnvBits(servant.environments);
-    bool has_host = false;
-    const std::string host = HostOf(servant.observed_location, &has_host);
+    auto prefixes = RequestorPrefixes(servant.observed_location);
     // No ':' in the location: an id of its own that no requestor address can map to.
-    added->ip_id = has_host ? InternIp(host, true)
-                            : InternIp(std::string("\0nohost#", 8) + std::to_string(added->uid), true);
+    added->ip_id = !prefixes.empty()
+                       ? InternIp(prefixes.front(), true)
+                       : InternIp(std::string("\0nohost#", 8) + std::to_string(added->uid), true);
+    for (std::size_t k = 1; k < prefixes.size(); ++k) {
+      ++shorter_prefix_refs_[prefixes[k]];
+      if (alias_ids_.count(prefixes[k])) aliases_dirty_ = true;
+      added->shorter_prefixes.push_back(std::move(prefixes[k]));
+    }
     index_of_location_.emplace(servant.observed_location, idx);
     index_of_uid_.emplace(added->uid, idx);
     servants_.push_back(std::move(added));
@@ -396,6 +418,10 @@ void GpuTaskDispatcher::OnExpirationTimer() {
         running_task_bookkeeper_.DropServant(s->personality.observed_location);
         ReleaseEnvBits(s->personality.environments);
         orphans.insert(orphans.end(), s->grants.begin(), s->grants.end());
+        for (auto&& p : s->shorter_prefixes) {
+          auto it = shorter_prefix_refs_.find(p);
+          if (it != shorter_prefix_refs_.end() && --it->second == 0) shorter_prefix_refs_.erase(it);
+        }
         index_of_location_.erase(s->personality.observed_location);
         index_of_uid_.erase(s->uid);
       } else {
@@ -411,6 +437,7 @@ void GpuTaskDispatcher::OnExpirationTimer() {
     dirty_rows_.clear();
     pending_release_.clear();
     row_is_dirty_.assign(servants_.size(), 0);
+    if (!alias_ids_.empty()) aliases_dirty_ = true;  // (rows moved: the device dropped its aliases)
   }
   // UnsafeSweepOrphans (:478-496): tasks of vanished servants are forgotten at
   // once. Their ids are exactly the grant sets of the servants removed above. Called on every
@@ -464,7 +491,8 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
     dirty_rows_.clear();
     pending_release_.clear();
     row_is_dirty_.assign(n, 0);
-    return YDC_OK;
+    if (!alias_ids_.empty()) aliases_dirty_ = true;  // (a fresh table has no aliases)
+    return UnsafeSyncAliases();
   }
   if (!dirty_rows_.empty()) {
     std::sort(dirty_rows_.begin(), dirty_rows_.end());  // appended rows in index order
@@ -493,23 +521,64 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
     if (rc != YDC_OK) return rc;
     pending_release_.clear();
   }
-  return YDC_OK;
+  return UnsafeSyncAliases();
+}
+
+// The presented shorter prefixes as (host id, servant row) entries of the device's lookup table.
+int GpuTaskDispatcher::UnsafeSyncAliases() {
+  if (!aliases_dirty_) return YDC_OK;
+  std::vector<std::uint32_t> ids, rows;
+  for (std::uint32_t i = 0; i != servants_.size(); ++i)
+    for (auto&& p : servants_[i]->shorter_prefixes) {
+      auto a = alias_ids_.find(p);
+      if (a != alias_ids_.end()) {
+        ids.push_back(a->second);
+        rows.push_back(i);
+      }
+    }
+  int rc = ydc_set_host_aliases(ctx_, ids.data(), rows.data(), (std::uint32_t)ids.size());
+  if (rc == YDC_OK) aliases_dirty_ = false;
+  return rc;
+}
+
+std::uint32_t* GpuTaskDispatcher::HostColumn::ensure(std::size_t n) {
+  if (n <= cap) return p;
+  if (p) {
+    if (pinned) ydc_host_free(p); else std::free(p);
+  }
+  p = nullptr;
+  cap = std::max<std::size_t>(n + n / 2, 1024);
+  void* q = nullptr;
+  pinned = ydc_host_alloc(cap * sizeof(std::uint32_t), &q) == YDC_OK;
+  if (!pinned) q = std::malloc(cap * sizeof(std::uint32_t));  // (no device: the batch fails anyway)
+  p = (std::uint32_t*)q;
+  return p;
+}
+
+GpuTaskDispatcher::HostColumn::~HostColumn() {
+  if (p) {
+    if (pinned) ydc_host_free(p); else std::free(p);
+  }
 }
 
 void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
   if (batch.empty()) return;
-  int rc = UnsafeSyncDevice();
   const std::uint32_t n = (std::uint32_t)batch.size();
-  std::vector<std::uint32_t> env(n), minv(n), rip(n), out(n, YDC_IDX_TIMEOUT);
+  std::uint32_t *env = col_env_.ensure(n), *minv = col_minv_.ensure(n), *rip = col_rip_.ensure(n),
+                *out = col_out_.ensure(n);
+  std::fill(out, out + n, YDC_IDX_TIMEOUT);
+  // (requestor ids first: an address presented for the first time may add table aliases, which
+  // the sync below sends along)
+  for (std::uint32_t i = 0; i != n; ++i) rip[i] = RequestorId(batch[i]->personality->requestor_ip);
+  int rc = UnsafeSyncDevice();
   if (rc == YDC_OK) {
     for (std::uint32_t i = 0; i != n; ++i) {
       const TaskPersonality& p = *batch[i]->personality;
       env[i] = LookupEnv(p.compiler_digest);
       minv[i] = p.min_version;
-      rip[i] = InternIp(p.requestor_ip, false);
     }
-    ydc_task_soa soa{env.data(), minv.data(), rip.data()};
-    rc = ydc_dispatch(ctx_, &soa, n, YDC_DISPATCH_COMMIT, out.data(), nullptr, nullptr);
+    ydc_task_soa soa{env, minv, rip};
+    rc = ydc_dispatch(ctx_, &soa, n, YDC_DISPATCH_COMMIT, out, nullptr, nullptr);
   }
   if (rc != YDC_OK) {
     // Fail loudly: every request of the batch gets the device error. The

@@ -167,7 +167,9 @@ class GpuTaskDispatcher {
     std::size_t running_tasks = 0;
     std::size_t ever_assigned_tasks = 0;
     std::vector<std::uint32_t> env_bits;  // interned digests (bit numbers), listing order
-    std::uint32_t ip_id = 0;     // interned host part of observed_location
+    std::uint32_t ip_id = 0;     // interned longest requestor address the location answers to
+    // The shorter ones (location prefixes ending before an earlier ':'; none for "a.b.c.d:port").
+    std::vector<std::string> shorter_prefixes;
     std::unordered_set<std::uint64_t> grants;  // live task ids (incl. zombies) on this servant
   };
   struct Task {
@@ -190,6 +192,8 @@ class GpuTaskDispatcher {
 
   std::size_t CapacityAvailable(const Servant& s) const;  // task_dispatcher.cc:283-313
   std::uint32_t InternIp(const std::string& ip, bool create);
+  // Host id of a requestor address (0: no servant answers to it).
+  std::uint32_t RequestorId(const std::string& ip);
   std::uint32_t LookupEnv(const std::string& digest) const;
   std::vector<std::uint32_t> AcquireEnvBits(const std::vector<std::string>& digests);
   void ReleaseEnvBits(const std::vector<std::string>& digests);
@@ -199,6 +203,7 @@ class GpuTaskDispatcher {
   void UnsafeSweepZombiesOf(Servant* servant, const std::unordered_set<std::uint64_t>& running);
   void UnsafeSweepOrphans();
   int UnsafeSyncDevice();
+  int UnsafeSyncAliases();
   // Places `batch` (arrival order) as one device batch and registers the grants.
   void UnsafeDispatch(const std::vector<Pending*>& batch);
   void UnsafeDrainQueue();
@@ -222,6 +227,13 @@ class GpuTaskDispatcher {
 
   // interning
   std::unordered_map<std::string, std::uint32_t> ip_ids_;
+  // A location with several ':' answers to several requestor addresses (IsNetworkAddressEqual,
+  // task_dispatcher.cc:66-69: every prefix that ends right before a ':'). The servant's ip_id is
+  // the longest of them; the shorter ones are counted here and become table aliases
+  // (ydc_set_host_aliases) the first time a requestor actually presents one.
+  std::unordered_map<std::string, std::uint32_t> shorter_prefix_refs_;  // prefix -> servants having it
+  std::unordered_map<std::string, std::uint32_t> alias_ids_;            // presented ones -> host id
+  bool aliases_dirty_ = false;
   std::unordered_map<std::string, std::pair<std::uint32_t, std::uint32_t>> env_ids_;  // digest -> (bit, refs)
   std::vector<std::uint32_t> free_env_bits_;
   std::uint32_t next_env_bit_ = 0;  // bit numbers handed out so far (freed ones are reused)
@@ -231,6 +243,18 @@ class GpuTaskDispatcher {
   std::vector<std::uint32_t> dirty_rows_;
   std::vector<std::uint8_t> row_is_dirty_;
   std::vector<std::uint32_t> pending_release_;
+
+  // Request columns and the result array of a device batch, reused from batch to batch and
+  // page-locked where the runtime lets us (ydc_host_alloc): ydc_dispatch then reads and writes
+  // them in place. Guarded by allocation_lock_.
+  struct HostColumn {
+    std::uint32_t* p = nullptr;
+    std::size_t cap = 0;
+    bool pinned = false;
+    std::uint32_t* ensure(std::size_t n);
+    ~HostColumn();
+  };
+  HostColumn col_env_, col_minv_, col_rip_, col_out_;
 
   // request combining
   std::mutex queue_lock_;

@@ -28,7 +28,7 @@ struct HostTables {
   std::vector<uint64_t> cls_env;    // per class, env_words words each
   uint32_t env_words = 1;           // 64-bit words of an environment mask
   std::vector<uint32_t> cls_ver;    // per class
-  std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant)
+  std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant); >= n entries (aliases)
   std::vector<uint32_t> ip_servant;
   bool any_shared_ip = false;       // some host runs more than one servant
   // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
@@ -55,9 +55,13 @@ struct HostTables {
 
   // env_mask: words_per_servant words per servant (word w of servant s at
   // env_mask[s * words_per_servant + w]).
+  // Aliases (n_alias entries, nullable): further (host id, servant) entries of the ip table — a
+  // servant whose location has several ':' answers to every prefix that ends before one of them
+  // (IsNetworkAddressEqual, task_dispatcher.cc:66-69), i.e. to more than one requestor address.
   void build(uint32_t n, const uint64_t* env_mask, const uint32_t* version,
              const uint32_t* max_tasks, const uint32_t* nproc, const uint32_t* ip_id,
-             uint32_t words_per_servant = 1) {
+             uint32_t words_per_servant = 1, uint32_t n_alias = 0, const uint32_t* alias_ip = nullptr,
+             const uint32_t* alias_servant = nullptr) {
     env_words = std::max<uint32_t>(1, words_per_servant);
     const uint32_t EW = env_words;
     class_of.assign(n, kNone);
@@ -151,11 +155,15 @@ struct HostTables {
 
     std::vector<std::pair<uint32_t, uint32_t>> byip(n);
     for (uint32_t s = 0; s < n; ++s) byip[s] = {ip_id[s], s};
+    for (uint32_t a = 0; a < n_alias; ++a)
+      if (alias_servant[a] < n) byip.push_back({alias_ip[a], alias_servant[a]});
     std::sort(byip.begin(), byip.end());
-    ip_sorted.resize(n);
-    ip_servant.resize(n);
+    byip.erase(std::unique(byip.begin(), byip.end()), byip.end());
+    const uint32_t n_ip = (uint32_t)byip.size();
+    ip_sorted.resize(n_ip);
+    ip_servant.resize(n_ip);
     any_shared_ip = false;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n_ip; ++i) {
       ip_sorted[i] = byip[i].first;
       ip_servant[i] = byip[i].second;
       if (i && byip[i].first == byip[i - 1].first) any_shared_ip = true;

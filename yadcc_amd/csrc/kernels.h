@@ -308,6 +308,7 @@ struct ClassifyArgs {
   // chunk_consuming is indexed by WAVE of 64 requests ([wave * n_parts + part], plain stores,
   // every entry written — nothing to reset) and the chunk prefix adds the waves of a chunk up.
   uint32_t by_servant, per_wave;
+  uint32_t n_ip;  // entries of the ip table (>= n_servants: a servant may answer to several host ids)
 };
 
 __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
@@ -347,9 +348,9 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
   }
   uint32_t lo = kNone, hi = kNone;
   const uint32_t rip = a.tk.requestor_ip[t];
-  const uint32_t i = lower_bound_u32(a.ip_sorted, a.n_servants, rip);
-  if (i < a.n_servants && a.ip_sorted[i] == rip) {
-    if (i + 1 < a.n_servants && a.ip_sorted[i + 1] == rip) {
+  const uint32_t i = lower_bound_u32(a.ip_sorted, a.n_ip, rip);
+  if (i < a.n_ip && a.ip_sorted[i] == rip) {
+    if (i + 1 < a.n_ip && a.ip_sorted[i + 1] == rip) {
       lo = i;  // several servants on the host: `self` is resolved at replay time
       hi = kSelfShared;
     } else if (a.by_servant) {

@@ -108,6 +108,7 @@ struct ydc_context {
   // Host mirror of the registry columns the derived tables need.
   uint32_t n_servants = 0;
   std::vector<uint32_t> h_version, h_nproc, h_load, h_max_tasks, h_flags, h_ip;
+  std::vector<uint32_t> h_alias_ip, h_alias_servant;  // ydc_set_host_aliases: further ip table entries
   std::vector<uint64_t> h_env;  // env_words words per servant
   uint32_t env_words = 1;
   uint32_t n_parts = 1;         // independent parts of the registry (host_tables.h)
@@ -236,6 +237,7 @@ struct ydc_context {
   // the H2D copy travels on a stream of its own (stage_host_requests).
   struct {
     bool active = false;
+    bool direct = false;  // the caller's columns are page-locked: DMA straight from them
     const ydc_task_soa* tk = nullptr;
     uint32_t n = 0;
     size_t col = 0, bytes = 0;
@@ -263,6 +265,10 @@ struct ydc_context {
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
+  // request columns read in place through the mapped pointer (YDC_HOST_IN=map) or copied by DMA
+  // from where they lie (YDC_HOST_IN=copy).
+  bool opt_zero_copy = true, opt_host_in_map = true;
   uint32_t opt_binsort_max_slots = 600000;
   bool binsort_blocked = false;
   bool debug_verify_binsort = false;  // YDC_BINSORT_VERIFY=1: check every bin sort against a host sort
@@ -290,6 +296,40 @@ void group_release(ydc_context* c);   // multi-GPU group, defined further down
 
 std::string g_create_error;  // errors raised before a context exists
 
+// Page-locked host ranges the device can address (ydc_host_register / ydc_host_alloc, or found
+// pinned by the caller's own means): ydc_dispatch hands such buffers to the kernels as they are —
+// request columns read and results written through the mapped pointer, no staging copy.
+struct PinnedRange {
+  const char* host;
+  size_t bytes;
+  char* dev;
+  int kind;  // 0: registered here, 1: allocated here
+};
+std::mutex g_pinned_mu;
+std::vector<PinnedRange> g_pinned;
+// Pointers that were asked about and are NOT pinned (so that an unpinned caller does not pay a
+// runtime query per batch); forgotten whenever a range is registered.
+std::vector<const void*> g_not_pinned;
+
+// Device address of [p, p + bytes) if it lies in a pinned range, else NULL.
+void* pinned_device_pointer(const void* p, size_t bytes) {
+  if (!p) return nullptr;
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  const char* q = (const char*)p;
+  for (auto& r : g_pinned)
+    if (q >= r.host && q + bytes <= r.host + r.bytes) return r.dev + (q - r.host);
+  for (auto* np : g_not_pinned)
+    if (np == p) return nullptr;
+  // Pinned by the caller itself (hipHostMalloc / hipHostRegister outside this library)?
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+    return a.devicePointer;  // (asked again next time: its owner may free it behind our back)
+  (void)hipGetLastError();
+  if (g_not_pinned.size() >= 64) g_not_pinned.clear();
+  g_not_pinned.push_back(p);
+  return nullptr;
+}
+
 int fail(ydc_context* ctx, int code, const char* fmt, ...) {
   if (ctx) {
     char buf[512];
@@ -315,14 +355,16 @@ inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 int rebuild_tables(ydc_context* c) {
   const uint32_t n = c->n_servants;
   c->tables.build(n, c->h_env.data(), c->h_version.data(), c->h_max_tasks.data(),
-                  c->h_nproc.data(), c->h_ip.data(), c->env_words);
+                  c->h_nproc.data(), c->h_ip.data(), c->env_words, (uint32_t)c->h_alias_ip.size(),
+                  c->h_alias_ip.data(), c->h_alias_servant.data());
+  const uint32_t n_ip = (uint32_t)c->tables.ip_sorted.size();
   c->n_parts = c->tables.n_comp;
   c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits, &c->n_parts);
   const uint32_t C = c->tables.n_classes();
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
-  HIP_TRY(c, c->d_ip_sorted.reserve(n));
-  HIP_TRY(c, c->d_ip_servant.reserve(n));
+  HIP_TRY(c, c->d_ip_sorted.reserve(n_ip));
+  HIP_TRY(c, c->d_ip_servant.reserve(n_ip));
   HIP_TRY(c, c->d_cls_env.reserve((size_t)C * c->env_words));
   HIP_TRY(c, c->d_cls_ver.reserve(C));
   HIP_TRY(c, c->d_cls_begin.reserve(C + 1));
@@ -339,9 +381,9 @@ int rebuild_tables(ydc_context* c) {
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->d_class_of.p, c->tables.class_of.data(), n * 4,
                               hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_ip_sorted.p, c->tables.ip_sorted.data(), n * 4,
+    HIP_TRY(c, hipMemcpyAsync(c->d_ip_sorted.p, c->tables.ip_sorted.data(), (size_t)n_ip * 4,
                               hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_ip_servant.p, c->tables.ip_servant.data(), n * 4,
+    HIP_TRY(c, hipMemcpyAsync(c->d_ip_servant.p, c->tables.ip_servant.data(), (size_t)n_ip * 4,
                               hipMemcpyHostToDevice, c->stream));
   }
   if (C) {
@@ -544,6 +586,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
+  if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
+  if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
@@ -612,6 +656,8 @@ int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   if (int rc = reserve_registry(c, n)) return rc;
   c->n_servants = n;
+  c->h_alias_ip.clear();  // (they name rows of the table that is being replaced)
+  c->h_alias_servant.clear();
   c->h_version.assign(sv ? sv->version : nullptr, sv ? sv->version + n : nullptr);
   c->h_nproc.assign(sv ? sv->num_processors : nullptr, sv ? sv->num_processors + n : nullptr);
   c->h_load.assign(sv ? sv->current_load : nullptr, sv ? sv->current_load + n : nullptr);
@@ -743,6 +789,18 @@ int ydc_update_servants(ydc_context* c, const uint32_t* idx, const ydc_servant_r
   return ydc_update_servants_wide(c, idx, rows, nullptr, 1, n);
 }
 
+int ydc_set_host_aliases(ydc_context* c, const uint32_t* ip_id, const uint32_t* servant_idx, uint32_t n) {
+  if (!c || (n && (!ip_id || !servant_idx))) return YDC_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < n; ++i)
+    if (servant_idx[i] >= c->n_servants)
+      return fail(c, YDC_ERR_INVALID_ARGUMENT, "alias %u names servant %u of %u", i, servant_idx[i], c->n_servants);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->h_alias_ip.assign(ip_id, ip_id + n);
+  c->h_alias_servant.assign(servant_idx, servant_idx + n);
+  return rebuild_tables(c);
+}
+
 int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
   if (!c || (n && !idx)) return YDC_ERR_INVALID_ARGUMENT;
   if (!n) return YDC_OK;
@@ -785,6 +843,8 @@ int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
     ++w;
   }
   c->n_servants = kept;
+  c->h_alias_ip.clear();  // (row numbers moved)
+  c->h_alias_servant.clear();
   c->h_version.resize(kept);
   c->h_nproc.resize(kept);
   c->h_load.resize(kept);
@@ -1005,8 +1065,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     p.rank_stride = 1;
   }
   p.T = TaskTable{c->d_mask.p, c->d_self_lo.p, c->d_self_hi.p, W};
-  p.shared = SharedIpTable{c->d_ip_sorted.p, c->d_ip_servant.p, p.S, c->d_class_of.p, c->d_slot_base.p,
-                           p.S, p.any_shared ? c->d_pos_last.p : nullptr};
+  p.shared = SharedIpTable{c->d_ip_sorted.p, c->d_ip_servant.p, (uint32_t)c->tables.ip_sorted.size(),
+                           c->d_class_of.p, c->d_slot_base.p, p.S, p.any_shared ? c->d_pos_last.p : nullptr};
   p.mb = MatchBuffers{};
   if (p.wave_path) {
     p.mb.guess0 = c->d_guess[0].p;
@@ -1098,6 +1158,7 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       p.mb.tail ? c->d_chunk_tail.p : nullptr, p.mb.warm_len,
                       p.binsort ? 1u : 0u, p.binsort ? 1u : 0u};
   }
+  ca.n_ip = (uint32_t)c->tables.ip_sorted.size();
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
   const uint32_t bpp0 = c->kf.bits_per_pass;
@@ -1247,10 +1308,17 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
 // for the copy (only the kernels behind this point read the columns).
 int stage_host_requests(ydc_context* c) {
   auto& h = c->host_in;
-  std::memcpy(c->h_in, h.tk->env_id, (size_t)h.n * 4);
-  std::memcpy(c->h_in + h.col, h.tk->min_version, (size_t)h.n * 4);
-  std::memcpy(c->h_in + 2 * h.col, h.tk->requestor_ip, (size_t)h.n * 4);
-  HIP_TRY(c, hipMemcpyAsync(c->d_in.p, c->h_in, h.bytes, hipMemcpyHostToDevice, c->copy_stream));
+  if (h.direct) {
+    const uint32_t* cols[3] = {h.tk->env_id, h.tk->min_version, h.tk->requestor_ip};
+    for (int k = 0; k < 3; ++k)
+      HIP_TRY(c, hipMemcpyAsync(c->d_in.p + k * h.col, cols[k], (size_t)h.n * 4, hipMemcpyHostToDevice,
+                                c->copy_stream));
+  } else {
+    std::memcpy(c->h_in, h.tk->env_id, (size_t)h.n * 4);
+    std::memcpy(c->h_in + h.col, h.tk->min_version, (size_t)h.n * 4);
+    std::memcpy(c->h_in + 2 * h.col, h.tk->requestor_ip, (size_t)h.n * 4);
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, c->h_in, h.bytes, hipMemcpyHostToDevice, c->copy_stream));
+  }
   HIP_TRY(c, hipEventRecord(c->copy_ev, c->copy_stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
   return YDC_OK;
@@ -1603,6 +1671,21 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t S = c->n_servants;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // Page-locked caller buffers (ydc_host_register / ydc_host_alloc) are used as they are: the
+  // classification reads the request columns and k_finalize writes the results through their
+  // device addresses — no staging memcpy, no copy command on either side.
+  const bool zero_copy = c->opt_zero_copy;
+  const uint32_t* m_in[3] = {nullptr, nullptr, nullptr};
+  if (zero_copy && N) {
+    m_in[0] = (const uint32_t*)pinned_device_pointer(tk->env_id, (size_t)N * 4);
+    m_in[1] = m_in[0] ? (const uint32_t*)pinned_device_pointer(tk->min_version, (size_t)N * 4) : nullptr;
+    m_in[2] = m_in[1] ? (const uint32_t*)pinned_device_pointer(tk->requestor_ip, (size_t)N * 4) : nullptr;
+  }
+  const bool in_pinned = m_in[0] && m_in[1] && m_in[2];
+  uint32_t* m_idx = zero_copy && N ? (uint32_t*)pinned_device_pointer(out_idx, (size_t)N * 4) : nullptr;
+  uint32_t* m_run = zero_copy && out_running && S ? (uint32_t*)pinned_device_pointer(out_running, (size_t)S * 4) : nullptr;
+  double* m_util = zero_copy && out_util && N ? (double*)pinned_device_pointer(out_util, (size_t)N * 8) : nullptr;
+  const bool out_pinned = (!N || m_idx) && (!(out_running && S) || m_run) && (!(out_util && N) || m_util);
   // in: env | min_version | requestor_ip        out: idx | running_tasks | utilisation
   const size_t col = pad((size_t)N * 4), in_bytes = 3 * col;
   const size_t o_run = pad((size_t)N * 4), o_util = o_run + pad((size_t)(out_running ? S : 0) * 4);
@@ -1617,27 +1700,46 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
     if (e == hipSuccess) *cap = want;
     return e;
   };
-  HIP_TRY(c, pinned(&c->h_in, &c->h_in_cap, in_bytes));
+  // Request columns: read in place (in_pinned, YDC_HOST_IN=map), copied by DMA straight from
+  // the caller's pinned columns (in_pinned, YDC_HOST_IN=copy), or staged through the context's
+  // own pinned arena (pageable caller memory).
+  const bool in_map = in_pinned && c->opt_host_in_map;
+  ydc_task_soa d{};
+  c->host_in.active = false;
+  if (in_map) {
+    d = ydc_task_soa{m_in[0], m_in[1], m_in[2]};
+  } else if (N) {
+    if (!in_pinned) HIP_TRY(c, pinned(&c->h_in, &c->h_in_cap, in_bytes));
+    HIP_TRY(c, c->d_in.reserve(std::max<size_t>(in_bytes, 256)));
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+    // The columns are staged and copied inside the batch, behind the launches that do not need
+    // them (enqueue_front / stage_host_requests).
+    c->host_in.active = true;
+    c->host_in.direct = in_pinned;
+    c->host_in.tk = tk;
+    c->host_in.n = N;
+    c->host_in.col = col;
+    c->host_in.bytes = in_bytes;
+    d = ydc_task_soa{(const uint32_t*)c->d_in.p, (const uint32_t*)(c->d_in.p + col),
+                     (const uint32_t*)(c->d_in.p + 2 * col)};
+  }
+  int rc;
+  if (out_pinned) {
+    c->post_copy.bytes = 0;
+    rc = ydc_dispatch_device(c, &d, N, flags, m_idx, out_util ? m_util : nullptr,
+                             out_running && S ? m_run : nullptr);
+    c->host_in.active = false;
+    return rc;  // ydc_dispatch_device has waited for the stream: the results are in the caller's buffers
+  }
   HIP_TRY(c, pinned(&c->h_res, &c->h_res_cap, res_bytes));
-  HIP_TRY(c, c->d_in.reserve(std::max<size_t>(in_bytes, 256)));
   HIP_TRY(c, c->d_res.reserve(std::max<size_t>(res_bytes, 256)));
-  if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  if (!c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
-  // The columns are staged and copied inside the batch, behind the launches that do not need
-  // them (enqueue_front / stage_host_requests).
-  c->host_in.active = N != 0;
-  c->host_in.tk = tk;
-  c->host_in.n = N;
-  c->host_in.col = col;
-  c->host_in.bytes = in_bytes;
-  ydc_task_soa d{(const uint32_t*)c->d_in.p, (const uint32_t*)(c->d_in.p + col),
-                 (const uint32_t*)(c->d_in.p + 2 * col)};
   c->post_copy.dst = c->h_res;
   c->post_copy.src = c->d_res.p;
   c->post_copy.bytes = res_bytes;
-  int rc = ydc_dispatch_device(c, &d, N, flags, (uint32_t*)c->d_res.p,
-                               out_util ? (double*)(c->d_res.p + o_util) : nullptr,
-                               out_running && S ? (uint32_t*)(c->d_res.p + o_run) : nullptr);
+  rc = ydc_dispatch_device(c, &d, N, flags, (uint32_t*)c->d_res.p,
+                           out_util ? (double*)(c->d_res.p + o_util) : nullptr,
+                           out_running && S ? (uint32_t*)(c->d_res.p + o_run) : nullptr);
   c->post_copy.bytes = 0;
   c->host_in.active = false;
   if (rc) return rc;
@@ -1646,6 +1748,74 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
   if (out_running && S) std::memcpy(out_running, c->h_res + o_run, (size_t)S * 4);
   if (out_util && N) std::memcpy(out_util, c->h_res + o_util, (size_t)N * 8);
   return YDC_OK;
+}
+
+int ydc_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return YDC_ERR_INVALID_ARGUMENT;
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+    return YDC_ERR_HIP;
+  }
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess || !dev) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(p);
+    g_create_error = "hipHostGetDevicePointer failed for a registered range";
+    return YDC_ERR_HIP;
+  }
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  g_pinned.push_back(PinnedRange{(const char*)p, bytes, (char*)dev, 0});
+  g_not_pinned.clear();
+  return YDC_OK;
+}
+
+int ydc_host_unregister(void* p) {
+  if (!p) return YDC_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  for (size_t i = 0; i < g_pinned.size(); ++i)
+    if (g_pinned[i].host == (const char*)p && g_pinned[i].kind == 0) {
+      g_pinned.erase(g_pinned.begin() + (long)i);
+      return hipHostUnregister(p) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
+    }
+  return YDC_ERR_INVALID_ARGUMENT;
+}
+
+int ydc_host_alloc(size_t bytes, void** out) {
+  if (!out) return YDC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? YDC_ERR_NO_DEVICE : YDC_ERR_HIP;
+  }
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess || !dev) {
+    (void)hipGetLastError();
+    (void)hipHostFree(p);
+    return YDC_ERR_HIP;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned.push_back(PinnedRange{(const char*)p, bytes ? bytes : 1, (char*)dev, 1});
+    g_not_pinned.clear();
+  }
+  *out = p;
+  return YDC_OK;
+}
+
+int ydc_host_free(void* p) {
+  if (!p) return YDC_OK;
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  for (size_t i = 0; i < g_pinned.size(); ++i)
+    if (g_pinned[i].host == (const char*)p && g_pinned[i].kind == 1) {
+      g_pinned.erase(g_pinned.begin() + (long)i);
+      return hipHostFree(p) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
+    }
+  return YDC_ERR_INVALID_ARGUMENT;
 }
 
 }  // extern "C" (reopened below)
@@ -2514,6 +2684,14 @@ int ydc_stream_end(ydc_context* c) {
 int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
                     uint32_t n_upd, const uint32_t* release_servant_idx, uint32_t n_rel,
                     const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx) {
+  return ydc_stream_tick_wide(c, upd_idx, upd_rows, nullptr, 1, n_upd, release_servant_idx, n_rel, tasks,
+                              n_tasks, out_servant_idx);
+}
+
+int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                         const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
+                         const uint32_t* release_servant_idx, uint32_t n_rel, const ydc_task_soa* tasks,
+                         uint32_t n_tasks, uint32_t* out_servant_idx) {
   if (!c || !c->stream_mode.active) return YDC_ERR_INVALID_ARGUMENT;
   auto& sm = c->stream_mode;
   if (n_upd > sm.max_upd || n_rel > sm.max_rel || n_tasks > sm.max_tasks)
@@ -2523,33 +2701,51 @@ int ydc_stream_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_r
   if ((n_upd && (!upd_idx || !upd_rows)) || (n_rel && !release_servant_idx) ||
       (n_tasks && (!tasks || !out_servant_idx)))
     return YDC_ERR_INVALID_ARGUMENT;
+  if (upd_env_masks && (env_words == 0 || env_words > YDC_MAX_ENV_WORDS))
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "env_words %u out of range", env_words);
   HIP_TRY(c, hipSetDevice(c->device));
-  // Heartbeats: structural ones (and new servants) take the eager path.
+  // Heartbeats: structural ones (and new servants) take the eager path. With masks (the wide
+  // form) a changed environment set is structural like any other change; without them, rows of
+  // a table with several mask words cannot say what the servant advertises — it keeps its
+  // environments, and a NEW servant (which would silently have none) is refused.
+  const uint32_t EW = c->env_words;
   bool structural = false;
   for (uint32_t i = 0; i < n_upd && !structural; ++i) {
     const uint32_t s = upd_idx[i];
     if (s >= c->n_servants) {
+      if (!upd_env_masks && EW > 1)
+        return fail(c, YDC_ERR_INVALID_ARGUMENT, "a tick that adds a servant to a table with %u mask "
+                    "words needs its environments: use ydc_stream_tick_wide", EW);
       structural = true;
       break;
     }
     const ydc_servant_row& r = upd_rows[i];
-    structural = c->h_version[s] != r.version || (c->env_words == 1 && c->h_env[s] != r.env_mask) ||
+    bool env_changed = false;
+    if (upd_env_masks) {
+      for (uint32_t w = 0; w < std::max(EW, env_words); ++w) {
+        const uint64_t have = w < EW ? c->h_env[(size_t)s * EW + w] : 0;
+        const uint64_t want = w < env_words ? upd_env_masks[(size_t)i * env_words + w] : 0;
+        env_changed |= have != want;
+      }
+    } else if (EW == 1) {
+      env_changed = c->h_env[s] != r.env_mask;
+    }
+    structural = c->h_version[s] != r.version || env_changed ||
                  c->h_ip[s] != r.ip_id || (c->h_max_tasks[s] == 0) != (r.max_tasks == 0) ||
                  std::min(c->h_max_tasks[s], c->h_nproc[s]) != std::min(r.max_tasks, r.num_processors);
   }
   uint32_t graph_upd = n_upd;
   if (structural) {
-    if (c->env_words == 1) {
+    if (upd_env_masks) {
+      if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, upd_env_masks, env_words, n_upd)) return rc;
+    } else if (EW == 1) {
       if (int rc = ydc_update_servants(c, upd_idx, upd_rows, n_upd)) return rc;
     } else {
-      // Wide masks do not fit a tick's rows: the servants keep their environments.
-      std::vector<uint64_t> env((size_t)n_upd * c->env_words, 0);
+      // Rows without masks on a wide table: the (known) servants keep their environments.
+      std::vector<uint64_t> env((size_t)n_upd * EW, 0);
       for (uint32_t i = 0; i < n_upd; ++i)
-        if (upd_idx[i] < c->n_servants)
-          std::copy_n(&c->h_env[(size_t)upd_idx[i] * c->env_words], c->env_words,
-                      &env[(size_t)i * c->env_words]);
-      if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, env.data(), c->env_words, n_upd))
-        return rc;
+        std::copy_n(&c->h_env[(size_t)upd_idx[i] * EW], EW, &env[(size_t)i * EW]);
+      if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, env.data(), EW, n_upd)) return rc;
     }
     graph_upd = 0;
   } else {

@@ -37,7 +37,8 @@ class EventStream:
             rows[k] = self.sv[k][who]
         rows["flags"] = self.abi["flags"][who]
         rows["ip_id"] = self.abi["ip_id"][who]
-        rows["env_mask"] = self.abi["env_mask"][who]
+        em = self.abi["env_mask"]
+        rows["env_mask"] = em[who] if em.ndim == 1 else em[who, 0]  # (wide masks travel beside the rows)
         n_free = min(self.frees_per_tick, len(self.live))
         pick = self.rng.choice(len(self.live), n_free, replace=False) if n_free else np.empty(0, np.int64)
         rel = self.live[pick]
