@@ -46,20 +46,12 @@ def sharded_run(ctxs, sv, tk, cuts, commit=False):
     return res
 
 
-def make_group(G, sv, transport=None):
+def make_group(G, sv):
     ctxs = [binding.Context(device=0) for _ in range(G)]
     cols = pack.to_abi_columns(sv)
     for c in ctxs:
         c.upload_servants(cols)
-    if transport is None:
-        binding.group_init_local(ctxs)
-    else:
-        # the inter-process mailbox transport between contexts of ONE process (peers inside the
-        # exporter's process take its pointer instead of opening the IPC handle)
-        handles = [c.group_ipc_export(r, G) for r, c in enumerate(ctxs)]
-        for r, c in enumerate(ctxs):
-            c.group_init_ipc(handles, r, G, transport)
-            assert c.group_transport() == transport
+    binding.group_init_local(ctxs)
     return ctxs
 
 
@@ -154,27 +146,6 @@ def test_local_ranks_match_oracle(G):
     res = sharded_run(ctxs, sv, tk, cuts)
     check_against_oracle(res, sv, tk)
     assert max(r[3]["rounds"] for r in res) == min(r[3]["rounds"] for r in res)  # lockstep
-    [c.close() for c in ctxs]
-
-
-@pytest.mark.parametrize("transport", [binding.TRANSPORT_IPC_DEVICE, binding.TRANSPORT_IPC_HOST])
-def test_mailbox_transport_in_process(transport):
-    """k_mailbox_all_gather (in-stream, tagged granules, two slot sets) between three contexts of
-    this process, each rank on its own thread and stream; tiny slots so that the 4.8 KB slot-delta
-    exchange is cut into pieces."""
-    import os
-    os.environ["YDC_IPC_SLOT_WORDS"] = "256"
-    try:
-        sv, tk = cases.random_case(seed=58, n_tasks=40_000, n_servants=1200, n_envs=4,
-                                   self_frac=0.15, unknown_env_frac=0.002)
-        n = len(tk["env_id"])
-        ctxs = make_group(3, sv, transport)
-    finally:
-        del os.environ["YDC_IPC_SLOT_WORDS"]
-    res = sharded_run(ctxs, sv, tk, [0, n // 4, n // 2, n])
-    check_against_oracle(res, sv, tk)
-    res = sharded_run(ctxs, sv, tk, [0, n // 2, n // 2, n])  # stamps and parities carry on
-    check_against_oracle(res, sv, tk)
     [c.close() for c in ctxs]
 
 
