@@ -191,6 +191,22 @@ int ydc_dispatch_device(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t 
                         uint32_t flags, uint32_t* d_out_servant_idx, double* d_out_utilization,
                         uint32_t* d_out_running);
 
+/* Pipelined form: ydc_dispatch_device_async enqueues the whole batch and returns without
+ * waiting; ydc_dispatch_wait waits for the OLDEST outstanding batch, whose results are final
+ * when it returns. At most two batches may be outstanding, so the usual loop is
+ *   async(0); for k = 1..: async(k); wait();  ...  wait();
+ * — the device works on batch k while the host looks at the outcome of batch k - 1 and enqueues
+ * batch k + 1. Batches take effect strictly in order (COMMIT of batch k is what batch k + 1
+ * sees), and results are exactly those of the synchronous calls: a batch that does not become
+ * final within the matching passes enqueued for it takes no effect on the device, neither does
+ * the batch behind it, and ydc_dispatch_wait places both again, in order. The caller's buffers
+ * of a batch (request columns, outputs) must stay untouched until its wait has returned; no
+ * other call on the context is allowed while batches are outstanding. */
+int ydc_dispatch_device_async(ydc_context* ctx, const ydc_task_soa* d_tasks, uint32_t n_tasks,
+                              uint32_t flags, uint32_t* d_out_servant_idx,
+                              double* d_out_utilization, uint32_t* d_out_running);
+int ydc_dispatch_wait(ydc_context* ctx);
+
 /* ---- streaming mode (BASELINE.json configs[4]) -------------------------------
  * One tick applies, in this order: n_upd heartbeats of known servants
  * (KeepServantAlive: personality replaced, running_tasks kept, task_dispatcher.cc:195-201),

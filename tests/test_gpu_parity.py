@@ -138,6 +138,43 @@ def test_dispatch_zero_copy_pinned_buffers(host_in, monkeypatch):
     c.close()
 
 
+def test_pipelined_batches_commit_in_order(monkeypatch):
+    """ydc_dispatch_device_async / ydc_dispatch_wait: a batch is enqueued while the previous one is
+    still running; every batch COMMITs, so batch k + 1 must see exactly the registry batch k left.
+    Six batches of one sequence == the oracle on the concatenation. Then the same with matching
+    passes that cannot converge in the pipeline (hand-off patience 0: most waves leave their
+    chunk to a later pass than the pipeline enqueues): the batches are replayed in order by
+    ydc_dispatch_wait — same placement, same final registry."""
+    DA = binding.DeviceArray
+    sv, tk = cases.random_case(seed=95, n_tasks=120_000, n_servants=1800, n_envs=3, self_frac=0.15,
+                               unknown_env_frac=0.002)
+    want, _, wrun = O.dispatch(sv, tk, "sorted")
+    n, S, nb = len(tk["env_id"]), len(sv["version"]), 6
+    per = n // nb
+    for tries in (None, "0"):
+        if tries is not None:
+            monkeypatch.setenv("YDC_HAND_TRIES", tries)
+        c = binding.Context(device=0)
+        c.upload_servants(pack.to_abi_columns(sv))
+        cols = [[DA.from_numpy(tk[k][b * per:(b + 1) * per]) for k in ("env_id", "min_version", "requestor_ip")]
+                for b in range(nb)]
+        outs = [DA.from_numpy(np.full(per, 0xDEADBEEF, np.uint32)) for _ in range(nb)]
+        runs = [DA(S, np.uint32) for _ in range(nb)]
+        c.dispatch_device_async(*cols[0], outs[0], None, runs[0], commit=True)
+        for b in range(1, nb):
+            c.dispatch_device_async(*cols[b], outs[b], None, runs[b], commit=True)
+            c.dispatch_wait()
+        c.dispatch_wait()
+        got = np.concatenate([o.numpy() for o in outs])
+        bad = np.nonzero(got != want[:per * nb])[0]
+        assert bad.size == 0, (tries, bad[:5], got[bad[:5]], want[bad[:5]])
+        wrun_b = O.dispatch(sv, {k: v[:per * nb] for k, v in tk.items()}, "sorted")[2]
+        assert np.array_equal(runs[-1].numpy(), wrun_b) and np.array_equal(c.get_running(), wrun_b)
+        with pytest.raises(binding.YdcError):
+            c.dispatch_wait()  # nothing outstanding
+        c.close()
+
+
 def test_golden_load_balance(ctx):
     """task_dispatcher_test.cc:216-298 through the GPU path, one request per batch with the
     chosen servant re-heartbeated at load + 1, like the reference test."""

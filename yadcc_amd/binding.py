@@ -28,7 +28,8 @@ ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
     "ydc_upload_servants", "ydc_update_servants", "ydc_update_servants_wide",
     "ydc_set_host_aliases", "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
-    "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_synchronize",
+    "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_dispatch_device_async",
+    "ydc_dispatch_wait", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
     "ydc_host_register", "ydc_host_unregister", "ydc_host_alloc", "ydc_host_free",
@@ -115,6 +116,8 @@ def lib():
         L.ydc_dispatch.argtypes = [C.c_void_p, C.POINTER(TaskSoA), C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
         L.ydc_dispatch_device.argtypes = L.ydc_dispatch.argtypes
+        L.ydc_dispatch_device_async.argtypes = L.ydc_dispatch.argtypes
+        L.ydc_dispatch_wait.argtypes = [C.c_void_p]
         L.ydc_synchronize.argtypes = [C.c_void_p]
         L.ydc_stream_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ydc_stream_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
@@ -380,6 +383,21 @@ class Context:
                                               DISPATCH_COMMIT if commit else 0, _ptr(d_out_idx),
                                               _ptr(d_out_util), _ptr(d_out_running)),
                     "ydc_dispatch_device")
+
+    def dispatch_device_async(self, d_env, d_minv, d_ip, d_out_idx=None, d_out_util=None,
+                              d_out_running=None, commit=False):
+        """Pipelined dispatch_device: enqueues the batch and returns; dispatch_wait() waits for
+        the oldest outstanding batch (at most two may be outstanding)."""
+        soa = TaskSoA(_ptr(d_env), _ptr(d_minv), _ptr(d_ip))
+        n = int(d_env.numel())
+        self._check(lib().ydc_dispatch_device_async(self._h, C.byref(soa), n,
+                                                    DISPATCH_COMMIT if commit else 0,
+                                                    _ptr(d_out_idx), _ptr(d_out_util),
+                                                    _ptr(d_out_running)),
+                    "ydc_dispatch_device_async")
+
+    def dispatch_wait(self):
+        self._check(lib().ydc_dispatch_wait(self._h), "ydc_dispatch_wait")
 
     def synchronize(self):
         self._check(lib().ydc_synchronize(self._h), "ydc_synchronize")

@@ -363,6 +363,11 @@ struct BinSortArgs {
   const uint32_t* cls_begin;     // [C + 1]
   uint2* list;                   // class lists: {global rank, slot}
   uint32_t* rank_to_g;
+  // [ceil(M / 64) * C] level table: entry (m, c) = position in class c's list of its first slot
+  // whose global rank is >= 64 m. The matching kernel's level guesses (the class states after
+  // the n lowest-ranked slots are gone) read it instead of searching the lists: one lookup and
+  // one 64-entry window per class.
+  uint32_t* level_tab;
 };
 
 __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, DeviceParams* prm, PrefixArgs pa) {
@@ -508,9 +513,13 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
   for (uint32_t t = threadIdx.x; t < kBinWaves * 256; t += blockDim.x) tab[t] = 0;
   __syncthreads();
   const uint32_t cmask = a.cls_bits ? (1u << a.cls_bits) - 1 : 0u;
-  for (uint32_t p0 = 0; p0 < n; p0 += blockDim.x) {
-    const uint32_t p = p0 + threadIdx.x;
-    const bool valid = p < n;
+  // (The walk is aligned to the global rank: wave w of a round starts at a rank that is a
+  // multiple of 64, so the level table's entries are the counts at wave starts.)
+  const uint32_t skew = lo & 63u;
+  for (uint32_t q0 = 0; q0 < n + skew; q0 += blockDim.x) {
+    const uint32_t q = q0 + threadIdx.x;
+    const bool valid = q >= skew && q - skew < n;
+    const uint32_t p = q - skew;
     uint32_t slot = 0, cls = 0;
     if (valid) {
       const uint32_t w = src[p];
@@ -528,6 +537,17 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
     const uint32_t before_in_wave = (uint32_t)__popcll(peers & lt_mask);
     if (valid && before_in_wave == 0) tab[wave * 256 + cls] = (uint32_t)__popcll(peers);
     __syncthreads();
+    {
+      // Level table: this wave's first rank, if it belongs to this bin.
+      const uint32_t r0 = lo - skew + q0 + wave * 64;
+      if (a.level_tab && r0 >= lo && r0 < hi) {
+        for (uint32_t c = lane; c < C; c += 64) {
+          uint32_t pos = cbase[c];
+          for (uint32_t w = 0; w < wave; ++w) pos += tab[w * 256 + c];
+          a.level_tab[(size_t)(r0 >> 6) * C + c] = pos;
+        }
+      }
+    }
     if (valid) {
       uint32_t pos = cbase[cls] + before_in_wave;
       for (uint32_t w = 0; w < wave; ++w) pos += tab[w * 256 + cls];

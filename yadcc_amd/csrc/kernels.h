@@ -56,6 +56,10 @@ struct DeviceParams {
   // Multi-GPU over the inter-process mailbox transport (k_mailbox_all_gather): a peer's data
   // did not arrive in time. Never reset by a batch: the group is broken.
   uint32_t exchange_timeout;
+  // Pipelined batches (ydc_dispatch_device_async): an earlier batch of the pipeline did not
+  // become final within its pre-launched passes — the batches enqueued behind it take no effect
+  // (their finalise is gated on this) and the host replays from there. Cleared by the host.
+  uint32_t pipeline_broken;
 };
 
 struct ServantTable {
@@ -991,6 +995,9 @@ struct RunningArgs {
   uint32_t* out_a;        // nullable: the caller's copy
   uint32_t* out_b;        // nullable: a second copy (never the resident column: see k_finalize)
   uint32_t* taken_out;    // nullable: multi-GPU, this rank's slot delta
+  // Pipelined batches: a batch that is not final latches DeviceParams::pipeline_broken, and no
+  // batch takes effect while it is set.
+  uint32_t pipelined;
 };
 
 // Slots of servant s (class c) that sort before what `st` has not consumed yet.
@@ -1024,7 +1031,9 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
                                                   uint32_t rank_stride) {
   // Pre-launched behind the matching passes: only takes effect once they have converged (and,
   // with a sharded sort, only if every rank's key window covered what its requests reached).
-  const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss;
+  const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss &&
+                     !(ra.pipelined && prm->pipeline_broken);
+  if (ra.pipelined && !final && blockIdx.x == req_blocks && threadIdx.x == 0) prm->pipeline_broken = 1;
   if (blockIdx.x < req_blocks) {
     if (!final) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -119,6 +119,10 @@ struct MatchBuffers {
   // the chunk's first request is almost always its predecessor's end state — and the chunk
   // needs no second replay.
   const uint32_t* tail;
+  // Non-NULL (bin sort, one part): level table, entry (m, c) = position in class c's list of its
+  // first slot whose global rank is >= 64 m (bin_sort.h). With <= 8 classes pass 0 turns a level
+  // into class cursors with one lookup and one 64-entry window per class instead of a search.
+  const uint32_t* level_tab;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
   uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
 };
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   if (pass_arg == 0) YDC_PROBE(probe_kc, 0);  // entry
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
   const uint32_t batch_seq = prm->batch_seq;
+  const uint32_t n_slots_all = prm->n_slots;
   const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
   const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
   const bool warm_mode = own_guess && B.hand != nullptr && B.tail != nullptr && B.n_parts <= 1 &&
@@ -604,7 +609,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       const uint32_t n0 = before0, n1 = before1;
       const uint32_t b = L.cls_begin[lane], e = L.cls_begin[lane + 1];
       uint32_t c0 = 0, c1 = 0;
-      if (L.list_p && C <= 4) {
+      if (L.list_p && B.level_tab && C <= 8) {
+        // (filled in below by the whole wave, from the level table)
+      } else if (L.list_p && C <= 4) {
         // (filled in below by the whole wave)
       } else if (L.list_p) {
         uint32_t lo0 = b, hi0 = e, lo1 = b, hi1 = e;
@@ -629,7 +636,43 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       next_guess = st;
       next_guess.cursor = next_guess.lo = c1;
     }
-    if (L.list_p && C <= 4) {
+    if (L.list_p && B.level_tab && C <= 8) {
+      // Level table: class c's first slot with rank >= 64 m is a lookup; the slots of the class
+      // with a rank in [64 m, level) — at most 64 — are counted by the whole wave in one
+      // 64-entry window of the list. Both levels of all classes side by side: two dependent
+      // round trips instead of one per search step.
+      uint32_t pos[2] = {0, 0}, lvl[2] = {before0, before1}, endc = 0;
+      if (lane < C) {
+        endc = L.cls_begin[lane + 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          pos[h] = lvl[h] < n_slots_all ? B.level_tab[(size_t)(lvl[h] >> 6) * C + lane] : endc;
+      }
+      uint32_t v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t c = (uint32_t)q >> 1;
+        v[q] = 0xFFFFFFFFu;  // "not below the level"
+        if (c < C) {
+          const uint32_t at = readlane_u32(pos[q & 1], c) + lane, e = readlane_u32(endc, c);
+          if (at < e) v[q] = list_rank(L, at);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t c = (uint32_t)q >> 1;
+        if (c < C) {
+          const uint32_t tgt = readlane_u32(lvl[q & 1], c);
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(v[q] < tgt));  // a prefix: the list is sorted
+          if (lane == c) {
+            const uint32_t cur = pos[q & 1] + cnt;
+            if (q & 1) next_guess.cursor = next_guess.lo = cur;
+            else st.cursor = st.lo = cur;
+          }
+        }
+      }
+      if (lane < C) next_guess.hown_lo = next_guess.hown_hi = kNone;
+    } else if (L.list_p && C <= 4) {
       // A handful of classes: the wave searches together, 64 probes per search and round
       // (three rounds for a list of 2^18 entries instead of eighteen dependent loads), the
       // 2 * C searches side by side (targets: the class's own level, see before0 / before1).

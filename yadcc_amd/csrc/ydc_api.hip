@@ -130,6 +130,7 @@ struct ydc_context {
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
   DevBuf<uint32_t> d_binbase, d_binruns;  // bin sort: starts of the bins per class, run table of the slot tiles
+  DevBuf<uint32_t> d_level_tab;           // bin sort: class-list positions at every 64th global rank
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_chunk_tail;  // consuming requests among the last kWarmUp of every chunk
@@ -137,6 +138,24 @@ struct ydc_context {
   DevBuf<ClassState> d_guess[1], d_endst, d_checkpoint, d_early;
   DevBuf<unsigned long long> d_claim, d_hand;  // d_hand: hand-off granules of the pass 0 + 1 launch
   uint32_t round_hint = 3;  // passes to pre-launch before looking at the outcome
+
+  // Pipelined batches (ydc_dispatch_device_async / ydc_dispatch_wait): up to two batches are
+  // enqueued before the host looks at the outcome of the older one.
+  struct Pending {
+    bool active = false, rerun = false, done_sync = false;
+    BatchPlan plan;
+    ydc_task_soa tk{};
+    uint32_t n = 0, flags = 0, launched = 0;
+    uint32_t* out_idx = nullptr;
+    double* out_util = nullptr;
+    uint32_t* out_running = nullptr;
+    DeviceParams* h_outcome = nullptr;  // pinned
+    hipEvent_t ev = nullptr;
+    int sync_rc = 0;
+  } pend[2];
+  uint32_t pend_head = 0, pend_count = 0;
+  bool enqueue_pipelined = false;  // the finalise being enqueued belongs to a pipelined batch
+  uint64_t pipeline_misses = 0;
 
   // Multi-GPU group (ydc_group_*): this context is one rank of a sharded dispatcher.
   struct LocalHub;  // single-process transport: several contexts on one device
@@ -265,6 +284,7 @@ struct ydc_context {
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  bool opt_level_tab = true;  // bin sort leaves a level table for pass 0's guesses (YDC_LEVEL_TAB=0: search)
   // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
   // request columns read in place through the mapped pointer (YDC_HOST_IN=map) or copied by DMA
   // from where they lie (YDC_HOST_IN=copy).
@@ -586,6 +606,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
+  if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
   if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
   if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
@@ -627,6 +648,10 @@ int ydc_destroy(ydc_context* c) {
   c->d_dirty.release();
   c->d_prm.release();
   if (c->h_prm) (void)hipHostFree(c->h_prm);
+  for (auto& pd : c->pend) {
+    if (pd.h_outcome) (void)hipHostFree(pd.h_outcome);
+    if (pd.ev) (void)hipEventDestroy(pd.ev);
+  }
   if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_rel) (void)hipHostFree(c->h_rel);
   if (c->h_rel_ev) (void)hipEventDestroy(c->h_rel_ev);
@@ -1009,6 +1034,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     HIP_TRY(c, c->d_binbase.reserve((size_t)(p.n_bins + 1) * (C + 1)));
     HIP_TRY(c, c->d_binruns.reserve((size_t)p.bin_tiles * p.n_bins));
     HIP_TRY(c, c->d_rank_to_g.reserve(slot_bound));
+    if (c->opt_level_tab) HIP_TRY(c, c->d_level_tab.reserve(((size_t)(slot_bound >> 6) + 2) * C));
     // (consuming counts per wave of 64 requests instead of per chunk)
     HIP_TRY(c, c->d_chunk_consuming.reserve(((size_t)ceil_div(std::max(N, 1u), 64) + 1) * c->n_parts));
   }
@@ -1084,6 +1110,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     p.mb.flags = c->d_prm.p->n_changed;
     p.mb.sampled = c->d_prm.p->n_sampled;
     p.mb.flag_mask = 63;
+    p.mb.level_tab = p.binsort && c->opt_level_tab && c->n_parts <= 1 ? c->d_level_tab.p : nullptr;
     // (a group of one rank is a single GPU with the exchanges of the protocol around it)
     p.fuse01 = c->opt_fuse_passes && c->group.n_ranks <= 1;
     if (p.fuse01) {
@@ -1220,7 +1247,8 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
     BinSortArgs ba{(const uint2*)c->d_keys[0].p,
                    BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles},
                    p.C, p.gbits, p.bin_slot_bits, p.bin_cls_bits, c->d_slot_base.p, c->d_cls_begin.p,
-                   (uint2*)c->d_keys[1].p, c->d_rank_to_g.p};
+                   (uint2*)c->d_keys[1].p, c->d_rank_to_g.p,
+                   c->opt_level_tab && c->n_parts <= 1 ? c->d_level_tab.p : nullptr};
     YDC_LAUNCH(c, "k_bin_sort", k_bin_sort, dim3(p.n_bins + (pending_prefix ? 1 : 0)), dim3(kBinThreads),
                (size_t)kBinLdsWords * 4, c->stream, ba, c->d_prm.p, pending_prefix ? pa : PrefixArgs{});
     mark(c, 3);
@@ -1387,6 +1415,7 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   // value of other servants (the head of their class list), so COMMIT is a copy behind it.
   ra.out_b = nullptr;
   ra.taken_out = d_taken;
+  ra.pipelined = c->enqueue_pipelined ? 1u : 0u;
   YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(req_blocks + srv_blocks), dim3(256), 0, c->stream, p.sv,
              c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N, p.wave_path ? 1u : 0u,
              d_out_idx, d_out_util, check_slot, c->d_prm.p, p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu,
@@ -1645,6 +1674,8 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   if (!c || (N && !tk)) return YDC_ERR_INVALID_ARGUMENT;
   if (c->max_tasks && N > c->max_tasks)
     return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
+  if (c->pend_count && !c->pend[c->pend_head].rerun && c->pend[c->pend_head].active)
+    return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
   HIP_TRY(c, hipSetDevice(c->device));
   BatchPlan p;
   if (int rc = plan_batch(c, N, &p)) return rc;
@@ -1663,6 +1694,105 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
     collect_kernel_profile(c);
   }
   return YDC_OK;
+}
+
+// Pipelined form of ydc_dispatch_device: enqueues the whole batch (front, the matching passes the
+// last batches needed, the gated finalise, the outcome read-back) and returns; the host looks at
+// the outcome in ydc_dispatch_wait — by then the next batch is already queued behind this one, so
+// the device does not idle while the host turns around. Exact whatever happens: a batch that is
+// not final within its pre-launched passes (or whose bins overflowed) takes no effect, latches
+// DeviceParams::pipeline_broken so that the batch behind it takes none either, and both are
+// replayed in order by ydc_dispatch_wait.
+int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
+                              uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running) {
+  if (!c || (N && !tk)) return YDC_ERR_INVALID_ARGUMENT;
+  if (c->pend_count == 2) return fail(c, YDC_ERR_INVALID_ARGUMENT, "two batches outstanding: ydc_dispatch_wait first");
+  if (c->max_tasks && N > c->max_tasks)
+    return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto& pd = c->pend[(c->pend_head + c->pend_count) & 1];
+  if (!pd.h_outcome) HIP_TRY(c, hipHostMalloc((void**)&pd.h_outcome, sizeof(DeviceParams)));
+  if (!pd.ev) HIP_TRY(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
+  pd.active = true;
+  pd.rerun = pd.done_sync = false;
+  pd.tk = tk ? *tk : ydc_task_soa{};
+  pd.n = N;
+  pd.flags = flags;
+  pd.out_idx = d_out_idx;
+  pd.out_util = d_out_util;
+  pd.out_running = d_out_running;
+  pd.launched = 0;
+  // A batch behind one that already has to be replayed is not worth enqueueing.
+  const bool behind_rerun = c->pend_count == 1 && c->pend[c->pend_head].rerun;
+  if (int rc = plan_batch(c, N, &pd.plan)) return rc;
+  if (behind_rerun || !pd.plan.wave_path || c->profiling || c->debug_verify_binsort) {
+    // (registries without the wave path have host-checked rounds: placed when waited for)
+    pd.rerun = true;
+  } else {
+    if (int rc = enqueue_front(c, pd.plan, &pd.tk)) return rc;
+    const uint32_t group = std::max(2u, std::min(c->round_hint, 16u));
+    for (uint32_t r = 0; r < group; ++r) enqueue_pass(c, pd.plan, r, 1u);
+    pd.launched = group;
+    c->enqueue_pipelined = true;
+    int rc = enqueue_finalize(c, pd.plan, flags, d_out_idx, d_out_util, d_out_running, (group - 1) & 63);
+    c->enqueue_pipelined = false;
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(pd.h_outcome, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(pd.ev, c->stream));
+  }
+  ++c->pend_count;
+  return YDC_OK;
+}
+
+// Waits for the OLDEST outstanding batch; its results are final when this returns.
+int ydc_dispatch_wait(ydc_context* c) {
+  if (!c) return YDC_ERR_INVALID_ARGUMENT;
+  if (c->pend_count == 0) return fail(c, YDC_ERR_INVALID_ARGUMENT, "no batch outstanding");
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto& pd = c->pend[c->pend_head];
+  auto pop = [&] {
+    pd.active = false;
+    c->pend_head ^= 1;
+    --c->pend_count;
+  };
+  bool miss = pd.rerun;
+  uint32_t rounds = 0;
+  if (!miss) {
+    HIP_TRY(c, hipEventSynchronize(pd.ev));
+    const DeviceParams& o = *pd.h_outcome;
+    if (o.overflow) {
+      pop();
+      return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", pd.plan.slot_bound);
+    }
+    miss = o.pipeline_broken || (pd.plan.binsort && o.window_miss) || o.n_changed[(pd.launched - 1) & 63] != 0;
+    if (!miss) {
+      rounds = pd.launched;
+      for (uint32_t r = 0; r < pd.launched; ++r)
+        if (o.n_changed[r & 63] == 0) {
+          rounds = r + 1;
+          break;
+        }
+      *c->h_prm = o;
+      c->round_hint = rounds;
+      fill_stats(c, pd.plan, rounds);
+      pop();
+      return YDC_OK;
+    }
+  }
+  // Not final in the pipeline (or never enqueued): nothing of this batch — nor of the one behind
+  // it — has taken effect. Drain, clear the latch, place it the synchronous way; the batch
+  // behind it is replayed when it is waited for.
+  ++c->pipeline_misses;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->pipeline_broken, 0, 4, c->stream));
+  if (c->pend_count == 2) c->pend[c->pend_head ^ 1].rerun = true;
+  const ydc_task_soa tk = pd.tk;
+  const uint32_t n = pd.n, flags = pd.flags;
+  uint32_t* oi = pd.out_idx;
+  double* ou = pd.out_util;
+  uint32_t* orun = pd.out_running;
+  pop();
+  return ydc_dispatch_device(c, &tk, n, flags, oi, ou, orun);
 }
 
 int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
