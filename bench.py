@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--shared-ip-frac", type=float, default=0.0,
                     help="fraction of servants that share a host with an earlier one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--digests", type=int, default=0,
+                    help="number of distinct compiler digests in the pool instead of the configuration's "
+                         "(e.g. 150: every servant advertises its own few, ~one servant class per servant)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one synchronous ydc_dispatch_device call per step instead of two batches in flight")
     ap.add_argument("--transport", choices=("auto", "rccl", "ipc", "ipc-host"), default="auto",
@@ -232,6 +235,7 @@ def main():
     # Strong: the config's own batch and pool. Either way rank r owns the r-th range of the
     # batch (arrival order).
     n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[args.config]
+    n_envs = args.digests or n_envs
     mult = world if args.scaling == "weak" else 1
     n_all = n_cfg * mult
     sv = synth.make_servants(s_cfg * mult, n_tasks_hint=n_all, n_envs=n_envs, seed=42,
@@ -500,8 +504,9 @@ def main():
                                     "ms_per_step_synchronous = one batch at a time)" if pipelined else ""),
             "pipeline_depth": 2 if pipelined else 1,
             "ms_per_step_synchronous": sync_ms,
-            "config": {"workload": "%s%s: %s%s, %d classes" % (
-                           args.config, "" if world == 1 else " (%s scaling)" % args.scaling, shape,
+            "config": {"workload": "%s%s%s: %s%s, %d classes" % (
+                           args.config, " with %d digests" % args.digests if args.digests else "",
+                           "" if world == 1 else " (%s scaling)" % args.scaling, shape,
                            ", %.0f %% of the servants on shared hosts" % (100 * args.shared_ip_frac)
                            if args.shared_ip_frac else "", st["n_classes"]),
                        "parallelism": "1 GPU" if world == 1 else

@@ -364,6 +364,33 @@ def test_many_classes_paths(ctx):
     assert st["n_classes"] > 256
 
 
+@pytest.mark.parametrize("wide", [1, 0])
+def test_more_than_256_classes(wide, monkeypatch):
+    """Pools whose machines advertise individual compiler sets (the reference has no limit on
+    (environment set, version) combinations, task_dispatcher.h:93-94, .cc:316-344): 150 digests,
+    about one class per servant. wide=1: one wave per chunk with the class states in LDS
+    (k_sim_wide); wide=0: the thread-per-chunk kernel. Plain, with traffic from the servants'
+    own hosts on shared hosts (holes, `self` resolved at replay time), and oversubscribed."""
+    monkeypatch.setenv("YDC_WIDE", str(wide))
+    c = binding.Context(device=0)
+    try:
+        n = 30_000 if wide else 6_000
+        sv, tk = cases.random_case(seed=37, n_tasks=n, n_servants=1200, n_envs=150,
+                                   unknown_env_frac=0.002, self_frac=0.1)
+        st = check(c, sv, tk)
+        assert 256 < st["n_classes"] <= 4096
+        sv, tk = cases.random_case(seed=38, n_tasks=n // 3, n_servants=700, n_envs=150,
+                                   shared_ip_frac=0.3, self_frac=0.5)
+        st = check(c, sv, tk, "scan")
+        assert st["n_classes"] > 256
+        sv, tk = cases.random_case(seed=39, n_tasks=n, n_servants=900, n_envs=100,
+                                   oversubscribed=True, self_frac=0.2)
+        st = check(c, sv, tk)
+        assert st["n_classes"] > 256 and st["timeouts"] > 100
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
 def test_ragged_batch_sizes(ctx, n):
     """Batches that are not a multiple of the 64-request block / of the chunk size."""

@@ -89,7 +89,7 @@ def test_native_scheduler_harness():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tests", "native", "harness_test")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "native"], cwd=root)
+    # (always through make: a binary built against an older gpu_task_dispatcher.h must not survive)
+    subprocess.check_call(["make", "-s", "tests/native/harness_test"], cwd=root)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "HARNESS-OK" in out.stdout, (out.stdout, out.stderr)

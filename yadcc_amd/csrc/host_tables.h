@@ -32,7 +32,7 @@ struct HostTables {
   std::vector<uint32_t> ip_servant;
   bool any_shared_ip = false;       // some host runs more than one servant
   // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
-  // class versions and <= 256 classes: ver_sorted = the distinct class versions ascending,
+  // class versions (and a table of at most 2^20 words): ver_sorted = the distinct class versions ascending,
   // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` (one of
   // the 64 * env_words bit numbers) whose version is >= ver_sorted[vi] (vi == V: none). A
   // request (env, min_version) looks up vi = number of entries of ver_sorted below
@@ -116,7 +116,9 @@ struct HostTables {
     ver_sorted.erase(std::unique(ver_sorted.begin(), ver_sorted.end()), ver_sorted.end());
     env_ver_mask.clear();
     const uint32_t C = (uint32_t)cls_ver.size(), V = (uint32_t)ver_sorted.size();
-    if (C && C <= 256 && V <= 16) {
+    // (built while it stays small: a few MB at most — 150 digests x 3 thresholds x 2000 classes
+    // are 150 KB; registries beyond that classify with the loop over the classes)
+    if (C && V <= 16 && (size_t)64 * EW * (V + 1) * ((C + 63) / 64) <= ((size_t)1 << 20)) {
       const uint32_t words = (C + 63) / 64;
       env_ver_mask.assign((size_t)64 * EW * (V + 1) * words, 0);
       for (uint32_t c = 0; c < C; ++c)

@@ -1538,5 +1538,6 @@ __global__ __launch_bounds__(256) void k_apply_tick(const uint32_t* idx, const S
 
 #include "bin_sort.h"
 #include "match_kernel.h"
+#include "wide_kernel.h"
 
 #endif  // YADCC_AMD_KERNELS_H_

@@ -599,6 +599,29 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
   // winners are mostly the same lane and the pairing only costs.
   const uint32_t pair_mode = (flags & 4u) && steps >= 3 ? 1u : 0u;
 
+  // The first block's requests do not depend on the start state: fetched now, behind the loads
+  // of the level guesses (pass 0 with own guesses, one mask word per request).
+  bool pre_staged = false;
+  uint64_t pre_m = 0;
+  uint32_t pre_slo = kNone, pre_shi = kNone;
+  if (own_guess && W == 1 && T.words == 1) {
+    const uint32_t c_t0 = kc * chunk_size, c_t1 = min(n_tasks, c_t0 + chunk_size);
+    const uint32_t tl = (warm_mode && kc > 0 ? c_t0 - B.warm_len : c_t0) + lane;
+    if (tl < c_t1) {
+      pre_m = T.mask[tl];
+      pre_slo = T.self_lo[tl];
+      pre_shi = T.self_hi[tl];
+      if (pre_shi == kSelfServant) {  // (own servant by index, bin_sort.h: its slot range)
+        const uint32_t b = shared.slot_base[pre_slo], e = shared.slot_base[pre_slo + 1];
+        pre_slo = e > b ? b : kNone;
+        pre_shi = e > b ? e : kNone;
+      }
+    }
+    pre_staged = true;
+  }
+  bool rings_from_windows = false;  // the level table's windows filled the rings already
+  uint32_t win_filled = 0;          // (this lane's class: list entries [.., win_filled) are in its ring)
+
   // ---- start state; is there anything to do? ----
   ClassState next_guess{};  // pass 0 with own guesses: the level guess of the next chunk
   if (own_guess) {
@@ -648,14 +671,36 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         for (int h = 0; h < 2; ++h)
           pos[h] = lvl[h] < n_slots_all ? B.level_tab[(size_t)(lvl[h] >> 6) * C + lane] : endc;
       }
-      uint32_t v[16];
+      // <= 4 classes: the window of this chunk's own level is read with the slots beside the
+      // ranks and two more windows behind it — the 192 list entries the rings start with, so the
+      // rings need no round trip of their own (init_rings).
+      const bool fill = C <= 4 && L.stride == 2 && (C << rshift) <= ring_total && (1u << rshift) >= 256;
+      uint32_t v[16], fr[8], fg[8], g0[4];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const uint32_t c = (uint32_t)q >> 1;
         v[q] = 0xFFFFFFFFu;  // "not below the level"
+        if (q < 8) {
+          fr[q] = 0u;  // (ring sentinels: ~rank 0 = no slot)
+          fg[q] = kNone;
+          if (q < 4) g0[q] = kNone;
+        }
         if (c < C) {
           const uint32_t at = readlane_u32(pos[q & 1], c) + lane, e = readlane_u32(endc, c);
-          if (at < e) v[q] = list_rank(L, at);
+          if (at < e) {
+            v[q] = list_rank(L, at);
+            if (fill && !(q & 1)) g0[c] = list_slot(L, at);
+          }
+          if (fill && !(q & 1)) {
+#pragma unroll
+            for (int part = 1; part < 3; ++part) {
+              const uint32_t a2 = at + 64 * part;
+              if (a2 < e) {
+                fr[2 * c + part - 1] = ~list_rank(L, a2);
+                fg[2 * c + part - 1] = list_slot(L, a2);
+              }
+            }
+          }
         }
       }
 #pragma unroll
@@ -672,6 +717,25 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
       }
       if (lane < C) next_guess.hown_lo = next_guess.hown_hi = kNone;
+      if (fill) {
+        // (ring positions are list positions modulo the ring size: entries below the cursor land
+        // in places the ring does not look at)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if ((uint32_t)c < C) {
+            const uint32_t p0 = readlane_u32(pos[0], c) + lane;
+            w.ring_p[w.at(c, p0)] = v[2 * c] == 0xFFFFFFFFu ? 0u : ~v[2 * c];
+            w.ring_g[w.at(c, p0)] = g0[c];
+#pragma unroll
+            for (int part = 1; part < 3; ++part) {
+              w.ring_p[w.at(c, p0 + 64 * part)] = fr[2 * c + part - 1];
+              w.ring_g[w.at(c, p0 + 64 * part)] = fg[2 * c + part - 1];
+            }
+          }
+        }
+        rings_from_windows = true;
+        win_filled = pos[0] + 192;
+      }
     } else if (L.list_p && C <= 4) {
       // A handful of classes: the wave searches together, 64 probes per search and round
       // (three rounds for a list of 2^18 entries instead of eighteen dependent loads), the
@@ -728,6 +792,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       }
     }
     w.set_state(0, st, lane, C);
+    if (rings_from_windows && lane < C) w.k[0].filled = win_filled;
   } else {
     const ClassState* start;
     if (pass == 0) {
@@ -839,6 +904,12 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
     auto stage = [&](uint32_t tb) {
       const uint32_t tl = tb + lane;
       nx_slo = nx_shi = kNone;
+      if (pre_staged) {  // (the chunk's first block, fetched before the level guesses)
+        pre_staged = false;
+        nx_m[0] = pre_m;
+        nx_slo = pre_slo;
+        nx_shi = pre_shi;
+      } else {
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         nx_m[j] = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
@@ -848,6 +919,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       if (tl < t1) {
         nx_slo = T.self_lo[tl];
         nx_shi = T.self_hi[tl];
+      }
+      }
+      if (tl < t1) {
         if (nx_shi == kSelfServant) {
           // The request's own servant by index (bin_sort.h): its slot range, if it offers any.
           const uint32_t b = shared.slot_base[nx_slo], e = shared.slot_base[nx_slo + 1];
@@ -899,8 +973,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
       stage(warm_blk ? t0 : tb + 64);
 
       if (!ring_ready) {
-        // First block that really runs: fill the rings.
-        w.init_rings(C, init_fill, W);
+        // First block that really runs: fill the rings (unless the level table's windows did).
+        if (!rings_from_windows) w.init_rings(C, init_fill, W);
+        rings_from_windows = false;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < W; ++j) {

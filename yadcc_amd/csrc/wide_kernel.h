@@ -1,0 +1,248 @@
+// wide_kernel.h — k_sim_wide: the chunk replay for registries with MANY servant classes
+// (more than kMaxWaveClasses = 256 distinct (environment set, version) signatures — a pool whose
+// machines advertise individual compiler sets has about one class per servant; the reference
+// has no limit, task_dispatcher.h:93-94, .cc:316-344).
+//
+// Same protocol as the thread-per-chunk k_sim_generic it replaces up to kMaxWideClasses (rounds
+// of replay + k_update, checked by the host; results identical): one WAVE per chunk, lane l owns
+// the classes l, l + 64, l + 128, ... and the whole class state lives in LDS as arrays
+// (structure-of-arrays: a lane's reads of one field for consecutive classes hit consecutive
+// banks). A request scans its eligible classes' head ranks — one LDS read per eligible class and
+// lane, the request's class mask words are wave-uniform scalars —, the wave takes the minimum,
+// and the winning lane advances its class from LDS (head <- next) while the list entry after
+// next is fetched from memory behind the following requests (one pending fetch per lane, stored
+// the next time that lane wins). Requests from a servant's own host and classes with holes take
+// the general step, which runs the shared state machine of dispatch_core.h on the LDS state.
+#ifndef YADCC_AMD_WIDE_KERNEL_H_
+#define YADCC_AMD_WIDE_KERNEL_H_
+
+#include "kernels.h"
+
+namespace ydc {
+
+constexpr uint32_t kMaxWideClasses = 4096;  // 36 B of LDS per class: 144 KB of a CU's 160 KB
+constexpr uint32_t kWideFields = 9;
+
+struct WideState {
+  uint32_t *cur, *lo, *hlo, *hhi, *end, *hp, *hg, *np, *ng;
+  __device__ __forceinline__ ClassRun run(const ClassLists& L, uint32_t c) const {
+    ClassRun r;
+    r.cursor = cur[c];
+    r.lo = lo[c];
+    r.hown_lo = hlo[c];
+    r.hown_hi = hhi[c];
+    r.end = end[c];
+    r.head_p = hp[c];
+    r.head_g = hg[c];
+    r.single = L.cls_single ? L.cls_single[c] : 0u;
+    return r;
+  }
+};
+
+__global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint32_t n_tasks,
+                                                 uint32_t chunk_size, uint32_t n_chunks,
+                                                 const ClassState* __restrict__ guess,
+                                                 ClassState* __restrict__ endst, uint8_t* dirty,
+                                                 uint32_t* __restrict__ slot_of, SharedIpTable shared,
+                                                 uint32_t round, DeviceParams* prm) {
+  extern __shared__ uint32_t wsm[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
+  const uint32_t k = blockIdx.x;
+  if (k >= n_chunks || !dirty[k]) return;
+  const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
+  WideState S{wsm,         wsm + C,     wsm + 2 * C, wsm + 3 * C, wsm + 4 * C,
+              wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C};
+  const ClassState* start = guess + (size_t)k * C;
+  // ---- start state (clamped like class_run_init: speculative states may be anything)
+  for (uint32_t c = lane; c < C; c += 64) {
+    const ClassState st = start[c];
+    const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
+    uint32_t cur = st.cursor, lo = st.lo;
+    cur = cur < b ? b : (cur > e ? e : cur);
+    lo = lo < b ? b : (lo > cur ? cur : lo);
+    S.cur[c] = cur;
+    S.lo[c] = lo;
+    S.hlo[c] = st.hown_lo;
+    S.hhi[c] = st.hown_hi;
+    S.end[c] = e;
+  }
+  uint32_t my_holes = 0;  // classes of this lane that have holes
+  for (uint32_t c = lane; c < C; c += 64) {
+    const uint32_t cur = S.cur[c], e = S.end[c];
+    S.hp[c] = cur < e ? list_rank(L, cur) : kNone;
+    S.hg[c] = cur < e ? list_slot(L, cur) : kNone;
+    S.np[c] = cur + 1 < e ? list_rank(L, cur + 1) : kNone;
+    S.ng[c] = cur + 1 < e ? list_slot(L, cur + 1) : kNone;
+    my_holes += S.lo[c] < cur ? 1u : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+  bool any_holes = __ballot(my_holes != 0) != 0;
+  // One fetch of "the entry after next" in flight per lane.
+  uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
+  bool pend_on = false;
+  auto flush = [&]() {
+    if (pend_on) {
+      S.np[pend_c] = pend_p;
+      S.ng[pend_c] = pend_g;
+      pend_on = false;
+    }
+  };
+
+  const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
+  for (uint32_t tb = t0; tb < t1; tb += 64) {
+    // this block's own-servant ranges: lane i holds request tb + i
+    const uint32_t tl = tb + lane;
+    const uint32_t slo_v = tl < t1 ? T.self_lo[tl] : kNone, shi_v = tl < t1 ? T.self_hi[tl] : kNone;
+    const uint32_t cnt = min(64u, t1 - tb);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t t = tb + i;
+      const uint64_t* __restrict__ mask = T.mask + (size_t)t * W;
+      uint32_t self_lo = readlane_u32(slo_v, i), self_hi = readlane_u32(shi_v, i);
+      bool general = any_holes || self_hi == kSelfShared;
+      uint32_t best = kNone, bw = 0;
+      uint64_t many = 0;
+      if (!general) {
+        bool own = false;
+        for (uint32_t w = 0; w < W; ++w) {
+          const uint64_t m = mask[w];  // wave-uniform
+          many |= m;
+          if ((m >> lane) & 1u) {
+            const uint32_t c = w * 64 + lane;
+            const uint32_t v = S.hp[c];
+            if (self_lo != kNone && S.hg[c] - self_lo < self_hi - self_lo) own = true;
+            if (v < best) {
+              best = v;
+              bw = w;
+            }
+          }
+        }
+        if (many == 0) {
+          if (lane == 0) slot_of[t] = kIdxEnvNotFound;  // task_dispatcher.cc:105-108
+          continue;
+        }
+        // An eligible class shows a slot of the requestor's own servant at its head (it has to be
+        // stepped over), or nothing is left but possibly the own servant: the general step.
+        const uint32_t mn = wave_min_u32(best);
+        if (__ballot(own) != 0 || (mn == kNone && self_lo != kNone)) {
+          general = true;
+        } else if (mn == kNone) {
+          if (lane == 0) slot_of[t] = kIdxTimeout;  // :116-118 with timeout == now
+          continue;
+        } else {
+          if (best == mn) {  // ranks are unique: exactly one lane
+            const uint32_t c = bw * 64 + lane;
+            slot_of[t] = S.hg[c];
+            flush();
+            const uint32_t cur = S.cur[c] + 1;
+            S.cur[c] = cur;
+            S.lo[c] = cur;  // (no holes anywhere on this path)
+            S.hp[c] = S.np[c];
+            S.hg[c] = S.ng[c];
+            if (cur + 1 < S.end[c]) {
+              pend_c = c;
+              pend_p = list_rank(L, cur + 1);
+              pend_g = list_slot(L, cur + 1);
+              pend_on = true;
+            } else {
+              S.np[c] = kNone;
+              S.ng[c] = kNone;
+            }
+          }
+          continue;
+        }
+      }
+      // ---- general step (dispatch_core.h's state machine on the LDS state)
+      flush();
+      __builtin_amdgcn_wave_barrier();
+      many = 0;
+      for (uint32_t w = 0; w < W; ++w) many |= mask[w];
+      if (many == 0) {
+        if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+        continue;
+      }
+      if (self_hi == kSelfShared) {
+        auto state_of = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
+          cursor = S.cur[c];
+          lo = S.lo[c];
+          hown_lo = S.hlo[c];
+        };
+        resolve_shared_self(mask, self_lo, &shared, state_of, self_lo, self_hi);
+      }
+      uint32_t bp = kNone, bi = 0, bg = 0, bc = kNone;
+      for (uint32_t w = 0; w < W; ++w) {
+        if ((mask[w] >> lane) & 1u) {
+          const uint32_t c = w * 64 + lane;
+          uint32_t ci, cp, cg;
+          if (class_candidate(L, S.run(L, c), self_lo, self_hi, ci, cp, cg) && cp < bp) {
+            bp = cp;
+            bi = ci;
+            bg = cg;
+            bc = c;
+          }
+        }
+      }
+      const uint32_t mn = wave_min_u32(bp);
+      bool win = mn != kNone && bp == mn;
+      if (mn == kNone) {
+        // task_dispatcher.cc:392-396: the requestor's own servant, first eligible class that has it
+        uint32_t sc = kNone;
+        if (self_lo != kNone) {
+          for (uint32_t w = 0; w < W && sc == kNone; ++w) {
+            if ((mask[w] >> lane) & 1u) {
+              const uint32_t c = w * 64 + lane;
+              uint32_t ci, cg;
+              if (class_self_candidate(L, S.run(L, c), self_lo, self_hi, ci, cg)) {
+                sc = c;
+                bi = ci;
+                bg = cg;
+                bc = c;
+              }
+            }
+          }
+        }
+        const uint32_t first = wave_min_u32(sc);
+        if (first == kNone) {
+          if (lane == 0) slot_of[t] = kIdxTimeout;
+          continue;
+        }
+        win = sc == first;
+      }
+      if (win) {
+        slot_of[t] = bg;
+        ClassRun r = S.run(L, bc);
+        const bool had = r.lo < r.cursor;
+        class_consume(L, r, bi, self_lo, self_hi);
+        S.cur[bc] = r.cursor;
+        S.lo[bc] = r.lo;
+        S.hlo[bc] = r.hown_lo;
+        S.hhi[bc] = r.hown_hi;
+        S.hp[bc] = r.head_p;
+        S.hg[bc] = r.head_g;
+        S.np[bc] = r.cursor + 1 < r.end ? list_rank(L, r.cursor + 1) : kNone;
+        S.ng[bc] = r.cursor + 1 < r.end ? list_slot(L, r.cursor + 1) : kNone;
+        const bool has = r.lo < r.cursor;
+        my_holes += (has ? 1u : 0u) - (had ? 1u : 0u);
+      }
+      __builtin_amdgcn_wave_barrier();
+      any_holes = __ballot(my_holes != 0) != 0;
+    }
+  }
+  flush();
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t c = lane; c < C; c += 64) {
+    ClassState s;
+    s.cursor = S.cur[c];
+    s.lo = S.lo[c];
+    const bool holes = s.lo < s.cursor;
+    s.hown_lo = holes ? S.hlo[c] : kNone;
+    s.hown_hi = holes ? S.hhi[c] : kNone;
+    endst[(size_t)k * C + c] = s;
+  }
+  if (lane == 0) {
+    dirty[k] = 0;
+    atomicAdd(&prm->chunk_sims, 1u);
+  }
+}
+
+}  // namespace ydc
+#endif  // YADCC_AMD_WIDE_KERNEL_H_

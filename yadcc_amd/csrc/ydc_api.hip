@@ -284,6 +284,7 @@ struct ydc_context {
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  bool opt_wide = true;  // > 256 classes: wave-per-chunk replay (YDC_WIDE=0: thread per chunk)
   bool opt_level_tab = true;  // bin sort leaves a level table for pass 0's guesses (YDC_LEVEL_TAB=0: search)
   // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
   // request columns read in place through the mapped pointer (YDC_HOST_IN=map) or copied by DMA
@@ -607,6 +608,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
   if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
+  if (const char* s = getenv("YDC_WIDE")) c->opt_wide = atoi(s) != 0;
   if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
   if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
@@ -1057,7 +1059,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
       HIP_TRY(c, hipMemsetAsync(c->d_claim.p, 0, c->d_claim.cap * 8, c->stream));
     }
   }
-  if (p.use_generic) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
+  if (p.use_generic && !(C <= kMaxWideClasses && c->opt_wide)) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
 
   p.sv = ServantTable{c->d_version.p, c->d_nproc.p,  c->d_load.p,     c->d_max_tasks.p,
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
@@ -1624,9 +1626,19 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
       for (;;) {
         for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
           ClassState* gold = c->d_guess[0].p;
-          YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
-                     p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
-                     p.shared, rounds, prm);
+          if (p.C <= kMaxWideClasses && c->opt_wide) {
+            // One wave per chunk, the class states in LDS (wide_kernel.h); above 64 KB of
+            // dynamic LDS the runtime wants to be told.
+            HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)kWideFields * kMaxWideClasses * 4)));
+            YDC_LAUNCH(c, "k_sim_wide", k_sim_wide, dim3(p.K), dim3(64), (size_t)kWideFields * p.C * 4, st,
+                       p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared,
+                       rounds, prm);
+          } else {
+            YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
+                       p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
+                       p.shared, rounds, prm);
+          }
           YDC_LAUNCH(c, "k_update", k_update, dim3(std::max(1u, ceil_div(p.K * p.C, 256))), dim3(256),
                      0, st, p.C, p.K, c->d_endst.p, gold, c->d_dirty.p, rounds, prm);
           ++rounds;

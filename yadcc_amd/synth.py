@@ -106,10 +106,13 @@ CONFIGS = {
 }
 
 
-def make_config(name, oversubscribed=False, n_tasks=None, n_servants=None, **kw):
+def make_config(name, oversubscribed=False, n_tasks=None, n_servants=None, n_envs=None, **kw):
+    """n_envs: another number of compiler digests than the configuration's own (> 64: every
+    servant advertises its own handful of them — about one servant class per servant)."""
     n, s, e, unk = CONFIGS[name]
     n = n_tasks or n
     s = n_servants or s
+    e = n_envs or e
     hint = n if name != "cfg5" else 100_000
     sv = make_servants(s, n_tasks_hint=hint, n_envs=e, oversubscribed=oversubscribed,
                        **{k: v for k, v in kw.items() if k in ("seed", "disjoint_envs",
