@@ -9,6 +9,7 @@
 // library never links this file.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -214,6 +215,36 @@ int model_dispatch_alias(uint32_t S, const uint32_t* version, const uint32_t* np
       // update (same rule as k_update): the start guess of chunk k+1 becomes the
       // end state chunk k reached in its latest simulation.
       bool any = false;
+      static const char* prefix_env = getenv("YDC_MODEL_PREFIX");
+      const bool prefix_rule = prefix_env && atoi(prefix_env) != 0;
+      if (prefix_rule) {
+        // k_update_prefix: chunk k+1's cursor guess = true start + the sum of what the chunks
+        // before it consumed in their latest replays (exact where the chain is consistent).
+        std::vector<uint32_t> acc(C), from(C);  // from: the cursor chunk k was replayed from
+        for (uint32_t c = 0; c < C; ++c) acc[c] = from[c] = guess[c].cursor;
+        for (uint32_t k = 0; k + 1 < K; ++k) {
+          for (uint32_t c = 0; c < C; ++c) {
+            const ClassState& en = endst[(size_t)k * C + c];
+            ClassState& g = guess[(size_t)(k + 1) * C + c];
+            if (!class_state_equal(g, en)) any = true;  // (consistency is judged on the old guesses)
+            acc[c] += en.cursor - from[c];
+            from[c] = g.cursor;  // (before it is overwritten below)
+            const uint32_t e = cls_begin[c + 1];
+            const uint32_t cur = acc[c] > e ? e : acc[c];
+            ClassState ng;
+            if (cur == en.cursor) {
+              ng = en;
+            } else {
+              ng.cursor = ng.lo = cur;
+              ng.hown_lo = ng.hown_hi = kNone;
+            }
+            if (!class_state_equal(g, ng)) {
+              g = ng;
+              dirty[k + 1] = 1;
+            }
+          }
+        }
+      } else
       for (uint32_t k = 0; k + 1 < K; ++k) {
         for (uint32_t c = 0; c < C; ++c) {
           const ClassState& en = endst[(size_t)k * C + c];

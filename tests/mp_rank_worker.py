@@ -38,6 +38,7 @@ def main():
     spec = json.load(open(sys.argv[4]))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
+    os.environ.update(spec.get("env", {}))  # (options the library reads when a context is created)
     from tests import cases
     from yadcc_amd import binding, pack, synth
     DA = binding.DeviceArray

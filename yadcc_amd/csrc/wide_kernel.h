@@ -39,17 +39,32 @@ struct WideState {
   }
 };
 
+// walk != 0 (launched with ONE workgroup): the speculation is not converging — pools of many
+// small classes with sparse eligibility have no "level" the guesses could start from, and a
+// correction then travels one chunk per round. The wave takes the first chunk whose start guess
+// changed (everything before it is final: its guess IS its predecessor's final end state) and
+// walks from there to the end of the batch with the state in LDS, leaving guesses and end
+// states consistent behind it; the next k_update finds nothing to change.
 __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                  uint32_t chunk_size, uint32_t n_chunks,
-                                                 const ClassState* __restrict__ guess,
+                                                 ClassState* __restrict__ guess,
                                                  ClassState* __restrict__ endst, uint8_t* dirty,
                                                  uint32_t* __restrict__ slot_of, SharedIpTable shared,
-                                                 uint32_t round, DeviceParams* prm) {
+                                                 uint32_t round, DeviceParams* prm, uint32_t walk) {
   extern __shared__ uint32_t wsm[];
   if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
-  const uint32_t k = blockIdx.x;
-  if (k >= n_chunks || !dirty[k]) return;
+  uint32_t k = blockIdx.x;
   const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
+  if (walk) {
+    k = n_chunks;
+    for (uint32_t base = 0; base < n_chunks && k == n_chunks; base += 64) {
+      const uint64_t m = __ballot(base + lane < n_chunks && dirty[base + lane] != 0);
+      if (m) k = base + (uint32_t)__builtin_ctzll(m);
+    }
+    if (k >= n_chunks) return;
+  } else if (k >= n_chunks || !dirty[k]) {
+    return;
+  }
   WideState S{wsm,         wsm + C,     wsm + 2 * C, wsm + 3 * C, wsm + 4 * C,
               wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C};
   const ClassState* start = guess + (size_t)k * C;
@@ -88,6 +103,7 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
     }
   };
 
+  for (;;) {  // chunk k (and, walking, every chunk behind it)
   const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
   for (uint32_t tb = t0; tb < t1; tb += 64) {
     // this block's own-servant ranges: lane i holds request tb + i
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
   }
   flush();
   __builtin_amdgcn_wave_barrier();
+  const bool more = walk && k + 1 < n_chunks;
   for (uint32_t c = lane; c < C; c += 64) {
     ClassState s;
     s.cursor = S.cur[c];
@@ -237,10 +254,14 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
     s.hown_lo = holes ? S.hlo[c] : kNone;
     s.hown_hi = holes ? S.hhi[c] : kNone;
     endst[(size_t)k * C + c] = s;
+    if (more) guess[(size_t)(k + 1) * C + c] = s;  // (what chunk k + 1 is replayed from, right now)
   }
   if (lane == 0) {
     dirty[k] = 0;
     atomicAdd(&prm->chunk_sims, 1u);
+  }
+  if (!more) break;
+  ++k;
   }
 }
 

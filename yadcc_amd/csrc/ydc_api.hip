@@ -284,6 +284,7 @@ struct ydc_context {
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
   bool opt_wide = true;  // > 256 classes: wave-per-chunk replay (YDC_WIDE=0: thread per chunk)
   bool opt_level_tab = true;  // bin sort leaves a level table for pass 0's guesses (YDC_LEVEL_TAB=0: search)
   // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
@@ -609,6 +610,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
   if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
   if (const char* s = getenv("YDC_WIDE")) c->opt_wide = atoi(s) != 0;
+  if (const char* s = getenv("YDC_GROUP_BINSORT")) c->opt_group_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
   if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
   if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
@@ -1622,18 +1624,23 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
     c->round_hint = rounds;
   } else {
     if (N && p.C && p.use_generic) {
-      // > kMaxWaveClasses classes: thread-per-chunk kernel, host-checked rounds.
+      // > kMaxWaveClasses classes: replay kernel + k_update per round, host-checked.
+      const bool wide = p.C <= kMaxWideClasses && c->opt_wide;
+      if (wide)  // (above 64 KB of dynamic LDS the runtime wants to be told)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((size_t)kWideFields * kMaxWideClasses * 4)));
+      uint32_t last_changed = 0xFFFFFFFFu;
+      bool walked = false;
       for (;;) {
         for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
           ClassState* gold = c->d_guess[0].p;
-          if (p.C <= kMaxWideClasses && c->opt_wide) {
-            // One wave per chunk, the class states in LDS (wide_kernel.h); above 64 KB of
-            // dynamic LDS the runtime wants to be told.
-            HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((size_t)kWideFields * kMaxWideClasses * 4)));
-            YDC_LAUNCH(c, "k_sim_wide", k_sim_wide, dim3(p.K), dim3(64), (size_t)kWideFields * p.C * 4, st,
-                       p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared,
-                       rounds, prm);
+          if (wide) {
+            // One wave per chunk, the class states in LDS (wide_kernel.h) — or, once the rounds
+            // have stopped making headway, one wave that walks the rest of the batch.
+            const bool walk = walked;
+            YDC_LAUNCH(c, walk ? "k_sim_wide(walk)" : "k_sim_wide", k_sim_wide, dim3(walk ? 1u : p.K), dim3(64),
+                       (size_t)kWideFields * p.C * 4, st, p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p,
+                       c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm, walk ? 1u : 0u);
           } else {
             YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
                        p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
@@ -1647,7 +1654,13 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
         HIP_TRY(c, hipStreamSynchronize(st));
         if (c->h_prm->overflow)
           return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
-        if (c->h_prm->n_changed[(rounds - 1) & 63] == 0) break;
+        const uint32_t changed = c->h_prm->n_changed[(rounds - 1) & 63];
+        if (changed == 0) break;
+        if (walked) return fail(c, YDC_ERR_NOT_CONVERGED, "the walk left %u inconsistent states", changed);
+        // Guesses that are still changing almost as much as a check ago: corrections are
+        // travelling chunk by chunk. Stop speculating.
+        if (wide && rounds >= 4 && changed > last_changed / 4 * 3) walked = true;
+        last_changed = changed;
         if (rounds > p.K + 4)
           return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", rounds);
       }
@@ -2491,8 +2504,11 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   // too small (window_miss, the same verdict on every rank) — runs with the full sort on
   // every rank. YDC_SHARD_SORT=0 switches it off.
   // (Decided from the registry alone — every rank must take the same branch, whatever its slice.)
+  // A registry small enough for the bin sort is ordered whole on every rank (two launches, no
+  // exchange) — cheaper than the key-count / window / radix sequence until the slot count is in
+  // the millions; the windows are for the registries the bin sort does not take.
   bool windowed = G > 1 && c->opt_shard_sort && c->kf.exact && P == 1 && !p.use_generic && C >= 2 &&
-                  !p.any_shared;
+                  !p.any_shared && !(full_plan.binsort && c->opt_group_binsort);
   BatchPlan win_plan;
   if (windowed)
     if (int rc = plan_batch(c, N, &win_plan, true)) return rc;
