@@ -360,6 +360,8 @@ def main():
     d_run2 = DA(n_serv, np.uint32, local_rank) if pipelined else None
 
     def run_steps(k):
+        if k <= 0:
+            return
         if not pipelined:
             for _ in range(k):
                 step()

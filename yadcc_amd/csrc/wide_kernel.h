@@ -20,8 +20,13 @@
 
 namespace ydc {
 
-constexpr uint32_t kMaxWideClasses = 4096;  // 36 B of LDS per class: 144 KB of a CU's 160 KB
+constexpr uint32_t kMaxWideClasses = 3072;  // 36 B of class state + 8 B of staged mask words per class
 constexpr uint32_t kWideFields = 9;
+// Dynamic LDS of k_sim_wide for C classes: the nine state arrays + the class masks of a block of
+// 64 requests (64 x ceil(C / 64) 64-bit words).
+__host__ __device__ inline size_t wide_lds_bytes(uint32_t C) {
+  return (size_t)kWideFields * C * 4 + 8 + (size_t)64 * ((C + 63) / 64) * 8;
+}
 
 struct WideState {
   uint32_t *cur, *lo, *hlo, *hhi, *end, *hp, *hg, *np, *ng;
@@ -67,6 +72,9 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
   }
   WideState S{wsm,         wsm + C,     wsm + 2 * C, wsm + 3 * C, wsm + 4 * C,
               wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C};
+  // The class masks of the current block of 64 requests, staged with coalesced loads: a
+  // request's W words are then wave-uniform LDS reads instead of W memory round trips.
+  uint64_t* const bmask = (uint64_t*)(wsm + (size_t)kWideFields * C + ((kWideFields * C) & 1u));
   const ClassState* start = guess + (size_t)k * C;
   // ---- start state (clamped like class_run_init: speculative states may be anything)
   for (uint32_t c = lane; c < C; c += 64) {
@@ -110,9 +118,12 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
     const uint32_t tl = tb + lane;
     const uint32_t slo_v = tl < t1 ? T.self_lo[tl] : kNone, shi_v = tl < t1 ? T.self_hi[tl] : kNone;
     const uint32_t cnt = min(64u, t1 - tb);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < cnt * W; j += 64) bmask[j] = T.mask[(size_t)tb * W + j];
+    __builtin_amdgcn_wave_barrier();
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t t = tb + i;
-      const uint64_t* __restrict__ mask = T.mask + (size_t)t * W;
+      const uint64_t* mask = bmask + (size_t)i * W;
       uint32_t self_lo = readlane_u32(slo_v, i), self_hi = readlane_u32(shi_v, i);
       bool general = any_holes || self_hi == kSelfShared;
       uint32_t best = kNone, bw = 0;

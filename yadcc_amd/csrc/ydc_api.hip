@@ -1628,7 +1628,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
       const bool wide = p.C <= kMaxWideClasses && c->opt_wide;
       if (wide)  // (above 64 KB of dynamic LDS the runtime wants to be told)
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((size_t)kWideFields * kMaxWideClasses * 4)));
+                                       (int)wide_lds_bytes(kMaxWideClasses)));
       uint32_t last_changed = 0xFFFFFFFFu;
       bool walked = false;
       for (;;) {
@@ -1639,7 +1639,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
             // have stopped making headway, one wave that walks the rest of the batch.
             const bool walk = walked;
             YDC_LAUNCH(c, walk ? "k_sim_wide(walk)" : "k_sim_wide", k_sim_wide, dim3(walk ? 1u : p.K), dim3(64),
-                       (size_t)kWideFields * p.C * 4, st, p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p,
+                       wide_lds_bytes(p.C), st, p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p,
                        c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm, walk ? 1u : 0u);
           } else {
             YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
