@@ -1,11 +1,11 @@
 #!/bin/bash
 # Copies the evidence tools/gpu_round_final.sh left under gpurun_out/ into profiles/ (tracked).
-# Usage: tools/collect_profiles.sh r02
+# Usage: tools/collect_profiles.sh r03
 set -eu
-R=${1:?round tag, e.g. r02}
+R=${1:?round tag, e.g. r03}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-for c in cfg2 cfg2_shared cfg3 cfg4 cfg5 dist1; do
+for c in cfg2 cfg2_sync cfg2_shared cfg2_d150 cfg3 cfg4 cfg5 dist1_rccl dist1_ipc; do
   if [ -s $F/bench_$c.json ] && tail -1 $F/bench_$c.json | python -c 'import json,sys; json.loads(sys.stdin.read())' 2>/dev/null; then
     tail -1 $F/bench_$c.json > profiles/${R}_bench_$c.json
   else
@@ -18,8 +18,10 @@ for c in cfg2 cfg3; do
   cp $P/pmc_hbm.json profiles/${R}_${c}_pmc_hbm.json
   { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (separate pass), per kernel: KB per dispatch"; cat $P/pmc_fetch.txt
     echo; echo "# rocprofv3 --kernel-trace --pmc WRITE_SIZE (separate pass)"; cat $P/pmc_write.txt; } > profiles/${R}_${c}_pmc_hbm.txt
+  [ -s $F/phase_$c.txt ] && cp $F/phase_$c.txt profiles/${R}_${c}_match_phases.txt
 done
 python tools/rocprof_summary.py hbmtable "cfg2 (100k requests x 2k servants)=profiles/${R}_cfg2_pmc_hbm.json" \
   "cfg3 (1M requests x 8k servants, 4 digests)=profiles/${R}_cfg3_pmc_hbm.json" > profiles/${R}_hbm_utilisation.txt
 cp $F/td_native_bench.log profiles/${R}_td_native_bench.txt
+[ -s gpurun_out/rccl_1rank_debug.log ] && cp gpurun_out/rccl_1rank_debug.log profiles/${R}_rccl_1rank_debug.log
 git status --short profiles
