@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--digests", type=int, default=0,
                     help="number of distinct compiler digests in the pool instead of the configuration's "
                          "(e.g. 150: every servant advertises its own few, ~one servant class per servant)")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="skip the host-buffer (end_to_end) loops: what tools/profile.sh runs under rocprofv3, "
+                         "so that per-kernel averages are those of the HBM-resident batches")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one synchronous ydc_dispatch_device call per step instead of two batches in flight")
     ap.add_argument("--transport", choices=("auto", "rccl", "ipc", "ipc-host"), default="auto",
@@ -419,7 +422,7 @@ def main():
     # the host, through the host-buffer entry point ydc_dispatch (H2D of 12 B/request over
     # PCIe, kernels, D2H of 4 B/request). Reported in `end_to_end`, next to `value`.
     e2e = None
-    if not use_dist:
+    if not use_dist and not args.resident_only:
         # (columns and the result array are the caller's and stay the same from batch to batch,
         # as in a scheduler loop; allocating them per call would time numpy, not the dispatch)
         # The scheduler's buffers are page-locked once (ydc_host_alloc): ydc_dispatch then reads
