@@ -10,7 +10,7 @@ from oracle import oraclebind as O
 from tests.model import modelbind as M
 
 ALL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-FILES = [f for f in ALL if "_prefix_" not in f]  # whole small batches (inputs inside)
+FILES = [f for f in ALL if "_prefix_" not in f and "_stream_" not in f]  # whole small batches (inputs inside)
 
 
 def test_fixtures_exist():
@@ -42,3 +42,23 @@ def test_full_size_pools_prefix_matches_reference(cfg):
     head = {k: v[:len(ref)] for k, v in tk.items()}
     idx, _, _ = O.dispatch(sv, head, "sorted")
     assert np.array_equal(idx, ref)
+
+
+def test_stream_fixture_first_ticks_match_the_oracle():
+    """tests/golden/ref_cfg5_stream_200_ticks.npz (the verbatim reference replaying configs[4]'s
+    event stream): the oracle restatement, fed the same stream, reproduces the reference's
+    digests on the first ticks — what the 200-tick GPU test relies on is the stream generator and
+    the digest, both exercised here on CPU."""
+    from yadcc_amd import streaming, synth
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_cfg5_stream_200_ticks.npz"))
+    assert int(fx["ticks"]) >= 200
+    sv, _ = synth.make_config("cfg5")
+    es = streaming.EventStream(sv, 10_000, 10_000)
+    for t in range(4):
+        _, _, _, tk = es.next_tick()
+        idx, _, run = O.dispatch(es.registry_snapshot(), tk, "sorted")
+        assert synth.placement_hash(idx) == int(fx["digest"][t]), t
+        assert int((idx < O.IDX_ENV_NOT_FOUND).sum()) == int(fx["granted"][t])
+        es.commit(idx)
+        assert synth.placement_hash(es.running.astype(np.uint32)) == int(fx["run_digest"][t])
+        assert np.array_equal(run, es.running.astype(np.uint32))

@@ -184,3 +184,27 @@ def test_stream_wide_masks_env_change_and_append_inside_a_tick():
             assert (got == es.n - 1).sum() > 0  # the newcomer takes requests at once
     ctx.stream_end()
     ctx.close()
+
+
+def test_stream_cfg5_200_ticks_against_the_reference():
+    """BASELINE.json configs[4], 200 ticks (10k requests + 10k frees + 200 heartbeats each) through
+    the captured step, tick by tick against what the VERBATIM reference answered on the same
+    stream (tests/golden/ref_cfg5_stream_200_ticks.npz, generator
+    tests/golden/make_stream_golden.py: digests of every tick's placement and running_tasks)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_cfg5_stream_200_ticks.npz"))
+    sv, _ = synth.make_config("cfg5")
+    es = streaming.EventStream(sv, 10_000, 10_000)
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.stream_begin(es.hb + 8, 10_000, 10_000)
+    for t in range(int(fx["ticks"])):
+        who, rows, rel, tk = es.next_tick()
+        got = ctx.stream_tick(who, rows, rel, tk)
+        assert synth.placement_hash(got) == int(fx["digest"][t]), "tick %d: placement differs" % t
+        assert int((got < binding.IDX_ENV_NOT_FOUND).sum()) == int(fx["granted"][t])
+        es.commit(got)
+        if t % 10 == 9 or t < 3:
+            assert synth.placement_hash(ctx.get_running()) == int(fx["run_digest"][t]), t
+    ctx.stream_end()
+    ctx.close()
