@@ -22,10 +22,15 @@ namespace ydc {
 
 constexpr uint32_t kMaxWideClasses = 3072;  // 36 B of class state + 8 B of staged mask words per class
 constexpr uint32_t kWideFields = 9;
+// The walk with prefetch waves keeps nine more words per class (a four-entry ring of upcoming list
+// entries + how far it is filled): 72 B + 8 B of mask words per class.
+constexpr uint32_t kMaxWalkPrefetchClasses = 1920;
+constexpr uint32_t kWalkRing = 4;
 // Dynamic LDS of k_sim_wide for C classes: the nine state arrays + the class masks of a block of
 // 64 requests (64 x ceil(C / 64) 64-bit words).
-__host__ __device__ inline size_t wide_lds_bytes(uint32_t C) {
-  return (size_t)kWideFields * C * 4 + 8 + (size_t)64 * ((C + 63) / 64) * 8;
+__host__ __device__ inline size_t wide_lds_bytes(uint32_t C, bool walk_prefetch = false) {
+  return (size_t)(kWideFields + (walk_prefetch ? 1 + 2 * kWalkRing : 0)) * C * 4 + 16 +
+         (size_t)64 * ((C + 63) / 64) * 8;
 }
 
 struct WideState {
@@ -50,7 +55,13 @@ struct WideState {
 // changed (everything before it is final: its guess IS its predecessor's final end state) and
 // walks from there to the end of the batch with the state in LDS, leaving guesses and end
 // states consistent behind it; the next k_update finds nothing to change.
-__global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint32_t n_tasks,
+// walk == 2 (256 threads): waves 1-3 are PREFETCHERS. A lone walker that fetches the list entry
+// after next itself waits out a cold memory access per pick — a wave's vmcnt is wave-wide and in
+// order —, 3.5 us per request. Here the walker never touches memory for the lists: every class
+// has a four-entry ring of upcoming entries in LDS, which the prefetch waves keep filled behind
+// its cursor (single-writer counters: the walker owns `cur`, the prefetchers own `fill`; a slot
+// is position & 3, free once the walker has passed it; entries are written before `fill` moves).
+__global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                  uint32_t chunk_size, uint32_t n_chunks,
                                                  ClassState* __restrict__ guess,
                                                  ClassState* __restrict__ endst, uint8_t* dirty,
@@ -59,14 +70,64 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
   extern __shared__ uint32_t wsm[];
   if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
   uint32_t k = blockIdx.x;
-  const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
+  const uint32_t lane = threadIdx.x & 63u, wave_id = threadIdx.x >> 6, C = L.n_classes, W = T.words;
+  const bool prefetched = walk == 2;
+  // walk == 2 only: [fill | ring_p[4] | ring_g[4]] behind the state arrays and the block's masks
+  // LDS: nine state arrays | "walk done" word | the block's class masks (8-byte aligned) | walk only:
+  const uint32_t mask_at = (kWideFields * C + 3u) & ~1u;
+  volatile uint32_t* const wdone = wsm + (size_t)kWideFields * C;
+  volatile uint32_t* const wfill = wsm + mask_at + (size_t)64 * W * 2;
+  volatile uint32_t* const wring_p = wfill + C;
+  volatile uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
+  volatile uint32_t* const vcur = wsm;  // == S.cur
+  if (prefetched && wave_id != 0) {
+    // ---- prefetch waves: class c belongs to wave 1 + (c / 64) % 3, lane c % 64
+    __syncthreads();  // (the walker has set the state up)
+    const uint32_t* endv = wsm + 4 * C;  // == S.end
+    while (*wdone == 0) {
+      for (uint32_t c = (wave_id - 1) * 64 + lane; c < C; c += 192) {
+        const uint32_t cur = vcur[c], e = endv[c];
+        uint32_t pos = wfill[c];
+        pos = pos > cur + 2 ? pos : cur + 2;
+        const uint32_t lim = cur + 2 + kWalkRing < e ? cur + 2 + kWalkRing : e;
+        if (pos < lim) {
+          uint32_t tp[kWalkRing], tg[kWalkRing];
+#pragma unroll
+          for (uint32_t u = 0; u < kWalkRing; ++u) {
+            tp[u] = tg[u] = kNone;
+            if (pos + u < lim) {
+              tp[u] = list_rank(L, pos + u);
+              tg[u] = list_slot(L, pos + u);
+            }
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < kWalkRing; ++u) {
+            if (pos + u < lim) {
+              wring_p[(size_t)((pos + u) & (kWalkRing - 1)) * C + c] = tp[u];
+              wring_g[(size_t)((pos + u) & (kWalkRing - 1)) * C + c] = tg[u];
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          wfill[c] = lim;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return;
+  }
   if (walk) {
     k = n_chunks;
     for (uint32_t base = 0; base < n_chunks && k == n_chunks; base += 64) {
       const uint64_t m = __ballot(base + lane < n_chunks && dirty[base + lane] != 0);
       if (m) k = base + (uint32_t)__builtin_ctzll(m);
     }
-    if (k >= n_chunks) return;
+    if (k >= n_chunks) {  // nothing left to walk (the prefetch waves are told, then let go)
+      if (prefetched) {
+        if (lane == 0) *wdone = 1;
+        __syncthreads();
+      }
+      return;
+    }
   } else if (k >= n_chunks || !dirty[k]) {
     return;
   }
@@ -74,7 +135,7 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
               wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C};
   // The class masks of the current block of 64 requests, staged with coalesced loads: a
   // request's W words are then wave-uniform LDS reads instead of W memory round trips.
-  uint64_t* const bmask = (uint64_t*)(wsm + (size_t)kWideFields * C + ((kWideFields * C) & 1u));
+  uint64_t* const bmask = (uint64_t*)(wsm + mask_at);
   const ClassState* start = guess + (size_t)k * C;
   // ---- start state (clamped like class_run_init: speculative states may be anything)
   for (uint32_t c = lane; c < C; c += 64) {
@@ -100,6 +161,19 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
   }
   __builtin_amdgcn_wave_barrier();
   bool any_holes = __ballot(my_holes != 0) != 0;
+  if (prefetched) {
+    for (uint32_t c = lane; c < C; c += 64) wfill[c] = 0;
+    if (lane == 0) *wdone = 0;
+    __syncthreads();  // the prefetch waves start
+  }
+  // The walker's "entry after next" of class c from the ring (waits for the prefetchers if the
+  // class was picked faster than they refill, which takes several picks within one of their sweeps).
+  auto ring_take = [&](uint32_t c, uint32_t pos, uint32_t& p, uint32_t& g) {
+    while (wfill[c] <= pos) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    p = wring_p[(size_t)(pos & (kWalkRing - 1)) * C + c];
+    g = wring_g[(size_t)(pos & (kWalkRing - 1)) * C + c];
+  };
   // One fetch of "the entry after next" in flight per lane.
   uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
   bool pend_on = false;
@@ -161,18 +235,23 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
             slot_of[t] = S.hg[c];
             flush();
             const uint32_t cur = S.cur[c] + 1;
+            // (the prefetch waves fill positions [cursor + 2, cursor + 6): the entry after next is
+            // taken while the cursor still names the old head, or they would step over it)
+            uint32_t p2 = kNone, g2 = kNone;
+            const bool more_entries = cur + 1 < S.end[c];
+            if (prefetched && more_entries) ring_take(c, cur + 1, p2, g2);
             S.cur[c] = cur;
             S.lo[c] = cur;  // (no holes anywhere on this path)
             S.hp[c] = S.np[c];
             S.hg[c] = S.ng[c];
-            if (cur + 1 < S.end[c]) {
+            if (!more_entries || prefetched) {
+              S.np[c] = p2;
+              S.ng[c] = g2;
+            } else {
               pend_c = c;
               pend_p = list_rank(L, cur + 1);
               pend_g = list_slot(L, cur + 1);
               pend_on = true;
-            } else {
-              S.np[c] = kNone;
-              S.ng[c] = kNone;
             }
           }
           continue;
@@ -274,6 +353,7 @@ __global__ __launch_bounds__(64) void k_sim_wide(ClassLists L, TaskTable T, uint
   if (!more) break;
   ++k;
   }
+  if (prefetched && lane == 0) *wdone = 1;
 }
 
 }  // namespace ydc

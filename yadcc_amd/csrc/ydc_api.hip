@@ -285,6 +285,7 @@ struct ydc_context {
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
   bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
+  bool opt_walk_prefetch = true;  // the walk of the wide kernel with prefetch waves (YDC_WALK_PREFETCH=0: a lone wave)
   bool opt_wide = true;  // > 256 classes: wave-per-chunk replay (YDC_WIDE=0: thread per chunk)
   bool opt_level_tab = true;  // bin sort leaves a level table for pass 0's guesses (YDC_LEVEL_TAB=0: search)
   // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
@@ -610,6 +611,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
   if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
   if (const char* s = getenv("YDC_WIDE")) c->opt_wide = atoi(s) != 0;
+  if (const char* s = getenv("YDC_WALK_PREFETCH")) c->opt_walk_prefetch = atoi(s) != 0;
   if (const char* s = getenv("YDC_GROUP_BINSORT")) c->opt_group_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
   if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
@@ -1628,7 +1630,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
       const bool wide = p.C <= kMaxWideClasses && c->opt_wide;
       if (wide)  // (above 64 KB of dynamic LDS the runtime wants to be told)
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)wide_lds_bytes(kMaxWideClasses)));
+                                       (int)std::max(wide_lds_bytes(kMaxWideClasses), wide_lds_bytes(kMaxWalkPrefetchClasses, true))));
       uint32_t last_changed = 0xFFFFFFFFu;
       bool walked = false;
       for (;;) {
@@ -1637,10 +1639,12 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
           if (wide) {
             // One wave per chunk, the class states in LDS (wide_kernel.h) — or, once the rounds
             // have stopped making headway, one wave that walks the rest of the batch.
-            const bool walk = walked;
-            YDC_LAUNCH(c, walk ? "k_sim_wide(walk)" : "k_sim_wide", k_sim_wide, dim3(walk ? 1u : p.K), dim3(64),
-                       wide_lds_bytes(p.C), st, p.L, p.T, N, p.cs, p.K, gold, c->d_endst.p,
-                       c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm, walk ? 1u : 0u);
+            // (the walk: with prefetch waves while their rings fit the LDS, YDC_WALK_PREFETCH=0: alone)
+            const bool walk = walked, pf = walk && p.C <= kMaxWalkPrefetchClasses && c->opt_walk_prefetch;
+            YDC_LAUNCH(c, walk ? "k_sim_wide(walk)" : "k_sim_wide", k_sim_wide, dim3(walk ? 1u : p.K),
+                       dim3(pf ? 256 : 64), wide_lds_bytes(p.C, pf), st, p.L, p.T, N, p.cs, p.K, gold,
+                       c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
+                       walk ? (pf ? 2u : 1u) : 0u);
           } else {
             YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
                        p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
