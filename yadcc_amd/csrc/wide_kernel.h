@@ -169,10 +169,16 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   // The walker's "entry after next" of class c from the ring (waits for the prefetchers if the
   // class was picked faster than they refill, which takes several picks within one of their sweeps).
   auto ring_take = [&](uint32_t c, uint32_t pos, uint32_t& p, uint32_t& g) {
-    while (wfill[c] <= pos) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    p = wring_p[(size_t)(pos & (kWalkRing - 1)) * C + c];
-    g = wring_g[(size_t)(pos & (kWalkRing - 1)) * C + c];
+    uint32_t spins = 0;
+    while (wfill[c] <= pos && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+    if (wfill[c] > pos) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      p = wring_p[(size_t)(pos & (kWalkRing - 1)) * C + c];
+      g = wring_g[(size_t)(pos & (kWalkRing - 1)) * C + c];
+    } else {  // (never expected: a prefetch wave that does not deliver; the walker fetches itself)
+      p = list_rank(L, pos);
+      g = list_slot(L, pos);
+    }
   };
   // One fetch of "the entry after next" in flight per lane.
   uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
