@@ -210,16 +210,30 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
       uint64_t many = 0;
       if (!general) {
         bool own = false;
-        for (uint32_t w = 0; w < W; ++w) {
-          const uint64_t m = mask[w];  // wave-uniform
-          many |= m;
-          if ((m >> lane) & 1u) {
-            const uint32_t c = w * 64 + lane;
-            const uint32_t v = S.hp[c];
-            if (self_lo != kNone && S.hg[c] - self_lo < self_hi - self_lo) own = true;
-            if (v < best) {
-              best = v;
-              bw = w;
+        // Eight mask words and the eight head ranks of this lane's classes under them per step, all
+        // read unconditionally and side by side: an LDS read takes ~100 cycles to come back, and a
+        // scan that tests a bit before it reads the head pays that twice per word (28 words:
+        // 3.8 us per request, measured).
+        const uint32_t self_len = self_hi - self_lo;  // (self_lo == kNone: never matches below)
+        for (uint32_t w0 = 0; w0 < W; w0 += 8) {
+          uint64_t m[8];
+          uint32_t v[8], g[8];
+#pragma unroll
+          for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t c = (w0 + u) * 64 + lane;
+            m[u] = w0 + u < W ? mask[w0 + u] : 0;  // wave-uniform
+            v[u] = c < C ? S.hp[c] : kNone;
+            g[u] = self_lo != kNone && c < C ? S.hg[c] : kNone;
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < 8; ++u) {
+            many |= m[u];
+            if ((m[u] >> lane) & 1u) {
+              if (self_lo != kNone && g[u] - self_lo < self_len) own = true;
+              if (v[u] < best) {
+                best = v[u];
+                bw = w0 + u;
+              }
             }
           }
         }
