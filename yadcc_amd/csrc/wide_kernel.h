@@ -30,7 +30,7 @@ constexpr uint32_t kWalkRing = 4;
 // 64 requests (64 x ceil(C / 64) 64-bit words).
 __host__ __device__ inline size_t wide_lds_bytes(uint32_t C, bool walk_prefetch = false) {
   return (size_t)(kWideFields + (walk_prefetch ? 1 + 2 * kWalkRing : 0)) * C * 4 + 16 +
-         (size_t)64 * ((C + 63) / 64) * 8;
+         (size_t)65 * ((C + 63) / 64) * 8;  // (64 requests' mask words + one word row of "has holes" bits)
 }
 
 struct WideState {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   // LDS: nine state arrays | "walk done" word | the block's class masks (8-byte aligned) | walk only:
   const uint32_t mask_at = (kWideFields * C + 3u) & ~1u;
   volatile uint32_t* const wdone = wsm + (size_t)kWideFields * C;
-  volatile uint32_t* const wfill = wsm + mask_at + (size_t)64 * W * 2;
+  volatile uint32_t* const wfill = wsm + mask_at + (size_t)65 * W * 2;
   volatile uint32_t* const wring_p = wfill + C;
   volatile uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
   volatile uint32_t* const vcur = wsm;  // == S.cur
@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   // The class masks of the current block of 64 requests, staged with coalesced loads: a
   // request's W words are then wave-uniform LDS reads instead of W memory round trips.
   uint64_t* const bmask = (uint64_t*)(wsm + mask_at);
+  // Bit c & 63 of word c / 64: class c has holes. A request takes the general step only if one of
+  // ITS classes has (with sparse eligibility some class nearly always has holes: a slot stepped
+  // over by its servant's own host waits for one of the few requests that may use it).
+  uint64_t* const holew = bmask + (size_t)64 * W;
   const ClassState* start = guess + (size_t)k * C;
   // ---- start state (clamped like class_run_init: speculative states may be anything)
   for (uint32_t c = lane; c < C; c += 64) {
@@ -160,7 +164,13 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     my_holes += S.lo[c] < cur ? 1u : 0u;
   }
   __builtin_amdgcn_wave_barrier();
-  bool any_holes = __ballot(my_holes != 0) != 0;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t c = w * 64 + lane;
+    const uint64_t hb = __ballot(c < C && S.lo[c] < S.cur[c]);
+    if (lane == 0) holew[w] = hb;
+  }
+  (void)my_holes;
+  __builtin_amdgcn_wave_barrier();
   if (prefetched) {
     for (uint32_t c = lane; c < C; c += 64) wfill[c] = 0;
     if (lane == 0) *wdone = 0;
@@ -205,7 +215,8 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
       const uint32_t t = tb + i;
       const uint64_t* mask = bmask + (size_t)i * W;
       uint32_t self_lo = readlane_u32(slo_v, i), self_hi = readlane_u32(shi_v, i);
-      bool general = any_holes || self_hi == kSelfShared;
+      bool general = self_hi == kSelfShared ||
+                     __ballot(lane < W && (mask[lane < W ? lane : 0] & holew[lane < W ? lane : 0]) != 0) != 0;
       uint32_t best = kNone, bw = 0;
       uint64_t many = 0;
       if (!general) {
@@ -347,10 +358,9 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
         S.np[bc] = r.cursor + 1 < r.end ? list_rank(L, r.cursor + 1) : kNone;
         S.ng[bc] = r.cursor + 1 < r.end ? list_slot(L, r.cursor + 1) : kNone;
         const bool has = r.lo < r.cursor;
-        my_holes += (has ? 1u : 0u) - (had ? 1u : 0u);
+        if (has != had) holew[bc >> 6] ^= 1ull << (bc & 63u);
       }
       __builtin_amdgcn_wave_barrier();
-      any_holes = __ballot(my_holes != 0) != 0;
     }
   }
   flush();
