@@ -30,11 +30,12 @@ constexpr uint32_t kWalkRing = 4;
 // 64 requests (64 x ceil(C / 64) 64-bit words).
 __host__ __device__ inline size_t wide_lds_bytes(uint32_t C, bool walk_prefetch = false) {
   return (size_t)(kWideFields + (walk_prefetch ? 1 + 2 * kWalkRing : 0)) * C * 4 + 16 +
-         (size_t)65 * ((C + 63) / 64) * 8;  // (64 requests' mask words + one word row of "has holes" bits)
+         (size_t)66 * ((C + 63) / 64) * 8;  // (64 requests' mask words + the "has holes" and "one servant" bit rows)
 }
 
 struct WideState {
   uint32_t *cur, *lo, *hlo, *hhi, *end, *hp, *hg, *np, *ng;
+  const uint64_t* singlew;  // LDS: bit c & 63 of word c / 64 = ClassLists::cls_single[c]
   __device__ __forceinline__ ClassRun run(const ClassLists& L, uint32_t c) const {
     ClassRun r;
     r.cursor = cur[c];
@@ -44,7 +45,7 @@ struct WideState {
     r.end = end[c];
     r.head_p = hp[c];
     r.head_g = hg[c];
-    r.single = L.cls_single ? L.cls_single[c] : 0u;
+    r.single = (uint32_t)((singlew[c >> 6] >> (c & 63u)) & 1u);  // (not a memory access per class)
     return r;
   }
 };
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   // LDS: nine state arrays | "walk done" word | the block's class masks (8-byte aligned) | walk only:
   const uint32_t mask_at = (kWideFields * C + 3u) & ~1u;
   volatile uint32_t* const wdone = wsm + (size_t)kWideFields * C;
-  volatile uint32_t* const wfill = wsm + mask_at + (size_t)65 * W * 2;
+  volatile uint32_t* const wfill = wsm + mask_at + (size_t)66 * W * 2;
   volatile uint32_t* const wring_p = wfill + C;
   volatile uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
   volatile uint32_t* const vcur = wsm;  // == S.cur
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     return;
   }
   WideState S{wsm,         wsm + C,     wsm + 2 * C, wsm + 3 * C, wsm + 4 * C,
-              wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C};
+              wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C,
+              (const uint64_t*)(wsm + mask_at) + (size_t)65 * W};
   // The class masks of the current block of 64 requests, staged with coalesced loads: a
   // request's W words are then wave-uniform LDS reads instead of W memory round trips.
   uint64_t* const bmask = (uint64_t*)(wsm + mask_at);
@@ -167,7 +169,11 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   for (uint32_t w = 0; w < W; ++w) {
     const uint32_t c = w * 64 + lane;
     const uint64_t hb = __ballot(c < C && S.lo[c] < S.cur[c]);
-    if (lane == 0) holew[w] = hb;
+    const uint64_t sb = __ballot(c < C && L.cls_single && L.cls_single[c] != 0);
+    if (lane == 0) {
+      holew[w] = hb;
+      holew[W + w] = sb;  // (== S.singlew[w])
+    }
   }
   (void)my_holes;
   __builtin_amdgcn_wave_barrier();
@@ -209,7 +215,19 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     const uint32_t slo_v = tl < t1 ? T.self_lo[tl] : kNone, shi_v = tl < t1 ? T.self_hi[tl] : kNone;
     const uint32_t cnt = min(64u, t1 - tb);
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < cnt * W; j += 64) bmask[j] = T.mask[(size_t)tb * W + j];
+    for (uint32_t j0 = 0; j0 < cnt * W; j0 += 512) {  // (eight loads per lane in flight)
+      uint64_t mv[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const uint32_t j = j0 + u * 64 + lane;
+        mv[u] = j < cnt * W ? T.mask[(size_t)tb * W + j] : 0;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const uint32_t j = j0 + u * 64 + lane;
+        if (j < cnt * W) bmask[j] = mv[u];
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t t = tb + i;
