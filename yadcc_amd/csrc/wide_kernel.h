@@ -33,6 +33,19 @@ __host__ __device__ inline size_t wide_lds_bytes(uint32_t C, bool walk_prefetch 
          (size_t)66 * ((C + 63) / 64) * 8;  // (64 requests' mask words + the "has holes" and "one servant" bit rows)
 }
 
+// LDS accesses of the walker / prefetcher protocol, as DS instructions on the LDS offset: a
+// `volatile` generic pointer makes the compiler emit FLAT loads, which count in vmcnt — every
+// protocol read then waits for the wave's outstanding global stores (measured: no faster than
+// fetching from memory). The "memory" clobber keeps the compiler from moving accesses across.
+__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t* p) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_store_u32(uint32_t* p, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+
 struct WideState {
   uint32_t *cur, *lo, *hlo, *hhi, *end, *hp, *hg, *np, *ng;
   const uint64_t* singlew;  // LDS: bit c & 63 of word c / 64 = ClassLists::cls_single[c]
@@ -76,19 +89,19 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   // walk == 2 only: [fill | ring_p[4] | ring_g[4]] behind the state arrays and the block's masks
   // LDS: nine state arrays | "walk done" word | the block's class masks (8-byte aligned) | walk only:
   const uint32_t mask_at = (kWideFields * C + 3u) & ~1u;
-  volatile uint32_t* const wdone = wsm + (size_t)kWideFields * C;
-  volatile uint32_t* const wfill = wsm + mask_at + (size_t)66 * W * 2;
-  volatile uint32_t* const wring_p = wfill + C;
-  volatile uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
-  volatile uint32_t* const vcur = wsm;  // == S.cur
+  uint32_t* const wdone = wsm + (size_t)kWideFields * C;
+  uint32_t* const wfill = wsm + mask_at + (size_t)66 * W * 2;
+  uint32_t* const wring_p = wfill + C;
+  uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
+  const uint32_t* const vcur = wsm;  // == S.cur
   if (prefetched && wave_id != 0) {
     // ---- prefetch waves: class c belongs to wave 1 + (c / 64) % 3, lane c % 64
     __syncthreads();  // (the walker has set the state up)
     const uint32_t* endv = wsm + 4 * C;  // == S.end
-    while (*wdone == 0) {
+    while (lds_load_u32(wdone) == 0) {
       for (uint32_t c = (wave_id - 1) * 64 + lane; c < C; c += 192) {
-        const uint32_t cur = vcur[c], e = endv[c];
-        uint32_t pos = wfill[c];
+        const uint32_t cur = lds_load_u32(vcur + c), e = endv[c];
+        uint32_t pos = lds_load_u32(wfill + c);
         pos = pos > cur + 2 ? pos : cur + 2;
         const uint32_t lim = cur + 2 + kWalkRing < e ? cur + 2 + kWalkRing : e;
         if (pos < lim) {
@@ -104,12 +117,12 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
 #pragma unroll
           for (uint32_t u = 0; u < kWalkRing; ++u) {
             if (pos + u < lim) {
-              wring_p[(size_t)((pos + u) & (kWalkRing - 1)) * C + c] = tp[u];
-              wring_g[(size_t)((pos + u) & (kWalkRing - 1)) * C + c] = tg[u];
+              lds_store_u32(wring_p + (size_t)((pos + u) & (kWalkRing - 1)) * C + c, tp[u]);
+              lds_store_u32(wring_g + (size_t)((pos + u) & (kWalkRing - 1)) * C + c, tg[u]);
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          wfill[c] = lim;
+          // (DS operations of a wave execute in order: the entries are in before `fill` moves)
+          lds_store_u32(wfill + c, lim);
         }
       }
       __builtin_amdgcn_s_sleep(1);
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     }
     if (k >= n_chunks) {  // nothing left to walk (the prefetch waves are told, then let go)
       if (prefetched) {
-        if (lane == 0) *wdone = 1;
+        if (lane == 0) lds_store_u32(wdone, 1u);
         __syncthreads();
       }
       return;
@@ -178,19 +191,18 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   (void)my_holes;
   __builtin_amdgcn_wave_barrier();
   if (prefetched) {
-    for (uint32_t c = lane; c < C; c += 64) wfill[c] = 0;
-    if (lane == 0) *wdone = 0;
+    for (uint32_t c = lane; c < C; c += 64) lds_store_u32(wfill + c, 0u);
+    if (lane == 0) lds_store_u32(wdone, 0u);
     __syncthreads();  // the prefetch waves start
   }
   // The walker's "entry after next" of class c from the ring (waits for the prefetchers if the
   // class was picked faster than they refill, which takes several picks within one of their sweeps).
   auto ring_take = [&](uint32_t c, uint32_t pos, uint32_t& p, uint32_t& g) {
     uint32_t spins = 0;
-    while (wfill[c] <= pos && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
-    if (wfill[c] > pos) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      p = wring_p[(size_t)(pos & (kWalkRing - 1)) * C + c];
-      g = wring_g[(size_t)(pos & (kWalkRing - 1)) * C + c];
+    while (lds_load_u32(wfill + c) <= pos && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+    if (lds_load_u32(wfill + c) > pos) {
+      p = lds_load_u32(wring_p + (size_t)(pos & (kWalkRing - 1)) * C + c);
+      g = lds_load_u32(wring_g + (size_t)(pos & (kWalkRing - 1)) * C + c);
     } else {  // (never expected: a prefetch wave that does not deliver; the walker fetches itself)
       p = list_rank(L, pos);
       g = list_slot(L, pos);
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   if (!more) break;
   ++k;
   }
-  if (prefetched && lane == 0) *wdone = 1;
+  if (prefetched && lane == 0) lds_store_u32(wdone, 1u);
 }
 
 }  // namespace ydc
