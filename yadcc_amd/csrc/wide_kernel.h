@@ -28,9 +28,13 @@ constexpr uint32_t kMaxWalkPrefetchClasses = 1920;
 constexpr uint32_t kWalkRing = 4;
 // Dynamic LDS of k_sim_wide for C classes: the nine state arrays + the class masks of a block of
 // 64 requests (64 x ceil(C / 64) 64-bit words).
+// Seven state arrays of C words, the two the scan reads (head rank, head slot) padded to a
+// multiple of 512 classes so that the scan needs no bounds tests; the class masks of a block of 64
+// requests (rows of W8 = ceil(W / 8) * 8 words) and the "has holes" / "one servant" bit rows.
 __host__ __device__ inline size_t wide_lds_bytes(uint32_t C, bool walk_prefetch = false) {
-  return (size_t)(kWideFields + (walk_prefetch ? 1 + 2 * kWalkRing : 0)) * C * 4 + 16 +
-         (size_t)66 * ((C + 63) / 64) * 8;  // (64 requests' mask words + the "has holes" and "one servant" bit rows)
+  const size_t W = (C + 63) / 64, W8 = (W + 7) & ~(size_t)7;
+  return (size_t)(kWideFields - 2 + (walk_prefetch ? 1 + 2 * kWalkRing : 0)) * C * 4 + 2 * W8 * 64 * 4 + 16 +
+         (64 * W8 + 2 * W) * 8;
 }
 
 // LDS accesses of the walker / prefetcher protocol, as DS instructions on the LDS offset: a
@@ -88,9 +92,11 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   const bool prefetched = walk == 2;
   // walk == 2 only: [fill | ring_p[4] | ring_g[4]] behind the state arrays and the block's masks
   // LDS: nine state arrays | "walk done" word | the block's class masks (8-byte aligned) | walk only:
-  const uint32_t mask_at = (kWideFields * C + 3u) & ~1u;
-  uint32_t* const wdone = wsm + (size_t)kWideFields * C;
-  uint32_t* const wfill = wsm + mask_at + (size_t)66 * W * 2;
+  const uint32_t W8 = (W + 7u) & ~7u, Cpad = W8 * 64;
+  const uint32_t state_words = (kWideFields - 2) * C + 2 * Cpad;
+  const uint32_t mask_at = (state_words + 3u) & ~1u;
+  uint32_t* const wdone = wsm + (size_t)state_words;
+  uint32_t* const wfill = wsm + mask_at + (size_t)(64 * W8 + 2 * W) * 2;
   uint32_t* const wring_p = wfill + C;
   uint32_t* const wring_g = wring_p + (size_t)kWalkRing * C;
   const uint32_t* const vcur = wsm;  // == S.cur
@@ -145,16 +151,17 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   } else if (k >= n_chunks || !dirty[k]) {
     return;
   }
-  WideState S{wsm,         wsm + C,     wsm + 2 * C, wsm + 3 * C, wsm + 4 * C,
-              wsm + 5 * C, wsm + 6 * C, wsm + 7 * C, wsm + 8 * C,
-              (const uint64_t*)(wsm + mask_at) + (size_t)65 * W};
+  // (cur | lo | hlo | hhi | end | np | ng: C words each; hp | hg: Cpad words each, kNone beyond C)
+  WideState S{wsm,         wsm + C,     wsm + 2 * C,        wsm + 3 * C,        wsm + 4 * C,
+              wsm + 7 * C, wsm + 7 * C + Cpad, wsm + 5 * C, wsm + 6 * C,
+              (const uint64_t*)(wsm + mask_at) + (size_t)64 * W8 + W};
   // The class masks of the current block of 64 requests, staged with coalesced loads: a
   // request's W words are then wave-uniform LDS reads instead of W memory round trips.
   uint64_t* const bmask = (uint64_t*)(wsm + mask_at);
   // Bit c & 63 of word c / 64: class c has holes. A request takes the general step only if one of
   // ITS classes has (with sparse eligibility some class nearly always has holes: a slot stepped
   // over by its servant's own host waits for one of the few requests that may use it).
-  uint64_t* const holew = bmask + (size_t)64 * W;
+  uint64_t* const holew = bmask + (size_t)64 * W8;
   const ClassState* start = guess + (size_t)k * C;
   // ---- start state (clamped like class_run_init: speculative states may be anything)
   for (uint32_t c = lane; c < C; c += 64) {
@@ -177,6 +184,10 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     S.np[c] = cur + 1 < e ? list_rank(L, cur + 1) : kNone;
     S.ng[c] = cur + 1 < e ? list_slot(L, cur + 1) : kNone;
     my_holes += S.lo[c] < cur ? 1u : 0u;
+  }
+  for (uint32_t c = C + lane; c < Cpad; c += 64) {
+    S.hp[c] = kNone;
+    S.hg[c] = kNone;
   }
   __builtin_amdgcn_wave_barrier();
   for (uint32_t w = 0; w < W; ++w) {
@@ -219,31 +230,39 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     }
   };
 
+#ifdef YDC_PHASE_PROBE
+  unsigned long long pr_stage = 0, pr_scan = 0, pr_take = 0, pr_gen = 0, pr_end = 0, pr_n_fast = 0, pr_n_gen = 0,
+                     pr_t = 0, pr_total0 = wall_clock64();
+#define YDC_WTICK() (pr_t = wall_clock64())
+#define YDC_WACC(x) ((x) += wall_clock64() - pr_t)
+#else
+#define YDC_WTICK() ((void)0)
+#define YDC_WACC(x) ((void)0)
+#endif
   for (;;) {  // chunk k (and, walking, every chunk behind it)
   const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
   for (uint32_t tb = t0; tb < t1; tb += 64) {
+    YDC_WTICK();
     // this block's own-servant ranges: lane i holds request tb + i
     const uint32_t tl = tb + lane;
     const uint32_t slo_v = tl < t1 ? T.self_lo[tl] : kNone, shi_v = tl < t1 ? T.self_hi[tl] : kNone;
     const uint32_t cnt = min(64u, t1 - tb);
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j0 = 0; j0 < cnt * W; j0 += 512) {  // (eight loads per lane in flight)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {  // (rows of W8 words, zero beyond W; eight loads in flight)
       uint64_t mv[8];
 #pragma unroll
-      for (uint32_t u = 0; u < 8; ++u) {
-        const uint32_t j = j0 + u * 64 + lane;
-        mv[u] = j < cnt * W ? T.mask[(size_t)tb * W + j] : 0;
-      }
+      for (uint32_t u = 0; u < 8; ++u)
+        mv[u] = i0 + u < cnt && lane < W ? T.mask[(size_t)(tb + i0 + u) * W + lane] : 0;
 #pragma unroll
-      for (uint32_t u = 0; u < 8; ++u) {
-        const uint32_t j = j0 + u * 64 + lane;
-        if (j < cnt * W) bmask[j] = mv[u];
-      }
+      for (uint32_t u = 0; u < 8; ++u)
+        if (i0 + u < cnt && lane < W8) bmask[(size_t)(i0 + u) * W8 + lane] = mv[u];
     }
     __builtin_amdgcn_wave_barrier();
+    YDC_WACC(pr_stage);
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t t = tb + i;
-      const uint64_t* mask = bmask + (size_t)i * W;
+      const uint64_t* mask = bmask + (size_t)i * W8;
+      YDC_WTICK();
       uint32_t self_lo = readlane_u32(slo_v, i), self_hi = readlane_u32(shi_v, i);
       bool general = self_hi == kSelfShared ||
                      __ballot(lane < W && (mask[lane < W ? lane : 0] & holew[lane < W ? lane : 0]) != 0) != 0;
@@ -255,26 +274,30 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
         // read unconditionally and side by side: an LDS read takes ~100 cycles to come back, and a
         // scan that tests a bit before it reads the head pays that twice per word (28 words:
         // 3.8 us per request, measured).
-        const uint32_t self_len = self_hi - self_lo;  // (self_lo == kNone: never matches below)
-        for (uint32_t w0 = 0; w0 < W; w0 += 8) {
+        const uint32_t self_len = self_hi - self_lo;
+        for (uint32_t w0 = 0; w0 < W8; w0 += 8) {  // (rows and head arrays are padded: no bounds tests)
           uint64_t m[8];
-          uint32_t v[8], g[8];
+          uint32_t v[8];
 #pragma unroll
           for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t c = (w0 + u) * 64 + lane;
-            m[u] = w0 + u < W ? mask[w0 + u] : 0;  // wave-uniform
-            v[u] = c < C ? S.hp[c] : kNone;
-            g[u] = self_lo != kNone && c < C ? S.hg[c] : kNone;
+            m[u] = mask[w0 + u];  // wave-uniform
+            v[u] = S.hp[(w0 + u) * 64 + lane];
+          }
+          if (self_lo != kNone) {  // (uniform) a request from a servant's host: is its own slot at a head?
+            uint32_t g[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) g[u] = S.hg[(w0 + u) * 64 + lane];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+              if (((m[u] >> lane) & 1u) && g[u] - self_lo < self_len) own = true;
           }
 #pragma unroll
           for (uint32_t u = 0; u < 8; ++u) {
             many |= m[u];
-            if ((m[u] >> lane) & 1u) {
-              if (self_lo != kNone && g[u] - self_lo < self_len) own = true;
-              if (v[u] < best) {
-                best = v[u];
-                bw = w0 + u;
-              }
+            const uint32_t cand = ((m[u] >> lane) & 1u) ? v[u] : kNone;
+            if (cand < best) {
+              best = cand;
+              bw = w0 + u;
             }
           }
         }
@@ -285,6 +308,8 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
         // An eligible class shows a slot of the requestor's own servant at its head (it has to be
         // stepped over), or nothing is left but possibly the own servant: the general step.
         const uint32_t mn = wave_min_u32(best);
+        YDC_WACC(pr_scan);
+        YDC_WTICK();
         if (__ballot(own) != 0 || (mn == kNone && self_lo != kNone)) {
           general = true;
         } else if (mn == kNone) {
@@ -315,9 +340,17 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
               pend_on = true;
             }
           }
+          YDC_WACC(pr_take);
+#ifdef YDC_PHASE_PROBE
+          ++pr_n_fast;
+#endif
           continue;
         }
       }
+#ifdef YDC_PHASE_PROBE
+      ++pr_n_gen;
+#endif
+      YDC_WTICK();
       // ---- general step (dispatch_core.h's state machine on the LDS state)
       flush();
       __builtin_amdgcn_wave_barrier();
@@ -391,8 +424,10 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
         if (has != had) holew[bc >> 6] ^= 1ull << (bc & 63u);
       }
       __builtin_amdgcn_wave_barrier();
+      YDC_WACC(pr_gen);
     }
   }
+  YDC_WTICK();
   flush();
   __builtin_amdgcn_wave_barrier();
   const bool more = walk && k + 1 < n_chunks;
@@ -410,9 +445,22 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     dirty[k] = 0;
     atomicAdd(&prm->chunk_sims, 1u);
   }
+  YDC_WACC(pr_end);
   if (!more) break;
   ++k;
   }
+#ifdef YDC_PHASE_PROBE
+  if (walk && lane == 0) {
+    ydc_phase_probe[0] = pr_stage;
+    ydc_phase_probe[1] = pr_scan;
+    ydc_phase_probe[2] = pr_take;
+    ydc_phase_probe[3] = pr_gen;
+    ydc_phase_probe[4] = pr_end;
+    ydc_phase_probe[5] = pr_n_fast;
+    ydc_phase_probe[6] = pr_n_gen;
+    ydc_phase_probe[7] = wall_clock64() - pr_total0;
+  }
+#endif
   if (prefetched && lane == 0) lds_store_u32(wdone, 1u);
 }
 
