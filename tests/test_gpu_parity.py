@@ -364,17 +364,20 @@ def test_many_classes_paths(ctx):
     assert st["n_classes"] > 256
 
 
-@pytest.mark.parametrize("wide", [1, 2, 0])
+@pytest.mark.parametrize("wide", [1, 2, 3, 0])
 def test_more_than_256_classes(wide, monkeypatch):
     """Pools whose machines advertise individual compiler sets (the reference has no limit on
     (environment set, version) combinations, task_dispatcher.h:93-94, .cc:316-344): 150 digests,
     about one class per servant. wide=1: one wave per chunk with the class states in LDS
-    (k_sim_wide) and — these pools do not converge by rounds — the walk with prefetch waves;
-    wide=2: the walk by a lone wave; wide=0: the thread-per-chunk kernel. Plain, with traffic from the servants'
+    (k_sim_wide), a request's classes read from its (digest, version threshold) row, and — these
+    pools do not converge by rounds — the walk; wide=2: the walk with prefetch waves; wide=3: mask
+    scan instead of the rows; wide=0: the thread-per-chunk kernel. Plain, with traffic from the servants'
     own hosts on shared hosts (holes, `self` resolved at replay time), and oversubscribed."""
     monkeypatch.setenv("YDC_WIDE", "1" if wide else "0")
     if wide == 2:
-        monkeypatch.setenv("YDC_WALK_PREFETCH", "0")  # the walk by a lone wave
+        monkeypatch.setenv("YDC_WALK_PREFETCH", "1")  # the walk with prefetch waves
+    if wide == 3:
+        monkeypatch.setenv("YDC_WIDE_LISTS", "0")  # mask scan instead of eligible-class lists
     c = binding.Context(device=0)
     try:
         n = 30_000 if wide else 6_000

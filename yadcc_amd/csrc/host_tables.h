@@ -39,6 +39,14 @@ struct HostTables {
   // min_version. Empty when not built.
   std::vector<uint32_t> ver_sorted;
   std::vector<uint64_t> env_ver_mask;
+  // The same lookup as LISTS, for registries with many classes and sparse eligibility (a pool
+  // whose machines advertise individual compiler sets: a request may use 2 % of ~2000 classes):
+  // row r = env * (V + 1) + vi holds the eligible classes elig_cls[elig_off[r] .. elig_off[r + 1])
+  // in ascending order. Built with env_ver_mask when there are more than kMaxWaveClasses classes;
+  // the wave-per-chunk kernel reads a request's classes from its row when the rows are short
+  // (elig_max_len <= 64) instead of scanning the mask words.
+  std::vector<uint32_t> elig_off, elig_cls;
+  uint32_t elig_max_len = 0;  // longest row
   // Independent parts of the registry: classes are linked when some request could take either
   // (they share a digest), and a request only ever compares slots of ONE part. cls_comp[c] is
   // the part of class c (ids below kMaxComponents; several parts may share an id, which is
@@ -126,8 +134,31 @@ struct HostTables {
           if ((cls_env[(size_t)c * EW + env / 64] >> (env % 64)) & 1u)
             for (uint32_t vi = 0; vi < V && ver_sorted[vi] <= cls_ver[c]; ++vi)
               env_ver_mask[((size_t)env * (V + 1) + vi) * words + c / 64] |= 1ull << (c % 64);
+      elig_off.clear();
+      elig_cls.clear();
+      elig_max_len = 0;
+      if (C > kMaxWaveClasses) {
+        const size_t rows = (size_t)64 * EW * (V + 1);
+        elig_off.assign(rows + 1, 0);
+        for (size_t r = 0; r < rows; ++r) {
+          uint32_t n_r = 0;
+          for (uint32_t w = 0; w < words; ++w) n_r += (uint32_t)__builtin_popcountll(env_ver_mask[r * words + w]);
+          elig_off[r + 1] = elig_off[r] + n_r;
+          elig_max_len = std::max(elig_max_len, n_r);
+        }
+        elig_cls.resize(elig_off[rows]);
+        for (size_t r = 0; r < rows; ++r) {
+          uint32_t at = elig_off[r];
+          for (uint32_t w = 0; w < words; ++w)
+            for (uint64_t m = env_ver_mask[r * words + w]; m; m &= m - 1)
+              elig_cls[at++] = w * 64 + (uint32_t)__builtin_ctzll(m);
+        }
+      }
     } else {
       ver_sorted.clear();
+      elig_off.clear();
+      elig_cls.clear();
+      elig_max_len = 0;
     }
 
     // Parts: union-find over the classes through the digests they advertise.

@@ -313,6 +313,9 @@ struct ClassifyArgs {
   // every entry written — nothing to reset) and the chunk prefix adds the waves of a chunk up.
   uint32_t by_servant, per_wave;
   uint32_t n_ip;  // entries of the ip table (>= n_servants: a servant may answer to several host ids)
+  // Nullable (lookup form only): row of the (digest, version threshold) lookup the request
+  // falls into (kNone: a digest nobody has) — k_sim_wide's eligible-class lists (host_tables.h).
+  uint32_t* row_out;
 };
 
 __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint32_t block,
@@ -327,6 +330,7 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
       uint32_t vi = 0;  // class versions below min_version
       for (uint32_t j = 0; j < a.n_versions; ++j) vi += a.ver_sorted[j] < minv;
       const uint32_t n_env = 64 * a.env_words;  // digests >= n_env: nobody has them
+      if (a.row_out) a.row_out[t] = env < n_env ? env * (a.n_versions + 1) + vi : kNone;
       const uint64_t* row = a.env_ver_mask + ((size_t)min(env, n_env - 1) * (a.n_versions + 1) + vi) * a.words;
       for (uint32_t w = 0; w < a.words; ++w) {
         const uint64_t m = env < n_env ? row[w] : 0;

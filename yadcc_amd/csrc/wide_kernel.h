@@ -50,6 +50,14 @@ __device__ __forceinline__ void lds_store_u32(uint32_t* p, uint32_t v) {
   asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
 }
 
+// Eligible-class lists (host_tables.h: elig_off / elig_cls, every row at most 64 classes) and the
+// row every request falls into. row_of == NULL: the kernel scans the requests' class mask words.
+struct WideLists {
+  const uint32_t* row_of;
+  const uint32_t* off;
+  const uint32_t* cls;
+};
+
 struct WideState {
   uint32_t *cur, *lo, *hlo, *hhi, *end, *hp, *hg, *np, *ng;
   const uint64_t* singlew;  // LDS: bit c & 63 of word c / 64 = ClassLists::cls_single[c]
@@ -84,7 +92,8 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
                                                  ClassState* __restrict__ guess,
                                                  ClassState* __restrict__ endst, uint8_t* dirty,
                                                  uint32_t* __restrict__ slot_of, SharedIpTable shared,
-                                                 uint32_t round, DeviceParams* prm, uint32_t walk) {
+                                                 uint32_t round, DeviceParams* prm, uint32_t walk,
+                                                 WideLists wl) {
   extern __shared__ uint32_t wsm[];
   if (blockIdx.x == 0 && threadIdx.x == 0) prm->n_changed[round & 63] = 0;
   uint32_t k = blockIdx.x;
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
     const uint32_t slo_v = tl < t1 ? T.self_lo[tl] : kNone, shi_v = tl < t1 ? T.self_hi[tl] : kNone;
     const uint32_t cnt = min(64u, t1 - tb);
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {  // (rows of W8 words, zero beyond W; eight loads in flight)
+    for (uint32_t i0 = 0; i0 < cnt && !wl.row_of; i0 += 8) {  // (rows of W8 words, zero beyond W; eight loads in flight)
       uint64_t mv[8];
 #pragma unroll
       for (uint32_t u = 0; u < 8; ++u)
@@ -257,18 +266,91 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
       for (uint32_t u = 0; u < 8; ++u)
         if (i0 + u < cnt && lane < W8) bmask[(size_t)(i0 + u) * W8 + lane] = mv[u];
     }
+    // Lists: lane i holds the row of request tb + i (start and length of its eligible classes); the
+    // class of lane l in request i + 1's list is fetched while request i is being placed.
+    uint32_t off_v = 0, len_v = 0, nxt_c = kNone;
+    if (wl.row_of) {
+      const uint32_t r = tl < t1 ? wl.row_of[tl] : kNone;
+      if (r != kNone) {
+        off_v = wl.off[r];
+        len_v = wl.off[r + 1] - off_v;
+      }
+      const uint32_t o = readlane_u32(off_v, 0), n0 = readlane_u32(len_v, 0);
+      nxt_c = lane < n0 ? wl.cls[o + lane] : kNone;
+    }
     __builtin_amdgcn_wave_barrier();
     YDC_WACC(pr_stage);
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t t = tb + i;
-      const uint64_t* mask = bmask + (size_t)i * W8;
+      // (lists: the mask words are only read by the rare general step, from memory)
+      const uint64_t* mask = wl.row_of ? T.mask + (size_t)t * W : bmask + (size_t)i * W8;
       YDC_WTICK();
       uint32_t self_lo = readlane_u32(slo_v, i), self_hi = readlane_u32(shi_v, i);
-      bool general = self_hi == kSelfShared ||
-                     __ballot(lane < W && (mask[lane < W ? lane : 0] & holew[lane < W ? lane : 0]) != 0) != 0;
+      const uint32_t my_c = nxt_c;  // lists: this lane's class of THIS request's row
+      bool general = self_hi == kSelfShared;
+      if (wl.row_of)
+        general |= __ballot(my_c != kNone && ((holew[my_c >> 6] >> (my_c & 63u)) & 1u)) != 0;
+      else
+        general |= __ballot(lane < W && (mask[lane < W ? lane : 0] & holew[lane < W ? lane : 0]) != 0) != 0;
       uint32_t best = kNone, bw = 0;
       uint64_t many = 0;
-      if (!general) {
+      if (wl.row_of && i + 1 < cnt) {
+        const uint32_t o2 = readlane_u32(off_v, i + 1), n2 = readlane_u32(len_v, i + 1);
+        nxt_c = lane < n2 ? wl.cls[o2 + lane] : kNone;
+      }
+      if (wl.row_of && !general) {
+        // ---- list form of the fast path: one head rank per eligible class and lane
+        const uint32_t n_el = readlane_u32(len_v, i);
+        if (n_el == 0) {
+          if (lane == 0) slot_of[t] = kIdxEnvNotFound;  // task_dispatcher.cc:105-108
+          continue;
+        }
+        bool own = false;
+        if (my_c != kNone) {
+          best = S.hp[my_c];
+          if (self_lo != kNone && S.hg[my_c] - self_lo < self_hi - self_lo) own = true;
+        }
+        const uint32_t mn = wave_min_u32(best);
+        YDC_WACC(pr_scan);
+        YDC_WTICK();
+        if (__ballot(own) != 0 || (mn == kNone && self_lo != kNone)) {
+          general = true;
+        } else if (mn == kNone) {
+          if (lane == 0) slot_of[t] = kIdxTimeout;  // :116-118 with timeout == now
+          continue;
+        } else {
+          // The class's own lane (class & 63) keeps its pending fetch: it does the update.
+          const uint32_t wlane = (uint32_t)__builtin_ctzll(__ballot(best == mn));
+          const uint32_t c = readlane_u32(my_c, wlane);
+          if (lane == (c & 63u)) {
+            slot_of[t] = S.hg[c];
+            flush();
+            const uint32_t cur = S.cur[c] + 1;
+            uint32_t p2 = kNone, g2 = kNone;
+            const bool more_entries = cur + 1 < S.end[c];
+            if (prefetched && more_entries) ring_take(c, cur + 1, p2, g2);
+            S.cur[c] = cur;
+            S.lo[c] = cur;  // (none of the request's classes has holes on this path)
+            S.hp[c] = S.np[c];
+            S.hg[c] = S.ng[c];
+            if (!more_entries || prefetched) {
+              S.np[c] = p2;
+              S.ng[c] = g2;
+            } else {
+              pend_c = c;
+              pend_p = list_rank(L, cur + 1);
+              pend_g = list_slot(L, cur + 1);
+              pend_on = true;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          YDC_WACC(pr_take);
+#ifdef YDC_PHASE_PROBE
+          ++pr_n_fast;
+#endif
+          continue;
+        }
+      } else if (!general) {
         bool own = false;
         // Eight mask words and the eight head ranks of this lane's classes under them per step, all
         // read unconditionally and side by side: an LDS read takes ~100 cycles to come back, and a

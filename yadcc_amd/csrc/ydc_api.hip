@@ -85,6 +85,7 @@ struct BatchPlan {
   bool win = false;  // multi-GPU with a sharded sort: this rank only holds a key window of the slots
   // Bin sort (bin_sort.h) instead of the radix sort: n_bins equal bins over the key space.
   bool fuse01 = false;  // the launch of matching pass 0 is pass 1 as well (no launch for pass 1)
+  bool wide_lists = false;  // > 256 classes with short eligible-class rows: k_sim_wide's list form
   bool binsort = false;
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   uint32_t bin_group = 0, bin_tiles = 0;  // servants per slot tile, slot tiles (k_front_bins)
@@ -131,6 +132,7 @@ struct ydc_context {
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
   DevBuf<uint32_t> d_binbase, d_binruns;  // bin sort: starts of the bins per class, run table of the slot tiles
   DevBuf<uint32_t> d_level_tab;           // bin sort: class-list positions at every 64th global rank
+  DevBuf<uint32_t> d_elig_off, d_elig_cls, d_row_of;  // > 256 classes: eligible-class lists, the requests' rows
   DevBuf<uint64_t> d_mask;
   DevBuf<uint32_t> d_self_lo, d_self_hi, d_chunk_consuming, d_before, d_slot_of, d_pos_last;
   DevBuf<uint32_t> d_chunk_tail;  // consuming requests among the last kWarmUp of every chunk
@@ -285,7 +287,10 @@ struct ydc_context {
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
   bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
-  bool opt_walk_prefetch = true;  // the walk of the wide kernel with prefetch waves (YDC_WALK_PREFETCH=0: a lone wave)
+  // The walk of the wide kernel with prefetch waves (YDC_WALK_PREFETCH=1). Off: measured slower
+  // than the walker's own one-ahead fetch (57 against 35 ms of 100k picks; the scan was the cost).
+  bool opt_walk_prefetch = false;
+  bool opt_wide_lists = true;  // eligible-class lists for the wide kernel where every row is short (YDC_WIDE_LISTS=0: masks)
   bool opt_wide = true;  // > 256 classes: wave-per-chunk replay (YDC_WIDE=0: thread per chunk)
   bool opt_level_tab = true;  // bin sort leaves a level table for pass 0's guesses (YDC_LEVEL_TAB=0: search)
   // ydc_dispatch with page-locked caller buffers: no staging (YDC_ZERO_COPY=0 switches it off);
@@ -414,6 +419,15 @@ int rebuild_tables(ydc_context* c) {
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_cls_ver.p, c->tables.cls_ver.data(), C * 4,
                               hipMemcpyHostToDevice, c->stream));
+  }
+  if (!c->tables.elig_off.empty()) {
+    HIP_TRY(c, c->d_elig_off.reserve(c->tables.elig_off.size()));
+    HIP_TRY(c, c->d_elig_cls.reserve(std::max<size_t>(c->tables.elig_cls.size(), 1)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_elig_off.p, c->tables.elig_off.data(), c->tables.elig_off.size() * 4,
+                              hipMemcpyHostToDevice, c->stream));
+    if (!c->tables.elig_cls.empty())
+      HIP_TRY(c, hipMemcpyAsync(c->d_elig_cls.p, c->tables.elig_cls.data(), c->tables.elig_cls.size() * 4,
+                                hipMemcpyHostToDevice, c->stream));
   }
   if (!c->tables.env_ver_mask.empty()) {
     HIP_TRY(c, c->d_ver_sorted.reserve(c->tables.ver_sorted.size()));
@@ -612,6 +626,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
   if (const char* s = getenv("YDC_WIDE")) c->opt_wide = atoi(s) != 0;
   if (const char* s = getenv("YDC_WALK_PREFETCH")) c->opt_walk_prefetch = atoi(s) != 0;
+  if (const char* s = getenv("YDC_WIDE_LISTS")) c->opt_wide_lists = atoi(s) != 0;
   if (const char* s = getenv("YDC_GROUP_BINSORT")) c->opt_group_binsort = atoi(s) != 0;
   if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
   if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
@@ -1064,6 +1079,11 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     }
   }
   if (p.use_generic && !(C <= kMaxWideClasses && c->opt_wide)) HIP_TRY(c, c->d_runs.reserve((size_t)K * C + 1));
+  // Sparse eligibility (every (digest, version threshold) row names at most 64 classes): the wide
+  // kernel reads a request's classes from its row instead of scanning C / 64 mask words.
+  p.wide_lists = p.use_generic && C <= kMaxWideClasses && c->opt_wide && c->opt_wide_lists &&
+                 !c->tables.elig_off.empty() && c->tables.elig_max_len <= 64;
+  if (p.wide_lists) HIP_TRY(c, c->d_row_of.reserve(std::max(N, 1u)));
 
   p.sv = ServantTable{c->d_version.p, c->d_nproc.p,  c->d_load.p,     c->d_max_tasks.p,
                       c->d_running.p, c->d_flags.p, c->d_class_of.p, p.S};
@@ -1192,6 +1212,7 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       p.binsort ? 1u : 0u, p.binsort ? 1u : 0u};
   }
   ca.n_ip = (uint32_t)c->tables.ip_sorted.size();
+  ca.row_out = p.wide_lists && N && classify ? c->d_row_of.p : nullptr;
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
   const uint32_t bpp0 = c->kf.bits_per_pass;
@@ -1644,7 +1665,9 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
             YDC_LAUNCH(c, walk ? "k_sim_wide(walk)" : "k_sim_wide", k_sim_wide, dim3(walk ? 1u : p.K),
                        dim3(pf ? 256 : 64), wide_lds_bytes(p.C, pf), st, p.L, p.T, N, p.cs, p.K, gold,
                        c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
-                       walk ? (pf ? 2u : 1u) : 0u);
+                       walk ? (pf ? 2u : 1u) : 0u,
+                       p.wide_lists ? WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}
+                                    : WideLists{nullptr, nullptr, nullptr});
           } else {
             YDC_LAUNCH(c, "k_sim_generic", k_sim_generic, dim3(ceil_div(p.K, 64)), dim3(64), 0, st, p.L,
                        p.T, N, p.cs, p.K, gold, c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, c->d_runs.p,
