@@ -20,6 +20,7 @@ def main():
     L = binding.lib()
     L.ydc_debug_phase_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     sv, tk = synth.make_config("cfg2", n_envs=digests, n_tasks=n)
+    os.environ["YDC_WALK_PREFETCH"] = "1"
     ctx = binding.Context(device=0)
     ctx.upload_servants(pack.to_abi_columns(sv))
     DA = binding.DeviceArray
