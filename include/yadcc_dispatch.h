@@ -38,8 +38,10 @@ extern "C" {
 #define YDC_ERR_NOT_CONVERGED (-6)   /* internal invariant broken (never expected) */
 
 /* Servant classes = distinct (env set, version) signatures among servants with max_tasks != 0.
- * Batch dispatch takes up to 65535 (a slower kernel above 256); streaming and sharded
- * dispatch take up to 256. */
+ * Every entry point takes up to 65535. Up to 256 the lane-per-class kernel places the batch; above
+ * that a wave-per-chunk kernel (up to 3072 classes) or a thread-per-chunk kernel does, a streaming
+ * tick is enqueued instead of replayed from its captured graph, and the ranks of a group place
+ * the whole batch redundantly (same results, no speed-up). */
 #define YDC_MAX_CLASSES 65535u
 #define YDC_MAX_FAST_CLASSES 256u
 /* Interned compiler digests per 64-bit word of an environment mask. The number of words per

@@ -208,3 +208,27 @@ def test_stream_cfg5_200_ticks_against_the_reference():
             assert synth.placement_hash(ctx.get_running()) == int(fx["run_digest"][t]), t
     ctx.stream_end()
     ctx.close()
+
+
+def test_stream_more_than_256_classes_runs_eagerly():
+    """A registry with ~600 servant classes (150 digests, individual compiler sets): the step
+    cannot be captured (the many-class path has host-checked rounds), so every tick is enqueued
+    instead of replayed — same interface, same placement as the reference order."""
+    n_envs = 150
+    sv = synth.make_servants(700, n_tasks_hint=9000, n_envs=n_envs, seed=23)
+    es = streaming.EventStream(sv, 1500, 1000, n_envs=n_envs)
+    ctx = binding.Context(device=0)
+    ctx.upload_servants(pack.to_abi_columns(sv))
+    ctx.stream_begin(es.hb + 8, 1000, 1500)
+    for t in range(5):
+        who, rows, rel, tk = es.next_tick()
+        want, _, wrun = O.dispatch(es.registry_snapshot(), tk, "sorted")
+        got = ctx.stream_tick(who, rows, rel, tk, env_masks=es.abi["env_mask"][who])
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (t, bad[:5], got[bad[:5]], want[bad[:5]])
+        es.commit(got)
+        assert np.array_equal(ctx.get_running(), wrun), t
+        st = ctx.stats()
+        assert st["n_classes"] > 256 and st["granted"] == int((want < O.IDX_ENV_NOT_FOUND).sum())
+    ctx.stream_end()
+    ctx.close()

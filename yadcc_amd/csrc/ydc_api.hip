@@ -144,7 +144,7 @@ struct ydc_context {
   // Pipelined batches (ydc_dispatch_device_async / ydc_dispatch_wait): up to two batches are
   // enqueued before the host looks at the outcome of the older one.
   struct Pending {
-    bool active = false, rerun = false, done_sync = false;
+    bool active = false, rerun = false;
     BatchPlan plan;
     ydc_task_soa tk{};
     uint32_t n = 0, flags = 0, launched = 0;
@@ -153,7 +153,6 @@ struct ydc_context {
     uint32_t* out_running = nullptr;
     DeviceParams* h_outcome = nullptr;  // pinned
     hipEvent_t ev = nullptr;
-    int sync_rc = 0;
   } pend[2];
   uint32_t pend_head = 0, pend_count = 0;
   bool enqueue_pipelined = false;  // the finalise being enqueued belongs to a pipelined batch
@@ -227,6 +226,7 @@ struct ydc_context {
     hipGraphExec_t exec = nullptr;
     BatchPlan plan;
     uint64_t ticks = 0, recaptures = 0, eager_fallbacks = 0;
+    bool eager_only = false;  // the registry's batches cannot be captured (> 256 classes): every tick runs eagerly
     // Passes to capture: one more than the last eager batch needed, to begin with; after 256
     // ticks that all needed fewer, exactly the most any of them needed (a pre-launched pass
     // that finds nothing to do still costs a launch); more again after a tick that ran out.
@@ -1766,7 +1766,7 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
   if (!pd.h_outcome) HIP_TRY(c, hipHostMalloc((void**)&pd.h_outcome, sizeof(DeviceParams)));
   if (!pd.ev) HIP_TRY(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
   pd.active = true;
-  pd.rerun = pd.done_sync = false;
+  pd.rerun = false;
   pd.tk = tk ? *tk : ydc_task_soa{};
   pd.n = N;
   pd.flags = flags;
@@ -2763,9 +2763,15 @@ int stream_capture(ydc_context* c) {
   c->profiling = false;  // no event pairs inside a capture
   // Sizes and workspace first (allocations and table uploads cannot be captured).
   if (int rc = plan_batch(c, sm.max_tasks, &sm.plan)) return rc;
-  if (sm.plan.use_generic)
-    return fail(c, YDC_ERR_TOO_MANY_CLASSES, "streaming mode needs <= %u servant classes",
-                kMaxWaveClasses);
+  if (sm.plan.use_generic) {
+    // More than 256 servant classes: the rounds of that path are checked by the host, which a
+    // captured step cannot do — such ticks run eagerly (ydc_stream_tick_wide, below).
+    c->profiling = was_profiling;
+    sm.eager_only = true;
+    sm.stale = false;
+    return YDC_OK;
+  }
+  sm.eager_only = false;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   sm.passes = sm.want_passes ? sm.want_passes : std::max(2u, std::min(c->round_hint + 1, 12u));
   sm.window_max = sm.window_ticks = 0;
@@ -2962,6 +2968,32 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
     sm.h_env[i] = 0xFFFFFFFFu;  // a digest nobody has: EnvironmentNotFound, consumes nothing
     sm.h_minv[i] = 0;
     sm.h_ip[i] = 0;
+  }
+  if (sm.eager_only) {
+    // The same step, enqueued instead of replayed: staging copy, registry deltas, the batch with
+    // its host-checked rounds, COMMIT, results back.
+    ++sm.eager_fallbacks;
+    HIP_TRY(c, hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (sm.max_upd + sm.max_rel) {
+      const uint32_t upd_blocks = ceil_div(sm.max_upd, 256);
+      hipLaunchKernelGGL(k_apply_tick, dim3(upd_blocks + ceil_div(sm.max_rel, 256)), dim3(256), 0, c->stream,
+                         sm.d_upd_idx, sm.d_upd_rows, sm.max_upd, upd_blocks, sm.d_rel, sm.max_rel,
+                         c->n_servants, c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p,
+                         c->d_flags.p, c->d_running.p);
+    }
+    BatchPlan pe;
+    if (int rc = plan_batch(c, sm.max_tasks, &pe)) return rc;
+    ydc_task_soa d{sm.d_env, sm.d_minv, sm.d_ip};
+    uint32_t rounds_e = 0;
+    if (int rc = run_planned_batch(c, pe, &d, YDC_DISPATCH_COMMIT, c->d_out_idx.p, nullptr, nullptr, &rounds_e))
+      return rc;
+    HIP_TRY(c, hipMemcpy(sm.h_out, c->d_out_idx.p, (size_t)sm.max_tasks * 4, hipMemcpyDeviceToHost));
+    ++sm.ticks;
+    fill_stats(c, pe, rounds_e);
+    c->stats.n_tasks = n_tasks;
+    c->stats.env_not_found -= std::min(c->stats.env_not_found, sm.max_tasks - n_tasks);  // padding
+    if (n_tasks) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
+    return YDC_OK;
   }
   HIP_TRY(c, hipGraphLaunch(sm.exec, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
