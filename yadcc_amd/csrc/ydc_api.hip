@@ -984,6 +984,10 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     p.cs = 64;
     while (p.cs < want && p.cs < 8192) p.cs <<= 1;
   }
+  // The many-class kernels replay whole chunks per round (no checkpoints): chunks long enough
+  // for a wrong start to heal inside them keep the rounds few (cfg2 with 10 digests, 947 classes:
+  // 16 / 10 / 6 / 4 rounds at 64 / 128 / 256 / 512 requests; 3.0 / 2.6 / 2.5 / 2.9 ms).
+  if (p.use_generic && c->opt_chunk_size == 0) p.cs = std::max(p.cs, 256u);
   p.K = N ? ceil_div(N, p.cs) : 0;
   const uint32_t C = p.C, K = p.K, W = p.W, slot_bound = p.slot_bound;
 
