@@ -323,6 +323,15 @@ __global__ __launch_bounds__(256) void k_front_bins(ServantTable sv, uint32_t n_
                                                     uint32_t comp_shift, uint32_t gbits, BinTable bt,
                                                     uint32_t* owner, uint2* stage, ClassifyArgs ca) {
   const uint32_t blk = blockIdx.x;
+#ifdef YDC_PHASE_PROBE
+  if (threadIdx.x == 0 && blk < 2400) ydc_phase_probe[40000 + blk * 2] = wall_clock64();
+  struct ProbeEnd {
+    uint32_t b;
+    __device__ ~ProbeEnd() {
+      if (threadIdx.x == 0 && b < 2400) ydc_phase_probe[40000 + b * 2 + 1] = wall_clock64();
+    }
+  } probe_end{blk};
+#endif
   if (blk < bt.n_bins) {
     front_bin_boundary(sv, n_classes, parts, cap_bits, comp_shift, bt, blk + 1, max_slots, slot_base,
                        cls_begin, prm);
@@ -373,8 +382,18 @@ struct BinSortArgs {
 __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, DeviceParams* prm, PrefixArgs pa) {
   extern __shared__ __attribute__((aligned(16))) uint32_t bsm[];
   __shared__ uint32_t lds[17];
+#ifdef YDC_PHASE_PROBE
+#define YDC_BPROBE(slot)                                                                              \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 2100) ydc_phase_probe[46000 + blockIdx.x * 6 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define YDC_BPROBE(slot) do { } while (0)
+#endif
+  YDC_BPROBE(0);
   if (blockIdx.x == a.bt.n_bins) {
     chunk_prefix_block(pa, prm);
+    YDC_BPROBE(5);
     return;
   }
   uint32_t* buf0 = bsm;
@@ -428,6 +447,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
       return;
     }
   }
+  YDC_BPROBE(1);  // run table read, tile starts scanned
 #pragma unroll
   for (int k = 0; k < (int)kBinRounds; ++k) {
     const uint32_t i = k * kBinThreads + threadIdx.x;
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
     }
   }
   __syncthreads();
+  YDC_BPROBE(2);  // records staged in LDS
   // ---- (2) stable counting passes over the key bits below the bin, 8 at a time
   uint32_t* src = buf0;
   uint32_t* dst = buf1;
@@ -507,6 +528,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
     src = dst;
     dst = t;
   }
+  YDC_BPROBE(3);  // counting passes done
   // ---- (3) places. Positions are walked 1024 at a time; within a round (wave, lane) order ==
   // position order, so "earlier slots of the same class" = earlier rounds (cbase) + earlier
   // waves of this round (tab) + lower lanes of this wave (ballot match on the class bits).
@@ -567,6 +589,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
     }
     __syncthreads();
   }
+  YDC_BPROBE(4);  // places written
 }
 
 }  // namespace ydc

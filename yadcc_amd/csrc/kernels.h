@@ -62,6 +62,14 @@ struct DeviceParams {
   uint32_t pipeline_broken;
 };
 
+// Measurement builds only (`make probe`): wall-clock stamps the kernels leave behind
+// (match_kernel.h: k_match_pass phases per chunk; bin_sort.h: the front's workgroups and
+// k_bin_sort's phases; wide_kernel.h: the walk's accumulators). Compiled out of the product.
+#ifdef YDC_PHASE_PROBE
+constexpr uint32_t kProbeSlots = 12, kProbeChunks = 8192;
+__device__ unsigned long long ydc_phase_probe[kProbeChunks * kProbeSlots];
+#endif
+
 struct ServantTable {
   const uint32_t* version;
   const uint32_t* nproc;

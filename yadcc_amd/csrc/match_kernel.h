@@ -66,8 +66,6 @@ constexpr uint32_t kPassSlots = 64;  // DeviceParams::n_changed is indexed by pa
 // tools/phase_probe.py): lane 0 of every wave leaves the 100 MHz wall clock at its phase
 // boundaries. Compiled out of the product library.
 #ifdef YDC_PHASE_PROBE
-constexpr uint32_t kProbeSlots = 12, kProbeChunks = 8192;
-__device__ unsigned long long ydc_phase_probe[kProbeChunks * kProbeSlots];
 #define YDC_PROBE(chunk, slot)                                                          \
   do {                                                                                  \
     if (threadIdx.x == 0 && (chunk) < kProbeChunks)                                     \
