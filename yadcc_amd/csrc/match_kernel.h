@@ -342,23 +342,32 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 }
 
 
-// The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs up to
-// n (>= 1) requests i, i+1, ... while each of them is "plain". Returns
-//   0  n requests done,
+// The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs requests
+// i, i+1, ... < end (i < end) while each of them is "plain". Returns
+//   0  all of them done,
 //   1  request i needs the general step (the requests before it were done).
 // `special` marks the requests of the block that need a look first: `hole_hit` ones (an
 // eligible class has holes) leave at once; `has_self` ones leave only if an eligible class
 // shows a slot of the requestor's own servant at its head, or if nothing is left for them
-// (last-resort self pick). Requests whose eligible classes are all exhausted keep the
-// default in `res`; a served request gets the global rank of its slot. The caller
-// guarantees that every ring holds at least n + 2 entries beyond its cursor.
+// (last-resort self pick). Requests whose eligible classes are all exhausted leave their
+// lane of `raw` alone; a served request gets ~(global rank of its slot) there (never 0; the
+// caller turns it into the rank once per block). The caller guarantees that every ring holds
+// at least end - i + 2 entries beyond its cursor.
+//
+// What bounds the loop is the number of instructions per request, whatever their kind
+// (a wave issues one every 4-5 cycles): the loop control and the "is the next request
+// plain" test are one bit test on a mask worked out before the loop (`go`: plain and below
+// `end`, bit 0 clear so that index 64 — which wraps to bit 0 — ends the loop too; `pairok`:
+// both i and i + 1 are), the requests' masks come from copies of the mask register shifted
+// by one, two and three lanes (the lane select is the request index itself: no second
+// counter), and results are written as they come out of the reduction.
 //
 // Registers: hq / nq = ~rank of head / next of the lane's class (0: none), `an` = LDS address
 // of `next` in the lane's ring of ring_p (rings are aligned to their size, so stepping is an
 // add + bit-field insert; the cursor is recovered from `an` by the caller), ring_g `goff` bytes
-// further (behind all of ring_p). m0 = i,
-// s[90:91] = class mask of request i (fetched one request ahead, in the wait states of
-// the DPP chain), s[92:93] scratch. One loop body per DPP depth (2^steps >= classes).
+// further (behind all of ring_p). m0 = i, s[90:91] = class mask of request i (fetched one
+// request ahead, in the wait states of the DPP chain), s[94:97] scratch. One loop body per DPP
+// depth (2^steps >= classes).
 // Wait states (gfx940/gfx950): VALU-written SGPR -> VALU read 2, VALU-written VGPR ->
 // DPP read 2, VALU-written VGPR -> v_readlane 1.
 #define YDC_MAXDPP(first, ctrl) "v_max_u32_dpp %[t], " first " " ctrl " bound_ctrl:0\n"
@@ -366,8 +375,8 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_RED_1(K) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")
 // HI: how the upper mask word of the next request gets into s91 in the gap behind the first
 // step — a v_readlane, or nothing at all with <= 32 classes (the word is always 0 and s91
-// stays 0: one VALU instruction less per request in a loop that is bound by VALU issue).
-#define YDC_HI_READ "v_readlane_b32 s91, %[mhi], %[ip]\ns_nop 0\n"
+// stays 0: one VALU instruction less per request).
+#define YDC_HI_READ "v_readlane_b32 s91, %[m1hi], m0\ns_nop 0\n"
 #define YDC_HI_ZERO "s_nop 1\n"
 #define YDC_RED_2(K, HI) YDC_RED_1(K) HI \
   YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")
@@ -375,123 +384,116 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_RED_4(K, HI) YDC_RED_3(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:8 row_mask:0xf bank_mask:0xf")
 #define YDC_RED_5(K, HI) YDC_RED_4(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
 #define YDC_RED_6(K, HI) YDC_RED_5(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:31 row_mask:0xc bank_mask:0xf")
-// With one step there is no gap to hide anything in (one wait state before the v_readlane).
-#define YDC_TAILFILL_1 "s_nop 0\n"
-#define YDC_TAILFILL_N "s_nop 0\n"
+#define YDC_TAILFILL "s_nop 0\n"
 
-// Two requests per iteration (>= 5 classes): the two selections and DPP chains are
-// independent until the winners are known, so they fill each other's wait states; when the
-// winners are different lanes (the usual case with many classes) both advance under one exec
-// mask, otherwise only the first request is committed and the second one starts the next
-// iteration. Plain requests only (neither of the two `special`), and both served.
-// s[92:93] = class mask of the second request, s[94:95] = its winner, s[96:97] scratch;
-// %[s0] / %[s1] double as the second request's maximum / result.
-#define YDC_MAX2(dst, first, ctrl) "v_max_u32_dpp " dst ", " first " " ctrl " bound_ctrl:0\n"
-#define YDC_P1                                                                        \
-  YDC_MAX2("%[t]", "%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")              \
-  "v_readlane_b32 s90, %[mlo], %[ip]\n"                                               \
-  YDC_MAX2("%[t1]", "%[c1], %[c1]", "row_shr:1 row_mask:0xf bank_mask:0xf")
-#define YDC_P2(HIFILL)                                                                \
-  YDC_MAX2("%[t]", "%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")              \
-  HIFILL                                                                              \
-  YDC_MAX2("%[t1]", "%[t1], %[t1]", "row_shr:2 row_mask:0xf bank_mask:0xf")
-#define YDC_PN(ctrl)                                                                  \
-  YDC_MAX2("%[t]", "%[t], %[t]", ctrl) "s_nop 0\n" YDC_MAX2("%[t1]", "%[t1], %[t1]", ctrl)
-#define YDC_P2_HI "v_readlane_b32 s91, %[mhi], %[ip]\n"
-#define YDC_P2_ZERO "s_nop 0\n"
-#define YDC_PRED_3(F) YDC_P1 YDC_P2(F) YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf")
-#define YDC_PRED_4(F) YDC_PRED_3(F) YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf")
-#define YDC_PRED_5(F) YDC_PRED_4(F) YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf")
-#define YDC_PRED_6(F) YDC_PRED_5(F) YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf")
-#define YDC_COMMIT                                                                    \
-  "s_waitcnt lgkmcnt(0)\n"                                                            \
+// The winning lane(s) advance (exec = winners; the read of `next` issued by the lane's
+// previous win has been waited for).
+#define YDC_ADVANCE                                                                   \
   "v_mov_b32 %[hq], %[nq]\n"                                                          \
   "v_add_u32 %[a], 4, %[an]\n"                                                        \
   "v_bfi_b32 %[an], %[rmask4], %[a], %[an]\n"                                         \
   "ds_read_b32 %[nq], %[an]\n"                                                        \
   "s_mov_b64 exec, -1\n"
-#define YDC_PAIR_HI93 "v_readlane_b32 s93, %[mhi], %[ip]\n"
-#define YDC_PAIR_ZERO93 "s_mov_b32 s93, 0\n"
-#define YDC_PAIR(K, PRED, LASTLANE, HI93)                                             \
-  "s_cmp_eq_u32 %[pair], 0\n"                                                         \
-  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
-  "s_cmp_eq_u32 %[n], 0\n"                                                            \
-  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
-  "s_lshr_b64 s[96:97], %[special], m0\n"                                             \
-  "s_and_b32 s96, s96, 3\n"                                                           \
-  "s_cbranch_scc1 L" #K "_single%=\n"                                                 \
-  "s_add_u32 %[ip], %[ip], 1\n"                                                       \
-  "v_readlane_b32 s92, %[mlo], %[ip]\n"                                               \
-  HI93                                                                                \
+
+// Two requests per iteration (>= 5 classes): the two selections and DPP chains are
+// independent until the winners are known, so they fill each other's wait states — and the
+// slots left over fetch the masks of the two requests after them, so that a pair that follows
+// a pair starts with both masks in place. When the winners are different lanes (the usual case
+// with many classes) both advance under one exec mask, otherwise only the first request is
+// committed and the second one starts the next iteration. Plain requests only, and both
+// served (a timeout among them: back to the single step).
+// s[92:93] = class mask of the second request, s[94:95] = its winner; %[s0] doubles as the
+// second request's maximum.
+#define YDC_MAX2(dst, first, ctrl) "v_max_u32_dpp " dst ", " first " " ctrl " bound_ctrl:0\n"
+#define YDC_P1                                                                        \
+  YDC_MAX2("%[t]", "%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")              \
+  "v_readlane_b32 s92, %[m3lo], m0\n"                                                 \
+  YDC_MAX2("%[t1]", "%[c1], %[c1]", "row_shr:1 row_mask:0xf bank_mask:0xf")
+#define YDC_PN(ctrl, FILL)                                                            \
+  YDC_MAX2("%[t]", "%[t], %[t]", ctrl) FILL YDC_MAX2("%[t1]", "%[t1], %[t1]", ctrl)
+#define YDC_PF_NOP "s_nop 0\n"
+#define YDC_PF_HI91 "v_readlane_b32 s91, %[m2hi], m0\n"
+#define YDC_PF_HI93 "v_readlane_b32 s93, %[m3hi], m0\n"
+#define YDC_PRED_3(F2, F3) YDC_P1 YDC_PN("row_shr:2 row_mask:0xf bank_mask:0xf", F2)   \
+  YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf", F3)
+#define YDC_PRED_4(F2, F3) YDC_PRED_3(F2, F3) YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf", YDC_PF_NOP)
+#define YDC_PRED_5(F2, F3) YDC_PRED_4(F2, F3) YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf", YDC_PF_NOP)
+#define YDC_PRED_6(F2, F3) YDC_PRED_5(F2, F3) YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf", YDC_PF_NOP)
+// How a pair that does not follow a pair gets its second mask (two wait states before its use).
+#define YDC_PAIRPRE_LO "v_readlane_b32 s92, %[m1lo], m0\ns_nop 0\n"
+#define YDC_PAIRPRE_HI "v_readlane_b32 s92, %[m1lo], m0\nv_readlane_b32 s93, %[m1hi], m0\ns_nop 0\n"
+#define YDC_REREAD_LO ""
+#define YDC_REREAD_HI "v_readlane_b32 s91, %[mhi], m0\n"
+#define YDC_PAIRTEST(K)                                                               \
+  "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
+  "s_cbranch_scc1 L" #K "_pairbody%=\n"
+#define YDC_PAIRENTRY(K)                                                              \
+  "s_cmp_eq_u32 %[entry], 2\n"                                                        \
+  "s_cbranch_scc1 L" #K "_pairbody%=\n"
+#define YDC_PAIR(K, PRED, LASTLANE, PAIRPRE, REREAD)                                  \
+  "L" #K "_pairbody%=:\n" PAIRPRE                                                     \
+  "L" #K "_pairchain%=:\n"                                                            \
   "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                          \
-  "s_add_u32 %[ip], %[ip], 1\n"                                                       \
-  "v_cndmask_b32 %[c1], 0, %[hq], s[92:93]\n" PRED                                    \
+  "v_cndmask_b32 %[c1], 0, %[hq], s[92:93]\n"                                         \
+  "v_readlane_b32 s90, %[m2lo], m0\n" PRED                                            \
   "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                        \
   "v_readlane_b32 %[s0], %[t1], " LASTLANE "\n"                                       \
-  "s_cmp_eq_u32 %[mn], 0\n"                                                           \
+  "s_min_u32 %[sp], %[mn], %[s0]\n"                                                   \
+  "s_cmp_eq_u32 %[sp], 0\n"                                                           \
   "s_cbranch_scc1 L" #K "_bail%=\n"                                                   \
-  "s_cmp_eq_u32 %[s0], 0\n"                                                           \
-  "s_cbranch_scc1 L" #K "_bail%=\n"                                                   \
-  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
   "v_cmp_eq_u32_e64 s[94:95], %[s0], %[c1]\n"                                         \
-  "s_not_b32 %[sp], %[mn]\n"                                                          \
-  "s_not_b32 %[s1], %[s0]\n"                                                          \
+  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
+  "s_waitcnt lgkmcnt(0)\n"                                                            \
   "s_and_b64 s[96:97], vcc, s[94:95]\n"                                               \
   "s_cbranch_scc1 L" #K "_conflict%=\n"                                               \
-  "s_or_b64 exec, vcc, s[94:95]\n" YDC_COMMIT                                         \
-  "v_writelane_b32 %[res], %[sp], m0\n"                                               \
+  "s_or_b64 exec, vcc, s[94:95]\n" YDC_ADVANCE                                        \
+  "v_writelane_b32 %[raw], %[mn], m0\n"                                               \
   "s_add_u32 m0, m0, 1\n"                                                             \
-  "v_writelane_b32 %[res], %[s1], m0\n"                                               \
+  "v_writelane_b32 %[raw], %[s0], m0\n"                                               \
   "s_add_u32 m0, m0, 1\n"                                                             \
-  "s_add_u32 %[n], %[n], -2\n"                                                        \
-  "s_cbranch_scc1 L" #K "_loop%=\n"                                                   \
-  "s_branch L_out%=\n"                                                                \
+  "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
+  "s_cbranch_scc1 L" #K "_pairchain%=\n"                                              \
+  "s_bitcmp1_b64 %[go], m0\n"                                                         \
+  "s_cbranch_scc1 L" #K "_cont%=\n"                                                   \
+  "s_branch L" #K "_check%=\n"                                                        \
   "L" #K "_conflict%=:\n"                                                             \
-  "s_mov_b64 exec, vcc\n" YDC_COMMIT                                                  \
-  "v_writelane_b32 %[res], %[sp], m0\n"                                               \
-  "s_mov_b64 s[90:91], s[92:93]\n"                                                    \
+  "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                                 \
+  "v_writelane_b32 %[raw], %[mn], m0\n"                                               \
   "s_add_u32 m0, m0, 1\n"                                                             \
-  "s_add_u32 %[ip], %[ip], -1\n"                                                      \
-  "s_add_u32 %[n], %[n], -1\n"                                                        \
-  "s_branch L" #K "_loop%=\n"                                                         \
+  "v_readlane_b32 s90, %[mlo], m0\n" REREAD                                           \
+  "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
+  "s_cbranch_scc1 L" #K "_pairbody%=\n"                                               \
+  "s_nop 0\n"                                                                         \
+  "s_branch L" #K "_cont%=\n"                                                         \
   "L" #K "_bail%=:\n"                                                                 \
   "v_readlane_b32 s90, %[mlo], m0\n"                                                  \
   "v_readlane_b32 s91, %[mhi], m0\n"                                                  \
-  "s_add_u32 %[ip], %[ip], -2\n"                                                      \
   "s_nop 1\n"                                                                         \
   "s_branch L" #K "_cont%=\n"
 
-#define YDC_LOOP_BODY(K, RED, TAILFILL, LASTLANE, PAIR)                            \
-  "L" #K "_loop%=:\n" PAIR                                                         \
-  "L" #K "_single%=:\n"                                                            \
-  "s_bitcmp1_b64 %[special], m0\n"                                                 \
-  "s_cbranch_scc1 L" #K "_special%=\n"                                             \
+#define YDC_LOOP_BODY(K, RED, LASTLANE, PAIRENTRY, PAIRTEST, PAIR)                 \
+  "L" #K "_entry%=:\n"                                                             \
+  "s_cmp_eq_u32 %[entry], 1\n"                                                     \
+  "s_cbranch_scc1 L" #K "_cont%=\n" PAIRENTRY                                      \
+  "s_branch L" #K "_special%=\n" PAIR                                              \
   "L" #K "_cont%=:\n"                                                              \
   "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                       \
-  "s_add_u32 %[ip], %[ip], 1\n"                                                    \
-  "v_readlane_b32 s90, %[mlo], %[ip]\n" RED TAILFILL                               \
+  "s_nop 0\n"                                                                      \
+  "v_readlane_b32 s90, %[m1lo], m0\n" RED YDC_TAILFILL                             \
   "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                     \
   "s_cmp_eq_u32 %[mn], 0\n"                                                        \
   "s_cbranch_scc1 L" #K "_tmo%=\n"                                                 \
   "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                \
-  "s_not_b32 %[sp], %[mn]\n"                                                       \
-  "s_mov_b64 exec, vcc\n"                                                          \
   "s_waitcnt lgkmcnt(0)\n"                                                         \
-  "v_mov_b32 %[hq], %[nq]\n"                                                       \
-  "v_add_u32 %[a], 4, %[an]\n"                                                     \
-  "v_bfi_b32 %[an], %[rmask4], %[a], %[an]\n"                                      \
-  "ds_read_b32 %[nq], %[an]\n"                                                     \
-  "s_mov_b64 exec, -1\n"                                                           \
-  "v_writelane_b32 %[res], %[sp], m0\n"                                            \
+  "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                              \
+  "v_writelane_b32 %[raw], %[mn], m0\n"                                            \
   "L" #K "_next%=:\n"                                                              \
-  "s_add_u32 m0, m0, 1\n"                                                          \
-  "s_add_u32 %[n], %[n], -1\n"                                                     \
-  "s_cbranch_scc1 L" #K "_loop%=\n"                                                \
-  "s_branch L_out%=\n"                                                             \
-  "L" #K "_tmo%=:\n"                                                               \
-  "s_bitcmp1_b64 %[hs], m0\n"                                                      \
-  "s_cbranch_scc0 L" #K "_next%=\n"                                                \
-  "s_branch L_slow%=\n"                                                            \
+  "s_add_u32 m0, m0, 1\n" PAIRTEST                                                 \
+  "s_bitcmp1_b64 %[go], m0\n"                                                      \
+  "s_cbranch_scc1 L" #K "_cont%=\n"                                                \
+  "L" #K "_check%=:\n"                                                             \
+  "s_cmp_ge_u32 m0, %[end]\n"                                                      \
+  "s_cbranch_scc1 L_out%=\n"                                                       \
   "L" #K "_special%=:\n"                                                           \
   "s_bitcmp1_b64 %[hh], m0\n"                                                      \
   "s_cbranch_scc1 L_slow%=\n"                                                      \
@@ -505,64 +507,101 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "s_waitcnt lgkmcnt(0)\n"                                                         \
   "v_subrev_u32 %[a], %[s0], %[a]\n"                                               \
   "v_cmp_gt_u32 vcc, %[s1], %[a]\n"                                                \
-  "s_and_b64 s[92:93], vcc, s[90:91]\n"                                            \
+  "s_and_b64 s[96:97], vcc, s[90:91]\n"                                            \
   "s_cbranch_scc0 L" #K "_cont%=\n"                                                \
+  "s_branch L_slow%=\n"                                                            \
+  "L" #K "_tmo%=:\n"                                                               \
+  "s_bitcmp1_b64 %[hs], m0\n"                                                      \
+  "s_cbranch_scc0 L" #K "_next%=\n"                                                \
   "s_branch L_slow%=\n"
 
+// Lane l of the result holds lane l + d of v (d = 1 .. 3; the last lanes get anything).
+template <int D>
+__device__ __forceinline__ uint32_t lanes_down(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + D) & 63u) << 2), (int)v);
+}
+
+// The masks of a block's requests as the loop wants them: as staged, and shifted down by one,
+// two and three lanes.
+struct BlockMasks {
+  uint32_t lo, hi, lo1, hi1, lo2, hi2, lo3, hi3;
+};
+__device__ __forceinline__ BlockMasks block_masks(uint32_t mlo, uint32_t mhi, bool wide) {
+  BlockMasks m{mlo, mhi, lanes_down<1>(mlo), 0, lanes_down<2>(mlo), 0, lanes_down<3>(mlo), 0};
+  if (wide) {  // (more than 32 classes)
+    m.hi1 = lanes_down<1>(mhi);
+    m.hi2 = lanes_down<2>(mhi);
+    m.hi3 = lanes_down<3>(mhi);
+  }
+  return m;
+}
+
 __device__ __forceinline__ uint32_t match_fast_loop(
-    uint32_t& i, uint32_t n, uint32_t mlo, uint32_t mhi, uint32_t slo, uint32_t shi,
-    uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& res, uint32_t& hq,
+    uint32_t& i, uint32_t end, const BlockMasks& m, uint32_t slo, uint32_t shi,
+    uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& raw, uint32_t& hq,
     uint32_t& nq, uint32_t& an, uint32_t goff, uint32_t rmask4, uint32_t steps, uint32_t pair) {
-  uint32_t status, c, t, c1, t1, a, mn, sp, ip, s0, s1, m0save;
+  // Plain requests below `end`; index 64 wraps to bit 0, which therefore always says "stop".
+  const uint64_t plain = ~special & (end >= 64 ? ~0ull : (1ull << end) - 1);
+  const uint64_t go = plain & ~1ull;
+  const uint64_t pairok = pair ? go & (go >> 1) : 0ull;
+  uint32_t entry = (uint32_t)(plain >> i) & 1u;
+  if (entry && pair && i < 63 && ((plain >> (i + 1)) & 1)) entry = 2;
+  uint32_t status, c, t, c1, t1, a, mn, sp, s0, s1, m0save;
   asm volatile(
       "s_mov_b32 %[m0s], m0\n"
       "s_mov_b32 %[st], 0\n"
       "s_mov_b32 m0, %[i]\n"
-      "s_add_u32 %[ip], %[i], 0\n"
-      "s_add_u32 %[n], %[n], -1\n"
+      "s_mov_b32 s93, 0\n"
       "s_nop 2\n"
-      "v_readlane_b32 s90, %[mlo], %[ip]\n"
-      "v_readlane_b32 s91, %[mhi], %[ip]\n"
+      "v_readlane_b32 s90, %[mlo], m0\n"
+      "v_readlane_b32 s91, %[mhi], m0\n"
       "s_cmp_eq_u32 %[steps], 1\n"
-      "s_cbranch_scc1 L1_loop%=\n"
+      "s_cbranch_scc1 L1_entry%=\n"
       "s_cmp_eq_u32 %[steps], 2\n"
-      "s_cbranch_scc1 L2_loop%=\n"
+      "s_cbranch_scc1 L2_entry%=\n"
       "s_cmp_eq_u32 %[steps], 3\n"
-      "s_cbranch_scc1 L3_loop%=\n"
+      "s_cbranch_scc1 L3_entry%=\n"
       "s_cmp_eq_u32 %[steps], 4\n"
-      "s_cbranch_scc1 L4_loop%=\n"
+      "s_cbranch_scc1 L4_entry%=\n"
       "s_cmp_eq_u32 %[steps], 5\n"
-      "s_cbranch_scc1 L5_loop%=\n"
-      "s_branch L6_loop%=\n"
-      YDC_LOOP_BODY(1, YDC_RED_1(1), YDC_TAILFILL_1, "1", "")
-      YDC_LOOP_BODY(2, YDC_RED_2(2, YDC_HI_ZERO), YDC_TAILFILL_N, "3", "")
-      YDC_LOOP_BODY(3, YDC_RED_3(3, YDC_HI_ZERO), YDC_TAILFILL_N, "7",
-                    YDC_PAIR(3, YDC_PRED_3(YDC_P2_ZERO), "7", YDC_PAIR_ZERO93))
-      YDC_LOOP_BODY(4, YDC_RED_4(4, YDC_HI_ZERO), YDC_TAILFILL_N, "15",
-                    YDC_PAIR(4, YDC_PRED_4(YDC_P2_ZERO), "15", YDC_PAIR_ZERO93))
-      YDC_LOOP_BODY(5, YDC_RED_5(5, YDC_HI_ZERO), YDC_TAILFILL_N, "31",
-                    YDC_PAIR(5, YDC_PRED_5(YDC_P2_ZERO), "31", YDC_PAIR_ZERO93))
-      YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ), YDC_TAILFILL_N, "63",
-                    YDC_PAIR(6, YDC_PRED_6(YDC_P2_HI), "63", YDC_PAIR_HI93))
+      "s_cbranch_scc1 L5_entry%=\n"
+      "s_branch L6_entry%=\n"
+      YDC_LOOP_BODY(1, YDC_RED_1(1), "1", "", "", "")
+      YDC_LOOP_BODY(2, YDC_RED_2(2, YDC_HI_ZERO), "3", "", "", "")
+      YDC_LOOP_BODY(3, YDC_RED_3(3, YDC_HI_ZERO), "7", YDC_PAIRENTRY(3), YDC_PAIRTEST(3),
+                    YDC_PAIR(3, YDC_PRED_3(YDC_PF_NOP, YDC_PF_NOP), "7", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(4, YDC_RED_4(4, YDC_HI_ZERO), "15", YDC_PAIRENTRY(4), YDC_PAIRTEST(4),
+                    YDC_PAIR(4, YDC_PRED_4(YDC_PF_NOP, YDC_PF_NOP), "15", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(5, YDC_RED_5(5, YDC_HI_ZERO), "31", YDC_PAIRENTRY(5), YDC_PAIRTEST(5),
+                    YDC_PAIR(5, YDC_PRED_5(YDC_PF_NOP, YDC_PF_NOP), "31", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ), "63", YDC_PAIRENTRY(6), YDC_PAIRTEST(6),
+                    YDC_PAIR(6, YDC_PRED_6(YDC_PF_HI91, YDC_PF_HI93), "63", YDC_PAIRPRE_HI, YDC_REREAD_HI))
       "L_slow%=:\n"
       "s_mov_b32 %[st], 1\n"
       "L_out%=:\n"
       "s_mov_b32 %[i], m0\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b32 m0, %[m0s]\n"
-      : [st] "=&s"(status), [i] "+s"(i), [n] "+s"(n), [res] "+v"(res), [hq] "+v"(hq), [nq] "+v"(nq),
+      : [st] "=&s"(status), [i] "+s"(i), [raw] "+v"(raw), [hq] "+v"(hq), [nq] "+v"(nq),
         [an] "+v"(an), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
         [a] "=&v"(a), [mn] "=&s"(mn),
-        [sp] "=&s"(sp), [ip] "=&s"(ip), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
-      : [mlo] "v"(mlo), [mhi] "v"(mhi), [slo] "v"(slo), [shi] "v"(shi), [special] "s"(special),
+        [sp] "=&s"(sp), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
+      : [mlo] "v"(m.lo), [mhi] "v"(m.hi), [m1lo] "v"(m.lo1), [m1hi] "v"(m.hi1), [m2lo] "v"(m.lo2),
+        [m2hi] "v"(m.hi2), [m3lo] "v"(m.lo3), [m3hi] "v"(m.hi3), [slo] "v"(slo), [shi] "v"(shi),
+        [go] "s"(go), [pairok] "s"(pairok), [entry] "s"(entry), [end] "s"(end),
         [hh] "s"(hole_hit), [hs] "s"(has_self), [goff] "s"(goff), [rmask4] "s"(rmask4),
-        [steps] "s"(steps), [pair] "s"(pair)
+        [steps] "s"(steps)
       : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
   return status;
 }
 
-template <int W>
-__global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
+// OCC: waves per SIMD the register allocation leaves room for. A wave's pace does not depend on
+// the waves it shares the SIMD with (tests/tools/issue_probe.hip: one instruction every ~4.5
+// cycles per wave at 1, 2 or 3 waves per SIMD), so where a batch has more than two chunks per
+// SIMD to offer, a fourth resident wave is worth the two dozen registers spilled in the prologue
+// (OCC = 4: 128 VGPRs instead of 152).
+template <int W, int OCC = 1>
+__global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
                                                    MatchBuffers B, uint32_t pass_arg,
                                                    uint32_t flags, uint32_t rshift,
@@ -1131,6 +1170,8 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         const uint32_t base = (uint32_t)(uintptr_t)lds_ring + ((lane << rshift) << 2);
         const uint32_t rmask4 = (R << 2) - 1;
         const uint64_t my_mask = ((uint64_t)mhi[0] << 32) | mlo[0];
+        const BlockMasks bm = block_masks(mlo[0], mhi[0], steps > 5);
+        uint32_t raw = 0;  // ~rank of the slot of every request the fast loop served
         uint32_t i = 0;
         // The first block of a chunk pauses after kEarlyAt requests for the early checkpoint.
         uint32_t lim = tb == t0 && cnt > kEarlyAt ? kEarlyAt : cnt;
@@ -1143,9 +1184,9 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
           // Requests that need a look before the plain step: an eligible class has holes, or
           // the requestor's host runs several servants (`self` is resolved in the general step).
           const uint64_t hole_hit = (holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull) | dyn_self;
-          const uint32_t st = match_fast_loop(i, n, mlo[0], mhi[0], slo, shi, has_self | hole_hit,
-                                              hole_hit, has_self, res, q.hq, q.nq, an, ring_total << 2,
-                                              rmask4, steps,
+          const uint32_t st = match_fast_loop(i, i + n, bm, slo, shi, has_self | hole_hit, hole_hit,
+                                              has_self, raw, q.hq, q.nq, an, ring_total << 2, rmask4,
+                                              steps,
                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode));
           // Picks of this lane's class in the call (fewer than the ring holds): how far `next` moved.
           q.cursor += ((an - an0) & rmask4) >> 2;
@@ -1176,6 +1217,7 @@ __global__ __launch_bounds__(64) void k_match_pass(ClassLists L, TaskTable T, ui
         }
         lim = cnt;
         }
+        if (raw != 0) res = ~raw;
       } else {
         uint32_t budget = 0;
         for (uint32_t i = 0; i < cnt; ++i) {

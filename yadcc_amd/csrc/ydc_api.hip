@@ -77,6 +77,7 @@ struct BatchPlan {
   uint32_t N = 0, S = 0, C = 0, W = 1, slot_bound = 0, n_tiles = 1, cs = 64, K = 0;
   uint32_t key_passes = 0, cls_passes = 0, cls_bits = 0, rshift = 4, init_fill = 8, sort_items = 8;
   uint32_t ring_total = 2048;  // entries of all rings of a matching wave (x 8 B of LDS)
+  bool dense = false;  // the matching kernel's 4-waves-per-SIMD build (match_kernel.h: OCC)
   uint32_t fused_cls_bits = 0;  // class partition folded into the last key pass (kernels.h)
   uint32_t gbits = 0;  // != 0: the sort's values carry the class above gbits slot bits (SortIn)
   uint32_t slot_bound_glob = 0, win_margin = 0;  // (sharded sort: slot_bound is the window's)
@@ -272,7 +273,8 @@ struct ydc_context {
   uint32_t opt_target_chunks = 2048;
   // 16 KB of LDS per matching wave = 10 waves per CU. Smaller rings (more waves per CU, shorter
   // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
-  uint32_t opt_ring_total = 2048;
+  uint32_t opt_ring_total = 0;  // entries of a matching wave's rings; 0: chosen per batch (YDC_RING_TOTAL)
+  bool opt_dense = true;  // 4-waves-per-SIMD matching kernel and twice the chunks where it pays (YDC_DENSE=0)
   bool opt_fused_class = true;
   bool opt_own_guess = true;
   bool opt_pair = true;
@@ -616,6 +618,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
   if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
+  if (const char* s = getenv("YDC_RING_TOTAL")) c->opt_ring_total = std::max(256u, (uint32_t)atoi(s));
+  if (const char* s = getenv("YDC_DENSE")) c->opt_dense = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
@@ -983,6 +987,11 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     uint32_t want = ceil_div(std::max<uint32_t>(N, 1), std::max<uint32_t>(1, c->opt_target_chunks));
     p.cs = 64;
     while (p.cs < want && p.cs < 8192) p.cs <<= 1;
+    // Big batches: twice the chunks while they stay at 1024 requests or more — four waves per
+    // SIMD instead of two (cfg4, 4M requests: k_match_pass 373 -> 294 us). Shorter chunks cost
+    // more in wrong guesses and replays than the occupancy brings (cfg3 at 256 instead of 512
+    // requests per chunk: 395 -> 465 us).
+    if (c->opt_dense && p.W == 1 && p.cs >= 2048) p.cs >>= 1;
   }
   // The many-class kernels replay whole chunks per round (no checkpoints): chunks long enough
   // for a wrong start to heal inside them keep the rounds few (cfg2 with 10 digests, 947 classes:
@@ -1161,6 +1170,17 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
     p.ring_total = c->opt_ring_total;
+    // The 4-waves-per-SIMD build of the matching kernel for chunks long enough to amortise its
+    // spills (cfg2's chunks of 64 requests: 22.7 -> 23.1 us with it; cfg3's of 512: 426 -> 395),
+    // and rings small enough for all of a CU's waves to be resident (160 KB of LDS, 16 waves).
+    p.dense = c->opt_dense && p.W == 1 && p.cs >= 256;
+    if (p.dense && c->opt_ring_total == 0) {
+      const uint32_t per_cu = std::min<uint32_t>(16, std::max<uint32_t>(1, ceil_div(p.K, 256)));
+      p.ring_total = 2048;
+      while (p.ring_total > 256 && (size_t)per_cu * p.ring_total * 8 > 150 * 1024) p.ring_total >>= 1;
+    } else if (c->opt_ring_total == 0) {
+      p.ring_total = 2048;
+    }
     while (p.ring_total < 2048 && ((size_t)C << 3) > p.ring_total) p.ring_total <<= 1;  // >= 8 per class
     p.rshift = 3;
     while (p.rshift < 10 && ((size_t)C << (p.rshift + 1)) <= p.ring_total) ++p.rshift;
@@ -1408,7 +1428,10 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   device_check |= c->opt_pair ? 4u : 0u;
   device_check |= p.ring_total << 8;
   DeviceParams* prm = c->d_prm.p;
-  if (p.W == 1) {
+  if (p.W == 1 && p.dense) {
+    YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1, 4>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
+               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
+  } else if (p.W == 1) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
                p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
   } else if (p.W == 2) {
