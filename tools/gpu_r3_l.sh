@@ -19,3 +19,4 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
     except Exception as ex:
         print(os.path.basename(f), "ERR", ex); print(open(f.replace('.json','.err')).read()[-800:])
 PY
+timeout 100 build/fastloop_probe > $O/fastloop_probe.txt 2>&1; grep "waves/SIMD [02]" $O/fastloop_probe.txt

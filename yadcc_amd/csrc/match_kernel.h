@@ -372,19 +372,27 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 // DPP read 2, VALU-written VGPR -> v_readlane 1.
 #define YDC_MAXDPP(first, ctrl) "v_max_u32_dpp %[t], " first " " ctrl " bound_ctrl:0\n"
 #define YDC_GAP "s_nop 1\n"
-#define YDC_RED_1(K) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")
+// NZ: the lanes that offer the request anything at all (eligible, not exhausted), worked out in
+// a wait state of the reduction. The winner is looked for among them only, so a request nobody
+// can serve (maximum 0 = "no slot") selects no lane, advances nothing and writes 0 = "not
+// served" — the common path needs no test for it (a VALU -> SGPR -> compare -> branch hop costs
+// ~40 cycles, tests/tools/issue_probe.hip; a plain instruction 4.5).
+#define YDC_NZ "v_cmp_ne_u32_e64 s[94:95], 0, %[c]\n"
+#define YDC_RED_1(K) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf") YDC_NZ
 // HI: how the upper mask word of the next request gets into s91 in the gap behind the first
 // step — a v_readlane, or nothing at all with <= 32 classes (the word is always 0 and s91
 // stays 0: one VALU instruction less per request).
-#define YDC_HI_READ "v_readlane_b32 s91, %[m1hi], m0\ns_nop 0\n"
-#define YDC_HI_ZERO "s_nop 1\n"
-#define YDC_RED_2(K, HI) YDC_RED_1(K) HI \
-  YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")
-#define YDC_RED_3(K, HI) YDC_RED_2(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:4 row_mask:0xf bank_mask:0xf")
+#define YDC_HI_READ "v_readlane_b32 s91, %[m1hi], m0\n" YDC_NZ
+#define YDC_HI_ZERO YDC_NZ "s_nop 0\n"
+#define YDC_RED_2(K, HI) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf") HI \
+  YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+#define YDC_RED_3(K, HI) YDC_MAXDPP("%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf") HI \
+  YDC_MAXDPP("%[t], %[t]", "row_shr:2 row_mask:0xf bank_mask:0xf")                           \
+  YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:4 row_mask:0xf bank_mask:0xf")
 #define YDC_RED_4(K, HI) YDC_RED_3(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_shr:8 row_mask:0xf bank_mask:0xf")
 #define YDC_RED_5(K, HI) YDC_RED_4(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
 #define YDC_RED_6(K, HI) YDC_RED_5(K, HI) YDC_GAP YDC_MAXDPP("%[t], %[t]", "row_bcast:31 row_mask:0xc bank_mask:0xf")
-#define YDC_TAILFILL "s_nop 0\n"
+#define YDC_TAIL_NOP "s_nop 0\n"
 
 // The winning lane(s) advance (exec = winners; the read of `next` issued by the lane's
 // previous win has been waited for).
@@ -397,13 +405,13 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 
 // Two requests per iteration (>= 5 classes): the two selections and DPP chains are
 // independent until the winners are known, so they fill each other's wait states — and the
-// slots left over fetch the masks of the two requests after them, so that a pair that follows
-// a pair starts with both masks in place. When the winners are different lanes (the usual case
-// with many classes) both advance under one exec mask, otherwise only the first request is
-// committed and the second one starts the next iteration. Plain requests only, and both
-// served (a timeout among them: back to the single step).
-// s[92:93] = class mask of the second request, s[94:95] = its winner; %[s0] doubles as the
-// second request's maximum.
+// slots left over fetch the masks of the two requests after them (a pair that follows a pair
+// starts with both masks in place) and work out who offers each of the two anything. When the
+// winners are different lanes both advance under one exec mask, otherwise only the first
+// request is committed and the second one starts the next iteration. Plain requests only.
+// s[92:93] = class mask of the second request, s[94:95] = its winner, s[98:99] / s[88:89] =
+// the lanes with something to offer to the first / second; %[s0] doubles as the second
+// request's maximum.
 #define YDC_MAX2(dst, first, ctrl) "v_max_u32_dpp " dst ", " first " " ctrl " bound_ctrl:0\n"
 #define YDC_P1                                                                        \
   YDC_MAX2("%[t]", "%[c], %[c]", "row_shr:1 row_mask:0xf bank_mask:0xf")              \
@@ -414,11 +422,17 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 #define YDC_PF_NOP "s_nop 0\n"
 #define YDC_PF_HI91 "v_readlane_b32 s91, %[m2hi], m0\n"
 #define YDC_PF_HI93 "v_readlane_b32 s93, %[m3hi], m0\n"
-#define YDC_PRED_3(F2, F3) YDC_P1 YDC_PN("row_shr:2 row_mask:0xf bank_mask:0xf", F2)   \
-  YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf", F3)
-#define YDC_PRED_4(F2, F3) YDC_PRED_3(F2, F3) YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf", YDC_PF_NOP)
-#define YDC_PRED_5(F2, F3) YDC_PRED_4(F2, F3) YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf", YDC_PF_NOP)
-#define YDC_PRED_6(F2, F3) YDC_PRED_5(F2, F3) YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf", YDC_PF_NOP)
+#define YDC_PF_NZ0 "v_cmp_ne_u32_e64 s[98:99], 0, %[c]\n"
+#define YDC_PF_NZ1 "v_cmp_ne_u32_e64 s[88:89], 0, %[c1]\n"
+#define YDC_PRED_3 YDC_P1 YDC_PN("row_shr:2 row_mask:0xf bank_mask:0xf", YDC_PF_NZ0)   \
+  YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf", YDC_PF_NZ1)
+#define YDC_PRED_4 YDC_PRED_3 YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf", YDC_PF_NOP)
+#define YDC_PRED_5 YDC_PRED_4 YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf", YDC_PF_NOP)
+#define YDC_PRED_6 YDC_P1 YDC_PN("row_shr:2 row_mask:0xf bank_mask:0xf", YDC_PF_HI91)   \
+  YDC_PN("row_shr:4 row_mask:0xf bank_mask:0xf", YDC_PF_HI93)                           \
+  YDC_PN("row_shr:8 row_mask:0xf bank_mask:0xf", YDC_PF_NZ0)                            \
+  YDC_PN("row_bcast:15 row_mask:0xa bank_mask:0xf", YDC_PF_NZ1)                         \
+  YDC_PN("row_bcast:31 row_mask:0xc bank_mask:0xf", YDC_PF_NOP)
 // How a pair that does not follow a pair gets its second mask (two wait states before its use).
 #define YDC_PAIRPRE_LO "v_readlane_b32 s92, %[m1lo], m0\ns_nop 0\n"
 #define YDC_PAIRPRE_HI "v_readlane_b32 s92, %[m1lo], m0\nv_readlane_b32 s93, %[m1hi], m0\ns_nop 0\n"
@@ -438,59 +452,72 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "v_readlane_b32 s90, %[m2lo], m0\n" PRED                                            \
   "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                        \
   "v_readlane_b32 %[s0], %[t1], " LASTLANE "\n"                                       \
-  "s_min_u32 %[sp], %[mn], %[s0]\n"                                                   \
-  "s_cmp_eq_u32 %[sp], 0\n"                                                           \
-  "s_cbranch_scc1 L" #K "_bail%=\n"                                                   \
-  "v_cmp_eq_u32_e64 s[94:95], %[s0], %[c1]\n"                                         \
-  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
   "s_waitcnt lgkmcnt(0)\n"                                                            \
-  "s_and_b64 s[96:97], vcc, s[94:95]\n"                                               \
-  "s_cbranch_scc1 L" #K "_conflict%=\n"                                               \
-  "s_or_b64 exec, vcc, s[94:95]\n" YDC_ADVANCE                                        \
+  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
+  "v_cmp_eq_u32_e64 s[94:95], %[s0], %[c1]\n"                                         \
   "v_writelane_b32 %[raw], %[mn], m0\n"                                               \
   "s_add_u32 m0, m0, 1\n"                                                             \
   "v_writelane_b32 %[raw], %[s0], m0\n"                                               \
   "s_add_u32 m0, m0, 1\n"                                                             \
+  "s_and_b64 vcc, vcc, s[98:99]\n"                                                    \
+  "s_and_b64 s[94:95], s[94:95], s[88:89]\n"                                          \
+  "s_and_b64 s[96:97], vcc, s[94:95]\n"                                               \
+  "s_cbranch_scc1 L" #K "_conflict%=\n"                                               \
+  "s_or_b64 exec, vcc, s[94:95]\n" YDC_ADVANCE                                        \
   "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
   "s_cbranch_scc1 L" #K "_pairchain%=\n"                                              \
   "s_bitcmp1_b64 %[go], m0\n"                                                         \
   "s_cbranch_scc1 L" #K "_cont%=\n"                                                   \
   "s_branch L" #K "_check%=\n"                                                        \
   "L" #K "_conflict%=:\n"                                                             \
+  "s_add_u32 m0, m0, -1\n"                                                            \
   "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                                 \
-  "v_writelane_b32 %[raw], %[mn], m0\n"                                               \
-  "s_add_u32 m0, m0, 1\n"                                                             \
+  "v_writelane_b32 %[raw], 0, m0\n"                                                   \
   "v_readlane_b32 s90, %[mlo], m0\n" REREAD                                           \
   "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
   "s_cbranch_scc1 L" #K "_pairbody%=\n"                                               \
   "s_nop 0\n"                                                                         \
-  "s_branch L" #K "_cont%=\n"                                                         \
-  "L" #K "_bail%=:\n"                                                                 \
-  "v_readlane_b32 s90, %[mlo], m0\n"                                                  \
-  "v_readlane_b32 s91, %[mhi], m0\n"                                                  \
-  "s_nop 1\n"                                                                         \
   "s_branch L" #K "_cont%=\n"
 
-#define YDC_LOOP_BODY(K, RED, LASTLANE, PAIRENTRY, PAIRTEST, PAIR)                 \
+// One request: select, reduce, (ZCHECK: leave if nobody serves it — only the requests that
+// came through the `special` test need that: their last resort is the general step), commit.
+#define YDC_ZCHECK_NONE ""
+#define YDC_ZCHECK(K)                                                                 \
+  "s_cmp_eq_u32 %[mn], 0\n"                                                           \
+  "s_cbranch_scc1 L" #K "_tmo%=\n"
+#define YDC_SINGLE(K, SFX, RED, LASTLANE, ZCHECK, CONTROL)                            \
+  "L" #K "_cont" SFX "%=:\n"                                                          \
+  "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                          \
+  "s_nop 0\n"                                                                         \
+  "v_readlane_b32 s90, %[m1lo], m0\n" RED                                             \
+  "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                        \
+  "s_mov_b64 exec, s[94:95]\n"                                                        \
+  "s_waitcnt lgkmcnt(0)\n" ZCHECK                                                     \
+  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                   \
+  "v_writelane_b32 %[raw], %[mn], m0\n"                                               \
+  "s_add_u32 m0, m0, 1\n" CONTROL
+// Loop control behind a request. Without pairs the "is the next request plain" test sits in
+// the shadow of the winner compare (nothing between it and the branch touches SCC).
+#define YDC_CONTROL_PLAIN(K)                                                          \
+  "s_bitcmp1_b64 %[go], m0\n"                                                         \
+  "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                                 \
+  "s_cbranch_scc1 L" #K "_cont%=\n"                                                   \
+  "s_branch L" #K "_check%=\n"
+#define YDC_CONTROL_PAIRS(K)                                                          \
+  "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                                 \
+  "s_bitcmp1_b64 %[pairok], m0\n"                                                     \
+  "s_cbranch_scc1 L" #K "_pairbody%=\n"                                               \
+  "s_bitcmp1_b64 %[go], m0\n"                                                         \
+  "s_cbranch_scc1 L" #K "_cont%=\n"                                                   \
+  "s_branch L" #K "_check%=\n"
+
+#define YDC_LOOP_BODY(K, RED, LASTLANE, PAIRENTRY, CONTROL, PAIR)                  \
   "L" #K "_entry%=:\n"                                                             \
   "s_cmp_eq_u32 %[entry], 1\n"                                                     \
   "s_cbranch_scc1 L" #K "_cont%=\n" PAIRENTRY                                      \
   "s_branch L" #K "_special%=\n" PAIR                                              \
-  "L" #K "_cont%=:\n"                                                              \
-  "v_cndmask_b32 %[c], 0, %[hq], s[90:91]\n"                                       \
-  "s_nop 0\n"                                                                      \
-  "v_readlane_b32 s90, %[m1lo], m0\n" RED YDC_TAILFILL                             \
-  "v_readlane_b32 %[mn], %[t], " LASTLANE "\n"                                     \
-  "s_cmp_eq_u32 %[mn], 0\n"                                                        \
-  "s_cbranch_scc1 L" #K "_tmo%=\n"                                                 \
-  "v_cmp_eq_u32 vcc, %[mn], %[c]\n"                                                \
-  "s_waitcnt lgkmcnt(0)\n"                                                         \
-  "s_mov_b64 exec, vcc\n" YDC_ADVANCE                                              \
-  "v_writelane_b32 %[raw], %[mn], m0\n"                                            \
-  "L" #K "_next%=:\n"                                                              \
-  "s_add_u32 m0, m0, 1\n" PAIRTEST                                                 \
-  "s_bitcmp1_b64 %[go], m0\n"                                                      \
-  "s_cbranch_scc1 L" #K "_cont%=\n"                                                \
+  YDC_SINGLE(K, "", RED, LASTLANE, YDC_ZCHECK_NONE, CONTROL)                       \
+  YDC_SINGLE(K, "_self", RED, LASTLANE, YDC_ZCHECK(K), CONTROL)                    \
   "L" #K "_check%=:\n"                                                             \
   "s_cmp_ge_u32 m0, %[end]\n"                                                      \
   "s_cbranch_scc1 L_out%=\n"                                                       \
@@ -508,11 +535,10 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "v_subrev_u32 %[a], %[s0], %[a]\n"                                               \
   "v_cmp_gt_u32 vcc, %[s1], %[a]\n"                                                \
   "s_and_b64 s[96:97], vcc, s[90:91]\n"                                            \
-  "s_cbranch_scc0 L" #K "_cont%=\n"                                                \
+  "s_cbranch_scc0 L" #K "_cont_self%=\n"                                           \
   "s_branch L_slow%=\n"                                                            \
   "L" #K "_tmo%=:\n"                                                               \
-  "s_bitcmp1_b64 %[hs], m0\n"                                                      \
-  "s_cbranch_scc0 L" #K "_next%=\n"                                                \
+  "s_mov_b64 exec, -1\n"                                                           \
   "s_branch L_slow%=\n"
 
 // Lane l of the result holds lane l + d of v (d = 1 .. 3; the last lanes get anything).
@@ -566,16 +592,16 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_cmp_eq_u32 %[steps], 5\n"
       "s_cbranch_scc1 L5_entry%=\n"
       "s_branch L6_entry%=\n"
-      YDC_LOOP_BODY(1, YDC_RED_1(1), "1", "", "", "")
-      YDC_LOOP_BODY(2, YDC_RED_2(2, YDC_HI_ZERO), "3", "", "", "")
-      YDC_LOOP_BODY(3, YDC_RED_3(3, YDC_HI_ZERO), "7", YDC_PAIRENTRY(3), YDC_PAIRTEST(3),
-                    YDC_PAIR(3, YDC_PRED_3(YDC_PF_NOP, YDC_PF_NOP), "7", YDC_PAIRPRE_LO, YDC_REREAD_LO))
-      YDC_LOOP_BODY(4, YDC_RED_4(4, YDC_HI_ZERO), "15", YDC_PAIRENTRY(4), YDC_PAIRTEST(4),
-                    YDC_PAIR(4, YDC_PRED_4(YDC_PF_NOP, YDC_PF_NOP), "15", YDC_PAIRPRE_LO, YDC_REREAD_LO))
-      YDC_LOOP_BODY(5, YDC_RED_5(5, YDC_HI_ZERO), "31", YDC_PAIRENTRY(5), YDC_PAIRTEST(5),
-                    YDC_PAIR(5, YDC_PRED_5(YDC_PF_NOP, YDC_PF_NOP), "31", YDC_PAIRPRE_LO, YDC_REREAD_LO))
-      YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ), "63", YDC_PAIRENTRY(6), YDC_PAIRTEST(6),
-                    YDC_PAIR(6, YDC_PRED_6(YDC_PF_HI91, YDC_PF_HI93), "63", YDC_PAIRPRE_HI, YDC_REREAD_HI))
+      YDC_LOOP_BODY(1, YDC_RED_1(1), "1", "", YDC_CONTROL_PLAIN(1), "")
+      YDC_LOOP_BODY(2, YDC_RED_2(2, YDC_HI_ZERO), "3", "", YDC_CONTROL_PLAIN(2), "")
+      YDC_LOOP_BODY(3, YDC_RED_3(3, YDC_HI_ZERO) YDC_TAIL_NOP, "7", YDC_PAIRENTRY(3), YDC_CONTROL_PAIRS(3),
+                    YDC_PAIR(3, YDC_PRED_3, "7", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(4, YDC_RED_4(4, YDC_HI_ZERO) YDC_TAIL_NOP, "15", YDC_PAIRENTRY(4), YDC_CONTROL_PAIRS(4),
+                    YDC_PAIR(4, YDC_PRED_4, "15", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(5, YDC_RED_5(5, YDC_HI_ZERO) YDC_TAIL_NOP, "31", YDC_PAIRENTRY(5), YDC_CONTROL_PAIRS(5),
+                    YDC_PAIR(5, YDC_PRED_5, "31", YDC_PAIRPRE_LO, YDC_REREAD_LO))
+      YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ) YDC_TAIL_NOP, "63", YDC_PAIRENTRY(6), YDC_CONTROL_PAIRS(6),
+                    YDC_PAIR(6, YDC_PRED_6, "63", YDC_PAIRPRE_HI, YDC_REREAD_HI))
       "L_slow%=:\n"
       "s_mov_b32 %[st], 1\n"
       "L_out%=:\n"
@@ -591,7 +617,8 @@ __device__ __forceinline__ uint32_t match_fast_loop(
         [go] "s"(go), [pairok] "s"(pairok), [entry] "s"(entry), [end] "s"(end),
         [hh] "s"(hole_hit), [hs] "s"(has_self), [goff] "s"(goff), [rmask4] "s"(rmask4),
         [steps] "s"(steps)
-      : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
+      : "vcc", "scc", "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+        "s98", "s99");
   return status;
 }
 
