@@ -973,16 +973,66 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   };
   // Refills every ring that is running low; returns how many picks are safe before the
   // next look (every ring keeps the entry after next).
+  // Up to four rings in one memory round trip: all their loads are in flight before the first
+  // LDS store (one refill at a time exposes a round trip per class, and classes that started
+  // with equally full rings run low together).
+  auto refill_group = [&](uint64_t& need, int bj) {
+    uint32_t g_cl[4], g_from[4], g_to[4], g_end[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g_cl[u] = g_from[u] = g_to[u] = g_end[u] = 0;
+      if (need) {
+        const uint32_t cc = (uint32_t)__builtin_ctzll(need);
+        need &= need - 1;
+        uint32_t f_cl = 0, f_from = 0, f_to = 0, f_end = 0;
+        if (lane == cc) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            if (j == bj) {
+              LaneClass& q = w.k[j];
+              if (q.filled < q.cursor) q.filled = q.cursor;
+              f_cl = lane + 64 * j;
+              f_from = q.filled;
+              f_to = min(q.filled + 64u, q.cursor + R);
+              f_end = q.end;
+              q.filled = f_to;
+            }
+          }
+        }
+        g_cl[u] = readlane_u32(f_cl, cc);
+        g_from[u] = readlane_u32(f_from, cc);
+        g_to[u] = readlane_u32(f_to, cc);
+        g_end[u] = readlane_u32(f_end, cc);
+      }
+    }
+    uint32_t tp[4], tg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t e = g_from[u] + lane;
+      const bool real = e < g_to[u] && e < g_end[u];
+      tp[u] = real ? ~list_rank(L, e) : 0u;
+      tg[u] = real ? list_slot(L, e) : kNone;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t e = g_from[u] + lane;
+      if (e < g_to[u]) {
+        w.ring_p[w.at(g_cl[u], e)] = tp[u];
+        w.ring_g[w.at(g_cl[u], e)] = tg[u];
+      }
+    }
+  };
+  // Refills every ring that is running low — and, while a round trip is being paid for anyway,
+  // every ring that is half empty; returns how many picks are safe before the next look (every
+  // ring keeps the entry after next).
   auto top_up = [&]() -> uint32_t {
     uint32_t least = 0x7FFFFFFFu;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const bool real = lane + 64 * j < C;
       uint64_t need = __ballot(real && w.ring_left(j) <= thresh);
-      while (need) {
-        refill((uint32_t)__builtin_ctzll(need), j);
-        need &= need - 1;
-      }
+      if (need) need = __ballot(real && w.ring_left(j) <= max(thresh, R / 2));
+      while (need) refill_group(need, j);
       least = min(least, real ? w.ring_left(j) : 0x7FFFFFFFu);
     }
     __builtin_amdgcn_wave_barrier();
@@ -1018,16 +1068,19 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
         nx_shi = T.self_hi[tl];
       }
       }
-      if (tl < t1) {
-        if (nx_shi == kSelfServant) {
-          // The request's own servant by index (bin_sort.h): its slot range, if it offers any.
-          const uint32_t b = shared.slot_base[nx_slo], e = shared.slot_base[nx_slo + 1];
-          nx_slo = e > b ? b : kNone;
-          nx_shi = e > b ? e : kNone;
-        }
+    };
+    // The second step of the staging, one block's work later (looking at what stage() fetched
+    // any earlier would expose a memory round trip in every block): a request's own servant by
+    // index (bin_sort.h) becomes its slot range, if it offers any.
+    auto resolve_staged = [&]() {
+      if (nx_shi == kSelfServant) {
+        const uint32_t b = shared.slot_base[nx_slo], e = shared.slot_base[nx_slo + 1];
+        nx_slo = e > b ? b : kNone;
+        nx_shi = e > b ? e : kNone;
       }
     };
     stage(warm ? t0 - B.warm_len : t0);
+    resolve_staged();
     ClassState early_cp{};
     if (W == 1 && pass != 0 && lane < C) early_cp = B.early[(size_t)kc * C + lane];
 
@@ -1309,6 +1362,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
           budget = 0;
         }
       }
+      resolve_staged();  // (the next block's requests: fetched a block ago)
       if (pass_arg == 0 && !fused_stage) YDC_PROBE(probe_kc, warm_blk ? 3 : 4);  // warm-up / block done
       // No eligible class at all: EnvironmentNotFound (task_dispatcher.cc:105-108).
       if (many == 0) res = kIdxEnvNotFound;
