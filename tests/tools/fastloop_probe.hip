@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
   for (uint32_t b = 0; b < blocks; ++b) {
     uint32_t hq = lane < n_classes ? ~lane : 0u, nq = lane < n_classes ? ~(n_classes + lane) : 0u;
     const uint32_t base = (uint32_t)(uintptr_t)lds + ((lane << rshift) << 2);
-    uint32_t an = base + 4, raw = 0;  // address of `next` (entry 1)
+    uint32_t an = base + 4, raw = 0, left = 0x7FFFFFFFu;  // address of `next` (entry 1)
     uint32_t i = 0;
     const uint32_t mlo = n_classes >= 32 ? 0xFFFFFFFFu : ((1u << n_classes) - 1);
     const uint32_t mhi = n_classes > 32 ? (n_classes >= 64 ? 0xFFFFFFFFu : (1u << (n_classes - 32)) - 1) : 0;
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(64) void probe(uint32_t n_classes, uint32_t blocks,
     const BlockMasks bm = block_masks(mlo, mhi, steps > 5);
     const uint64_t a = wall_clock64();
     // 20 requests per block: at most 20 picks per class, the ring (32) never wraps.
-    uint32_t st = match_fast_loop(i, 20, bm, kNone, kNone, 0ull, 0ull, 0ull, raw, hq, nq, an,
-                                  2048u << 2, R * 4 - 1, steps, pair && steps >= 3 ? 1u : 0u);
+    uint32_t st = match_fast_loop<false>(i, 20, bm, kNone, kNone, 0ull, 0ull, 0ull, raw, hq, nq, an,
+                                  2048u << 2, R * 4 - 1, steps, pair && steps >= 3 ? 1u : 0u, left);
     t_asm += wall_clock64() - a;
     total_i += i + st + (raw & 1);
   }

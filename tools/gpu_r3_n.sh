@@ -17,3 +17,4 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
     except Exception as ex:
         print(os.path.basename(f), "ERR", ex); print(open(f.replace('.json','.err')).read()[-800:])
 PY
+for c in cfg3 cfg4; do YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 120 python tools/phase_probe.py $c 10 2>&1 | tail -9; done

@@ -75,6 +75,20 @@ def main():
         dur = (vb - va)[m] / 100.0
         print("%-44s %8.2f %8.2f %8.2f %8.2f   (%d waves)" % (name, np.percentile(dur, 50), np.percentile(dur, 90),
                                                            np.percentile(dur, 99), dur.max(), m.sum() // reps))
+    # Inside the block loop of the first replay (warm-up included): where the time goes.
+    tu, lp = T[:, :, 10], T[:, :, 11]
+    m = (T[:, :, 2] > 0) & (T[:, :, 4] > 0)
+    if m.any() and (lp[m] != 0).any():
+        blocks = (T[:, :, 4] - T[:, :, 2])[m] / 100.0
+        t_top, n_top = (tu[m] & 0xFFFFFFFF) / 100.0, tu[m] >> 32
+        t_loop, n_gen = (lp[m] & 0xFFFFFFFF) / 100.0, lp[m] >> 32
+        print("\n-- inside the block loop of a chunk's first replay (per wave, p50 / p90)")
+        for name, v in (("all blocks (warm-up + chunk)", blocks), ("  fast loop (asm)", t_loop),
+                        ("  ring top-ups", t_top), ("  the rest (checkpoints, staging, general steps, glue)",
+                                                 blocks - t_loop - t_top)):
+            print("%-56s %8.2f %8.2f us" % (name, np.percentile(v, 50), np.percentile(v, 90)))
+        print("%-56s %8.1f %8.1f" % ("  calls of the fast loop", np.percentile(n_top, 50), np.percentile(n_top, 90)))
+        print("%-56s %8.1f %8.1f" % ("  general steps", np.percentile(n_gen, 50), np.percentile(n_gen, 90)))
     last = np.maximum.reduce([T[:, :, s] for s in range(10)]).max(axis=1)
     print("\nlast stamp of a launch - first entry: p50 %.2f us, max %.2f us" % (
         np.percentile((last - launch0[:, 0]) / 100.0, 50), ((last - launch0[:, 0]) / 100.0).max()))

@@ -71,8 +71,25 @@ constexpr uint32_t kPassSlots = 64;  // DeviceParams::n_changed is indexed by pa
     if (threadIdx.x == 0 && (chunk) < kProbeChunks)                                     \
       ydc_phase_probe[(size_t)(chunk) * kProbeSlots + (slot)] = wall_clock64();         \
   } while (0)
+// Accumulated inside the block loop of a chunk's first replay: ticks spent topping rings up and
+// in the fast loop (low words), calls of the fast loop and general steps (high words).
+#define YDC_PROBE_ACC(var, expr)                                                        \
+  do {                                                                                  \
+    const uint64_t ydc_t0 = wall_clock64();                                             \
+    expr;                                                                               \
+    var += wall_clock64() - ydc_t0;                                                     \
+  } while (0)
+#define YDC_PROBE_COUNT(var) (var += 1ull << 32)
+#define YDC_PROBE_PUT(chunk, slot, v)                                                   \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && (chunk) < kProbeChunks)                                     \
+      ydc_phase_probe[(size_t)(chunk) * kProbeSlots + (slot)] = (v);                    \
+  } while (0)
 #else
 #define YDC_PROBE(chunk, slot) do { (void)(chunk); } while (0)
+#define YDC_PROBE_ACC(var, expr) do { expr; } while (0)
+#define YDC_PROBE_COUNT(var) do { } while (0)
+#define YDC_PROBE_PUT(chunk, slot, v) do { (void)(chunk); } while (0)
 #endif
 
 struct MatchBuffers {
@@ -345,7 +362,8 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 // The fast loop of one block of (up to 64) requests, W == 1, hand-scheduled. Runs requests
 // i, i+1, ... < end (i < end) while each of them is "plain". Returns
 //   0  all of them done,
-//   1  request i needs the general step (the requests before it were done).
+//   1  request i needs the general step (the requests before it were done),
+//   2  a ring may run dry within the next few picks: top up, come back for request i.
 // `special` marks the requests of the block that need a look first: `hole_hit` ones (an
 // eligible class has holes) leave at once; `has_self` ones leave only if an eligible class
 // shows a slot of the requestor's own servant at its head, or if nothing is left for them
@@ -397,6 +415,9 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
 // The winning lane(s) advance (exec = winners; the read of `next` issued by the lane's
 // previous win has been waited for).
 #define YDC_ADVANCE                                                                   \
+  ".if %c[ck]\n"                                                                      \
+  "v_add_u32 %[left], -1, %[left]\n"                                                  \
+  ".endif\n"                                                                          \
   "v_mov_b32 %[hq], %[nq]\n"                                                          \
   "v_add_u32 %[a], 4, %[an]\n"                                                        \
   "v_bfi_b32 %[an], %[rmask4], %[a], %[an]\n"                                         \
@@ -521,6 +542,12 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
   "L" #K "_check%=:\n"                                                             \
   "s_cmp_ge_u32 m0, %[end]\n"                                                      \
   "s_cbranch_scc1 L_out%=\n"                                                       \
+  "s_bitcmp1_b64 %[chk], m0\n"                                                     \
+  "s_cbranch_scc0 L" #K "_special%=\n"                                             \
+  "v_cmp_gt_u32 vcc, %[thr], %[left]\n"                                            \
+  "s_cbranch_vccnz L_low%=\n"                                                      \
+  "s_bitcmp1_b64 %[plain], m0\n"                                                   \
+  "s_cbranch_scc1 L" #K "_cont%=\n"                                                \
   "L" #K "_special%=:\n"                                                           \
   "s_bitcmp1_b64 %[hh], m0\n"                                                      \
   "s_cbranch_scc1 L_slow%=\n"                                                      \
@@ -562,13 +589,23 @@ __device__ __forceinline__ BlockMasks block_masks(uint32_t mlo, uint32_t mhi, bo
   return m;
 }
 
+template <bool kChecked>
 __device__ __forceinline__ uint32_t match_fast_loop(
     uint32_t& i, uint32_t end, const BlockMasks& m, uint32_t slo, uint32_t shi,
     uint64_t special, uint64_t hole_hit, uint64_t has_self, uint32_t& raw, uint32_t& hq,
-    uint32_t& nq, uint32_t& an, uint32_t goff, uint32_t rmask4, uint32_t steps, uint32_t pair) {
+    uint32_t& nq, uint32_t& an, uint32_t goff, uint32_t rmask4, uint32_t steps, uint32_t pair,
+    uint32_t& left) {
+  constexpr uint32_t check_every = kChecked ? 8u : 0u;
   // Plain requests below `end`; index 64 wraps to bit 0, which therefore always says "stop".
   const uint64_t plain = ~special & (end >= 64 ? ~0ull : (1ull << end) - 1);
-  const uint64_t go = plain & ~1ull;
+  // kChecked: the loop looks at the rings itself, before every request whose index is a
+  // multiple of 8 — `left` = entries each lane's ring holds beyond its cursor, counted down as the
+  // lane wins — and returns 2 when one of them could run dry within the next 8 picks. (Otherwise
+  // the caller bounds `end` by what the emptiest ring allows.) With 30 classes sharing 1024 entries
+  // that is a return every ~25 requests instead of every ~11 (cfg4).
+  const uint64_t chk = check_every ? 0x0101010101010100ull : 0ull;
+  const uint32_t thr = check_every + 2;
+  const uint64_t go = plain & ~1ull & ~chk;
   const uint64_t pairok = pair ? go & (go >> 1) : 0ull;
   uint32_t entry = (uint32_t)(plain >> i) & 1u;
   if (entry && pair && i < 63 && ((plain >> (i + 1)) & 1)) entry = 2;
@@ -602,6 +639,9 @@ __device__ __forceinline__ uint32_t match_fast_loop(
                     YDC_PAIR(5, YDC_PRED_5, "31", YDC_PAIRPRE_LO, YDC_REREAD_LO))
       YDC_LOOP_BODY(6, YDC_RED_6(6, YDC_HI_READ) YDC_TAIL_NOP, "63", YDC_PAIRENTRY(6), YDC_CONTROL_PAIRS(6),
                     YDC_PAIR(6, YDC_PRED_6, "63", YDC_PAIRPRE_HI, YDC_REREAD_HI))
+      "L_low%=:\n"
+      "s_mov_b32 %[st], 2\n"
+      "s_branch L_out%=\n"
       "L_slow%=:\n"
       "s_mov_b32 %[st], 1\n"
       "L_out%=:\n"
@@ -609,12 +649,13 @@ __device__ __forceinline__ uint32_t match_fast_loop(
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b32 m0, %[m0s]\n"
       : [st] "=&s"(status), [i] "+s"(i), [raw] "+v"(raw), [hq] "+v"(hq), [nq] "+v"(nq),
-        [an] "+v"(an), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
+        [an] "+v"(an), [left] "+v"(left), [c] "=&v"(c), [t] "=&v"(t), [c1] "=&v"(c1), [t1] "=&v"(t1),
         [a] "=&v"(a), [mn] "=&s"(mn),
         [sp] "=&s"(sp), [s0] "=&s"(s0), [s1] "=&s"(s1), [m0s] "=&s"(m0save)
       : [mlo] "v"(m.lo), [mhi] "v"(m.hi), [m1lo] "v"(m.lo1), [m1hi] "v"(m.hi1), [m2lo] "v"(m.lo2),
         [m2hi] "v"(m.hi2), [m3lo] "v"(m.lo3), [m3hi] "v"(m.hi3), [slo] "v"(slo), [shi] "v"(shi),
-        [go] "s"(go), [pairok] "s"(pairok), [entry] "s"(entry), [end] "s"(end),
+        [go] "s"(go), [pairok] "s"(pairok), [entry] "s"(entry), [end] "s"(end), [chk] "s"(chk),
+        [plain] "s"(plain), [thr] "s"(thr), [ck] "n"(kChecked ? 1 : 0),
         [hh] "s"(hole_hit), [hs] "s"(has_self), [goff] "s"(goff), [rmask4] "s"(rmask4),
         [steps] "s"(steps)
       : "vcc", "scc", "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
@@ -627,7 +668,8 @@ __device__ __forceinline__ uint32_t match_fast_loop(
 // cycles per wave at 1, 2 or 3 waves per SIMD), so where a batch has more than two chunks per
 // SIMD to offer, a fourth resident wave is worth the two dozen registers spilled in the prologue
 // (OCC = 4: 128 VGPRs instead of 152).
-template <int W, int OCC = 1>
+// CHECKED: rings of 32 entries, watched by the fast loop itself (match_fast_loop<true>).
+template <int W, int OCC = 1, bool CHECKED = false>
 __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
                                                    MatchBuffers B, uint32_t pass_arg,
@@ -640,6 +682,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
   uint32_t kc = blockIdx.x;  // chunk
   const uint32_t probe_kc = blockIdx.x;
+  [[maybe_unused]] uint64_t probe_topup = 0, probe_loop = 0;  // (measurement builds only)
   if (pass_arg == 0) YDC_PROBE(probe_kc, 0);  // entry
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
   const uint32_t batch_seq = prm->batch_seq;
@@ -689,7 +732,12 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   MatchWave<W> w{L, lds_ring, lds_ring + ring_total, (1u << rshift) - 1, rshift, lane, {}};
   const uint32_t R = 1u << rshift;
   // A ring is topped up when no more than `thresh` entries are left in it.
-  const uint32_t thresh = R / 4 < 4 ? 4 : (R / 4 > 12 ? 12 : R / 4);
+  // Rings of 32 entries: the fast loop watches them itself (match_fast_loop<true>) and wants more
+  // than 10 entries in every ring when it starts. With 64 entries or more the caller's bound on
+  // the run length is rarely what ends a call, and the watching costs more than it saves (one
+  // instruction per request: cfg3 379 -> 393 us); with 16 or fewer a look every 8 picks is too late.
+  constexpr uint32_t check_every = CHECKED ? 8u : 0u;  // (the host: CHECKED <=> W == 1 and rshift == 5)
+  const uint32_t thresh = check_every ? 12 : (R / 4 < 4 ? 4 : (R / 4 > 12 ? 12 : R / 4));
   uint32_t steps = 1;  // DPP steps of the min over the class lanes
   while ((1u << steps) < C) ++steps;
   // Two requests per iteration of the fast loop (match_fast_loop): with few classes the two
@@ -1257,23 +1305,28 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
         uint32_t lim = tb == t0 && cnt > kEarlyAt ? kEarlyAt : cnt;
         for (;;) {
         while (i < lim) {
-          const uint32_t budget = top_up();
-          const uint32_t n = min(lim - i, budget);
+          uint32_t budget;
+          YDC_PROBE_ACC(probe_topup, budget = top_up());
+          YDC_PROBE_COUNT(probe_topup);
+          const uint32_t n = check_every ? lim - i : min(lim - i, budget);
+          uint32_t left = lane < C ? w.ring_left(0) : 0x7FFFFFFFu;
           const uint32_t an0 = base + (((q.cursor + 1) & w.rmask) << 2);  // address of `next`
           uint32_t an = an0;
           // Requests that need a look before the plain step: an eligible class has holes, or
           // the requestor's host runs several servants (`self` is resolved in the general step).
           const uint64_t hole_hit = (holes[0] ? __ballot((my_mask & holes[0]) != 0) : 0ull) | dyn_self;
-          const uint32_t st = match_fast_loop(i, i + n, bm, slo, shi, has_self | hole_hit, hole_hit,
-                                              has_self, raw, q.hq, q.nq, an, ring_total << 2, rmask4,
-                                              steps,
-                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode));
+          uint32_t st;
+          const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair_mode);
+          YDC_PROBE_ACC(probe_loop, st = match_fast_loop<CHECKED>(i, i + n, bm, slo, shi, has_self | hole_hit,
+                                                                  hole_hit, has_self, raw, q.hq, q.nq, an,
+                                                                  ring_total << 2, rmask4, steps, pm, left));
           // Picks of this lane's class in the call (fewer than the ring holds): how far `next` moved.
           q.cursor += ((an - an0) & rmask4) >> 2;
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
           if (st == 1) {
             general_step(i);
+            YDC_PROBE_COUNT(probe_loop);
             ++i;
           }
         }
@@ -1405,6 +1458,10 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       if ((kc & 15u) == 0) atomicAdd(&B.sampled[pass & B.flag_mask], 1u);
     }
     if (pass_arg == 0 && !fused_stage) YDC_PROBE(probe_kc, 5);  // results + end state stored
+    if (pass_arg == 0 && !fused_stage) {
+      YDC_PROBE_PUT(probe_kc, 10, probe_topup);
+      YDC_PROBE_PUT(probe_kc, 11, probe_loop);
+    }
     if (pass_arg == 0 && fused_stage) YDC_PROBE(probe_kc, 9);   // second replay done
     if (pass == 0) {
       if (!fuse) return;

@@ -1428,12 +1428,17 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   device_check |= c->opt_pair ? 4u : 0u;
   device_check |= p.ring_total << 8;
   DeviceParams* prm = c->d_prm.p;
-  if (p.W == 1 && p.dense) {
-    YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1, 4>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
-               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
-  } else if (p.W == 1) {
-    YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
-               p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
+  // (rings of 32 entries are watched by the fast loop itself: match_kernel.h, CHECKED)
+  const bool checked = p.W == 1 && p.rshift == 5;
+#define YDC_LAUNCH_MATCH1(OCC, CHECKED)                                                             \
+  YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1, OCC, CHECKED>), dim3(p.K), dim3(64), lds, c->stream, \
+             p.L, p.T, p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm)
+  if (p.W == 1) {
+    if (p.dense && checked) YDC_LAUNCH_MATCH1(4, true);
+    else if (p.dense) YDC_LAUNCH_MATCH1(4, false);
+    else if (checked) YDC_LAUNCH_MATCH1(1, true);
+    else YDC_LAUNCH_MATCH1(1, false);
+#undef YDC_LAUNCH_MATCH1
   } else if (p.W == 2) {
     YDC_LAUNCH(c, "k_match_pass", (k_match_pass<2>), dim3(p.K), dim3(64), lds, c->stream, p.L, p.T,
                p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm);
