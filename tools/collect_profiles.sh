@@ -20,6 +20,10 @@ for c in cfg2 cfg3; do
     echo; echo "# rocprofv3 --kernel-trace --pmc WRITE_SIZE (separate pass)"; cat $P/pmc_write.txt; } > profiles/${R}_${c}_pmc_hbm.txt
   [ -s $F/phase_$c.txt ] && cp $F/phase_$c.txt profiles/${R}_${c}_match_phases.txt
 done
+[ -s gpurun_out/prof_cfg4/kernel_stats.txt ] && cp gpurun_out/prof_cfg4/kernel_stats.txt profiles/${R}_cfg4_kernel_stats.txt
+[ -s $F/phase_cfg4.txt ] && cp $F/phase_cfg4.txt profiles/${R}_cfg4_match_phases.txt
+[ -s $F/issue_probe.txt ] && cp $F/issue_probe.txt profiles/${R}_issue_probe.txt
+[ -s $F/fastloop_probe.txt ] && cp $F/fastloop_probe.txt profiles/${R}_fastloop_probe.txt
 python tools/rocprof_summary.py hbmtable "cfg2 (100k requests x 2k servants)=profiles/${R}_cfg2_pmc_hbm.json" \
   "cfg3 (1M requests x 8k servants, 4 digests)=profiles/${R}_cfg3_pmc_hbm.json" > profiles/${R}_hbm_utilisation.txt
 cp $F/td_native_bench.log profiles/${R}_td_native_bench.txt

@@ -16,11 +16,14 @@ timeout 300 python bench.py --digests 150 --steps 5 --warmup 1 > $O/bench_cfg2_d
 for t in rccl ipc; do
   YDC_BENCH_FORCE_DIST=1 YDC_BENCH_RCCL_TIMEOUT=100 timeout 260 python bench.py --gpus 1 --steps 500 --warmup 50 --transport $t --no-cpu-baseline > $O/bench_dist1_$t.json 2> $O/bench_dist1_$t.err
 done
-for c in cfg2 cfg3; do
+for c in cfg2 cfg3 cfg4; do
   YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 200 python tools/phase_probe.py $c 20 > $O/phase_$c.txt 2>&1
 done
+[ -x build/issue_probe ] && timeout 100 build/issue_probe > $O/issue_probe.txt 2>&1
+[ -x build/fastloop_probe ] && timeout 100 build/fastloop_probe > $O/fastloop_probe.txt 2>&1
 timeout 300 bash tools/profile.sh cfg2 > $O/profile_cfg2.log 2>&1
 timeout 400 bash tools/profile.sh cfg3 --config cfg3 > $O/profile_cfg3.log 2>&1
+YDC_PROFILE_PMC=0 timeout 300 bash tools/profile.sh cfg4 --config cfg4 > $O/profile_cfg4.log 2>&1
 (timeout 120 tools/td_native_bench 2>&1 | tail -12) > $O/td_native_bench.log
 cat $O/pytest.log
 python - $O <<'PY'
