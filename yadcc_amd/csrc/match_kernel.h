@@ -40,16 +40,17 @@
 // harmless) state; the inconsistency shows in the next pass.
 //
 // The pick of one request depends on the previous one, so the inner loop is a
-// dependency chain, and a single wave issues at most one instruction every ~4-5
-// cycles whatever its kind: what counts is the instruction count per request. The
-// loop works on *inverted* ranks (~rank, 0 = no slot) so that the winner is a DPP
-// max with zero fill (no identity moves), the request's class mask is used
-// directly as a lane mask (v_cndmask with an SGPR pair), the result of a request is
-// its slot's global rank (the reduced value itself; k_finalize maps rank -> slot ->
-// servant), and the winning lane advances from registers (head / next kept in
-// VGPRs, the LDS read of the entry after next is only waited for when the lane wins
-// again). About 34 instructions per request at 32 classes; with >= 5 classes two
-// requests share an iteration when their winners are different lanes.
+// dependency chain. A wave issues one instruction every ~4.5 cycles whatever its kind and
+// however many waves share the SIMD, and stalls ~18 cycles wherever the scalar side waits for
+// the vector side (tests/tools/issue_probe.hip): what counts is the number of instructions
+// and of such hops per request, and the number of resident waves. The loop works on
+// *inverted* ranks (~rank, 0 = no slot) so that the winner is a DPP max with zero fill (no
+// identity moves), the request's class mask is used directly as a lane mask (v_cndmask with
+// an SGPR pair), the result of a request is its slot's global rank (the reduced value itself;
+// k_finalize maps rank -> slot -> servant), and the winning lane advances from registers
+// (head / next kept in VGPRs, the LDS read of the entry after next is only waited for when the
+// lane wins again). About 21 instructions per request at 4 classes, 29 at 32; with >= 5
+// classes two requests share an iteration when their winners are different lanes.
 #ifndef YADCC_AMD_MATCH_KERNEL_H_
 #define YADCC_AMD_MATCH_KERNEL_H_
 
