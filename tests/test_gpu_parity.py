@@ -472,3 +472,37 @@ def test_switchable_fast_paths_off(monkeypatch):
             check(c, sv, tk)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n_envs", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("rings", ["default", "1024", "256"])
+def test_matching_loop_variants(n_envs, rings, monkeypatch):
+    """The hand-scheduled loop of the matching kernel in all its shapes (match_kernel.h): one body
+    per DPP depth (the digests make 2 .. 60 classes), single steps and pairs — with requests
+    nobody can serve any more inside the pairs (an oversubscribed pool: half of the requests time
+    out), requests for unknown digests (empty class masks) and the requestors' own servants —,
+    chunks long enough for the 4-waves-per-SIMD build, and rings of 32 entries (watched by the loop
+    itself), of 8 (the caller's bound) and whatever the plan picks; two committed batches."""
+    monkeypatch.setenv("YDC_CHUNK_SIZE", "512")
+    if rings != "default":
+        monkeypatch.setenv("YDC_RING_TOTAL", rings)
+    c = binding.Context(device=0)
+    try:
+        sv, tk = cases.random_case(seed=90 + n_envs, n_tasks=40_000, n_servants=700, n_envs=n_envs,
+                                   oversubscribed=True, unknown_env_frac=0.01, self_frac=0.25)
+        want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+        assert (want == O.IDX_TIMEOUT).sum() > 1000 and (want == O.IDX_ENV_NOT_FOUND).sum() > 100
+        c.upload_servants(pack.to_abi_columns(sv))
+        cut = 23_456
+        a, ua, _ = c.dispatch({k: v[:cut] for k, v in tk.items()}, commit=True)
+        sa = c.stats()
+        b, ub, run = c.dispatch({k: v[cut:] for k, v in tk.items()}, commit=True)
+        got = np.concatenate([a, b])
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "first mismatch at task %d: gpu %d oracle %d (%d total) stats=%s" % (
+            bad[0], got[bad[0]], want[bad[0]], bad.size, sa)
+        assert np.array_equal(np.concatenate([ua, ub]), wutil)
+        assert np.array_equal(run, wrun) and np.array_equal(c.get_running(), wrun)
+        print("n_envs", n_envs, "classes", sa["n_classes"], "rings", rings, "rounds", sa["rounds"])
+    finally:
+        c.close()

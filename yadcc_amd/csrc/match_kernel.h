@@ -823,14 +823,15 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       const bool fill = C <= 4 && L.stride == 2 && (C << rshift) <= ring_total && (1u << rshift) >= 256;
       uint32_t v[16], fr[8], fg[8], g0[4];
 #pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        fr[q] = 0u;  // (ring sentinels: ~rank 0 = no slot)
+        fg[q] = kNone;
+        if (q < 4) g0[q] = kNone;
+      }
+#pragma unroll
       for (int q = 0; q < 16; ++q) {
         const uint32_t c = (uint32_t)q >> 1;
         v[q] = 0xFFFFFFFFu;  // "not below the level"
-        if (q < 8) {
-          fr[q] = 0u;  // (ring sentinels: ~rank 0 = no slot)
-          fg[q] = kNone;
-          if (q < 4) g0[q] = kNone;
-        }
         if (c < C) {
           const uint32_t at = readlane_u32(pos[q & 1], c) + lane, e = readlane_u32(endc, c);
           if (at < e) {
