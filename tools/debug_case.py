@@ -21,6 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 base = dict(seed=91, n_tasks=40_000, n_servants=700, n_envs=1, oversubscribed=True, unknown_env_frac=0.01, self_frac=0.25)
 variants = [
     ("as in the test", {"YDC_CHUNK_SIZE": "512"}, {}),
+    # (a library built from an earlier commit, if there is one at build/libydc_old.so)
     ("old library", {"YDC_CHUNK_SIZE": "512", "YDC_LIB": os.path.join(ROOT, "build/libydc_old.so")}, {}),
     ("no dense", {"YDC_CHUNK_SIZE": "512", "YDC_DENSE": "0"}, {}),
     ("chunk 64", {"YDC_CHUNK_SIZE": "64"}, {}),
@@ -36,6 +37,8 @@ variants = [
     ("4 envs", {"YDC_CHUNK_SIZE": "512"}, {"n_envs": 4}),
 ]
 for name, env, over in variants:
+    if "YDC_LIB" in env and not os.path.exists(env["YDC_LIB"]):
+        continue
     kw = dict(base, **over)
     print(name, env, over, flush=True)
     subprocess.run([sys.executable, __file__, "child", repr(kw)], env=dict(os.environ, **env))
