@@ -274,6 +274,7 @@ struct ydc_context {
   // 16 KB of LDS per matching wave = 10 waves per CU. Smaller rings (more waves per CU, shorter
   // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
   uint32_t opt_ring_total = 0;  // entries of a matching wave's rings; 0: chosen per batch (YDC_RING_TOTAL)
+  bool opt_split_gen = false;  // slot generation and request classification as two launches (YDC_SPLIT_GEN=1)
   bool opt_dense = true;  // 4-waves-per-SIMD matching kernel and twice the chunks where it pays (YDC_DENSE=0)
   bool opt_fused_class = true;
   bool opt_own_guess = true;
@@ -620,6 +621,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
   if (const char* s = getenv("YDC_RING_TOTAL")) c->opt_ring_total = std::max(256u, (uint32_t)atoi(s));
   if (const char* s = getenv("YDC_DENSE")) c->opt_dense = atoi(s) != 0;
+  if (const char* s = getenv("YDC_SPLIT_GEN")) c->opt_split_gen = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
@@ -1261,14 +1263,15 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                c->kf.comp_shift, p.gbits, bt, c->d_owner.p, (uint2*)c->d_keys[0].p, ca);
     return;
   }
+  const char* gen_name = gen_blocks && cls_blocks ? "k_slot_gen" : (gen_blocks ? "k_slot_gen(slots)" : "k_slot_gen(requests)");
   if (p.key32) {
-    YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+    YDC_LAUNCH(c, gen_name, k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
                r_first, gbase, p.packed ? 1u : 0u, p.win ? nullptr : c->d_tile_first.p);
   } else {
-    YDC_LAUNCH(c, "k_slot_gen", k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+    YDC_LAUNCH(c, gen_name, k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
@@ -1353,7 +1356,12 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
 // Everything before the level guesses: slots, sort, class lists, request classification.
 int enqueue_front_a(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk) {
   enqueue_scan(c, p, c->d_cls_begin.p);
-  enqueue_gen(c, p, tk, true, true);
+  if (c->opt_split_gen) {  // (measurement: the two halves of the launch timed apart)
+    enqueue_gen(c, p, tk, true, false);
+    enqueue_gen(c, p, tk, false, true);
+  } else {
+    enqueue_gen(c, p, tk, true, true);
+  }
   return enqueue_sort(c, p, true);
 }
 
