@@ -488,8 +488,27 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
                                                   const uint32_t* gslot_base, uint32_t packed,
                                                   const uint32_t* tile_first) {
   extern __shared__ uint32_t h0[];  // 1 << bits0
+#ifdef YDC_PHASE_PROBE
+  // Measurement builds (tools/gen_probe.py): start and end of every stride-th workgroup, where
+  // k_front_bins leaves its own stamps on the bin-sort path (never both in one batch).
+  const uint32_t probe_stride = (gridDim.x + 2399) / 2400;
+  const bool probed = threadIdx.x == 0 && blockIdx.x % probe_stride == 0;
+  if (probed) ydc_phase_probe[40000 + blockIdx.x / probe_stride * 2] = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ydc_phase_probe[39990] = gridDim.x;
+    ydc_phase_probe[39991] = gen_blocks;
+    ydc_phase_probe[39992] = probe_stride;
+  }
+#define YDC_GEN_PROBE_END()                                                                    \
+  do {                                                                                         \
+    if (probed) ydc_phase_probe[40000 + blockIdx.x / probe_stride * 2 + 1] = wall_clock64();   \
+  } while (0)
+#else
+#define YDC_GEN_PROBE_END() do { } while (0)
+#endif
   if (blockIdx.x >= gen_blocks) {
     task_classify_block(ca, blockIdx.x - gen_blocks, prm);
+    YDC_GEN_PROBE_END();
     return;
   }
   // Owners: slots are servant-major, so a tile's owners are one short run of servants. Two
@@ -565,7 +584,9 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) hist[d * gen_blocks + tile] = h0[d];
+  YDC_GEN_PROBE_END();
 }
+#undef YDC_GEN_PROBE_END
 
 // ---------------------------------------------------------------------------
 // Stable LSD radix sort, three kernels per pass, digit width chosen per pass (up
