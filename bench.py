@@ -10,22 +10,34 @@ starts from the same snapshot (no COMMIT), so every step does identical work.
 region starts). The metric as SURVEY.md §8(d) words it — batch visible to the dispatcher ->
 all results visible to the host, i.e. H2D + kernels + D2H through ydc_dispatch — is in
 `end_to_end` on the same line (rate, p50 / p99 over >= 100 batches); `value_definition` says
-which is which.
+which is which, and `value_synchronous` / `value_pipelined` / `value_end_to_end` carry the
+three rates side by side.
 
-GPU work goes through yadcc_amd/libydc.so only (its own HIP runtime, /opt/rocm). For
-N > 1 (launched by torch.distributed.run, one rank per GPU) torch.distributed (gloo) is used
+N = 1 (default cfg2): the line also carries `configs` — compact records of BASELINE.json
+configs[2] (cfg3), configs[3]'s batch on one GPU (cfg4) and configs[4] (cfg5, streaming), each
+timed in this very run and pinned to the committed fixtures of the verbatim reference
+(tests/golden: first 50k placements / 200 ticks) — no CPU replay, a few seconds.
+
+N > 1: `python bench.py --gpus N` launches its N ranks itself when no launcher did
+(WORLD_SIZE unset): rank r takes device r % (visible devices), so the command also runs on
+a box with fewer GPUs than ranks (the ranks then share a device over the mailbox transport).
+Under torch.distributed.run (one rank per GPU) RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
+from the environment; `--gpus` must agree with WORLD_SIZE. torch.distributed (gloo) is used
 for the rendezvous, the barriers and the max-over-ranks of the wall time; the data path of
 the sharded batch is RCCL inside libydc.so. `--scaling weak` (default): G ranks place ONE
 global batch of G x (the config's requests) on a pool of G x (the config's servants);
-`--scaling strong`: the config's batch itself (e.g. --config cfg4: 4M requests x 16k
-servants = BASELINE.json configs[3]) is cut into G rank ranges.
+`--scaling strong`: the config's batch itself is cut into G rank ranges. For N > 1 the line
+also carries `strong_cfg4`: BASELINE.json configs[3] as specified (4M requests x 16k
+servants cut over the N ranks), timed in the same run.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+import types
 
 import numpy as np
 
@@ -79,22 +91,52 @@ def cpu_baseline(sv, tk, max_tasks=None):
                  "host_cores_available": os.cpu_count()}
 
 
-def stream_main(args):
+def golden(name):
+    """A committed fixture of the verbatim reference (tests/golden/, generators beside them)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", name))
+
+
+def fixture_prefix(cfg, sv, tk):
+    """The verbatim reference's placement of the first requests of `cfg` (tests/golden/
+    ref_<cfg>_prefix_50k.npz, tests/golden/make_golden.py), or None when (sv, tk) are not the
+    inputs the fixture was generated from (another digest count, shared hosts, ...)."""
+    import hashlib
+    try:
+        z = golden("ref_%s_prefix_50k.npz" % cfg)
+    except OSError:
+        return None
+    n = int(z["prefix"])
+    h = hashlib.sha256()
+    for k in sorted(sv):
+        h.update(np.ascontiguousarray(sv[k]).tobytes())
+    for k in sorted(tk):
+        h.update(np.ascontiguousarray(tk[k][:n]).tobytes())
+    return z["ref_servant_idx"] if h.hexdigest() == str(z["input_sha256"]) else None
+
+
+def stream_record(args, steps, warmup, ref_ticks, device=0):
     """BASELINE.json configs[4]: 10k requests/tick x 2k servants with rolling heartbeats (10 % of
     the servants per tick) and 10k frees per tick; the whole tick is one replay of a captured
     hipGraph (ydc_stream_tick). A step is a tick; only the tick call is timed (the event
-    generator is host-side test scaffolding). Host buffers in, host results out. The reference
-    class replays the first ticks of the very same stream beside it (heartbeats, frees by
-    grant id, sequential WaitForStartingNewTask calls): cpu_baseline + per-tick parity."""
+    generator is host-side test scaffolding). Host buffers in, host results out. Every one of
+    the first 200 ticks is compared with what the verbatim reference answered on the same
+    stream (tests/golden/ref_cfg5_stream_200_ticks.npz); with ref_ticks > 0 the reference class
+    also replays the first ticks beside it (heartbeats, frees by grant id, sequential
+    WaitForStartingNewTask calls): cpu_baseline + per-tick parity."""
     from yadcc_amd import binding, pack, streaming, synth
     sv, _ = synth.make_config("cfg5")
     es = streaming.EventStream(sv, 10_000, 10_000)
-    ctx = binding.Context(device=int(os.environ.get("LOCAL_RANK", 0)))
+    ctx = binding.Context(device=device)
     ctx.upload_servants(pack.to_abi_columns(sv))
     ctx.stream_begin(es.hb + 8, 10_000, 10_000)
+    try:
+        fx = golden("ref_cfg5_stream_200_ticks.npz")
+        fx_ticks = int(fx["ticks"])
+    except OSError:
+        fx, fx_ticks = None, 0
     ref = ref_ids = None
-    ref_ticks = 0 if args.no_cpu_baseline else 30  # ~ 300k reference calls, ~10 s
     ref_secs, ref_granted, ref_lat, parity = 0.0, 0, [], True
+    fx_ok, fx_seen = True, 0
     if ref_ticks:
         from oracle import refbind as R
         if R.available():
@@ -102,7 +144,7 @@ def stream_main(args):
             ref.load_servants(sv)
             ref_ids = np.empty(0, np.uint64)  # grant id of every live grant, stream order
     lat, granted = [], 0
-    for t in range(args.warmup + args.steps):
+    for t in range(warmup + steps):
         who, rows, rel, tk = es.next_tick()
         if ref is not None and t < ref_ticks:
             # heartbeats: the same personalities, current_load as the stream reports it
@@ -122,15 +164,18 @@ def stream_main(args):
         dt = time.perf_counter() - s0
         if ref is not None and t < ref_ticks:
             parity &= bool(np.array_equal(got, ridx))
+        if t < fx_ticks:
+            fx_ok &= synth.placement_hash(got) == int(fx["digest"][t])
+            fx_seen += 1
         es.commit(got)
-        if t >= args.warmup:
+        if t >= warmup:
             lat.append(dt)
             granted += int((got < binding.IDX_ENV_NOT_FOUND).sum())
     st = ctx.stats()
     out = {
         "metric": METRIC,
         "value": granted / sum(lat), "unit": "assignments/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * sum(lat) / len(lat),
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * sum(lat) / len(lat),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
         "value_definition": "end to end per tick: host buffers in (one H2D copy), registry "
@@ -140,7 +185,10 @@ def stream_main(args):
                    "parallelism": "1 GPU", "inputs": "host buffers per tick (PCIe included)"},
         "p99_dispatch_latency_ms": 1e3 * percentile(lat, 0.99),
         "p50_dispatch_latency_ms": 1e3 * percentile(lat, 0.50),
+        "latency_samples": len(lat),
         "stats": {k: v for k, v in st.items() if k != "stage_ms"},
+        "parity_vs_reference_fixture": bool(fx_ok) if fx_seen else None,
+        "fixture_ticks": fx_seen,
     }
     # 16 B per request + 40 B per servant per tick over the whole tick: the
     # captured step is one graph launch, so the "dominant kernel" is the step itself.
@@ -164,12 +212,12 @@ def stream_main(args):
             "host_cores_available": os.cpu_count()}
         out["parity_vs_cpu_baseline"] = parity
         out["parity_ticks"] = ref_ticks
-    print(json.dumps(out))
     ctx.stream_end()
     ctx.close()
+    return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # A step is ~0.1 ms: enough of them that one scheduling hiccup of the host does not move
@@ -189,46 +237,225 @@ def main():
                          "so that per-kernel averages are those of the HBM-resident batches")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one synchronous ydc_dispatch_device call per step instead of two batches in flight")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="only the selected configuration: no `configs` records (N = 1), no `strong_cfg4` "
+                         "record (N > 1), no steady-state COMMIT loop")
     ap.add_argument("--transport", choices=("auto", "rccl", "ipc", "ipc-host"), default="auto",
                     help="N > 1: how the ranks exchange boundary states and slot deltas. auto = RCCL "
                          "(the default transport), and if its communicator does not come up in time "
                          "the RCCL-free mailbox transport of libydc.so (HIP IPC device memory, then "
                          "the shared host segment) instead of giving the sharded run up")
-    args = ap.parse_args()
-    if args.config == "cfg5":
-        return stream_main(args)
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    use_dist = world > 1 or os.environ.get("YDC_BENCH_FORCE_DIST") == "1"
-    dist = torch = None
-    t_start = time.perf_counter()
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher of N
+    ranks of itself (what torch.distributed.run would do: RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in the environment, gloo rendezvous on loopback). Rank 0's stdout
+    is captured and its ONE JSON line re-printed last; everything else passes through."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   YDC_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True))
+    deadline = time.time() + float(os.environ.get("YDC_BENCH_LAUNCH_TIMEOUT", "1500"))
+    out0 = None
+    rcs = [None] * n
+    try:
+        # (rank 0's pipe is drained by communicate(); the others write nothing to stdout)
+        try:
+            out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            out0 = None
+        for r, p in enumerate(procs):
+            try:
+                rcs[r] = p.wait(timeout=max(1.0, deadline - time.time()) if out0 is not None else 1.0)
+            except subprocess.TimeoutExpired:
+                rcs[r] = None
+    finally:
+        for p in procs:
+            if p.poll() is None:  # exactly the processes started here, by pid / process group
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    p.kill()
+    text = (out0 or b"").decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    for ln in text.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(rc != 0 for rc in rcs) or len(lines) != 1:
+        print("[bench] self-launched ranks failed: exit codes %s, %d JSON lines" % (rcs, len(lines)),
+              file=sys.stderr)
+        return 1
+    j = json.loads(lines[0])
+    if j.get("n_gpus") != n:
+        print("[bench] the ranks report n_gpus = %r, asked for %d" % (j.get("n_gpus"), n), file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def setup(args):
+    """Rank environment, the gloo group (N > 1), this rank's context and — N > 1 — the group
+    transport of libydc.so. Returns the run's state."""
+    E = types.SimpleNamespace()
+    E.rank = int(os.environ.get("RANK", 0))
+    E.world = int(os.environ.get("WORLD_SIZE", 1))
+    E.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    E.use_dist = E.world > 1 or os.environ.get("YDC_BENCH_FORCE_DIST") == "1"
+    E.dist = E.torch = None
+    E.t_start = time.perf_counter()
+    E.group_note = None
+    E.sharded = False
+    E.init_thread = None
+    E.rccl_ranks, E.is_rccl = 0, False
+    E.transport = "none"
+    E.abandoned = []  # contexts stuck inside a communicator bootstrap: never torn down
 
     def phase(what):
         # Start-up phases of a distributed run on stderr: the rendezvous and the RCCL bootstrap
         # are the parts whose duration depends on the box, not on this code.
-        if use_dist and rank == 0:
-            print("[bench] %6.1f s  %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+        if E.use_dist and E.rank == 0:
+            print("[bench] %6.1f s  %s" % (time.perf_counter() - E.t_start, what), file=sys.stderr, flush=True)
 
-    if use_dist:
+    E.phase = phase
+    if E.use_dist:
         # Rendezvous, barriers and the max over ranks go through gloo (CPU); the data path of
         # the sharded batch is RCCL inside libydc.so (ydc_group_init / ydc_dispatch_sharded).
         import torch
         import torch.distributed as dist
+        E.torch, E.dist = torch, dist
         phase("torch imported")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        if world == 1:  # (YDC_BENCH_FORCE_DIST=1 without a launcher: a group of one rank)
+        if E.world == 1:  # (YDC_BENCH_FORCE_DIST=1 without a launcher: a group of one rank)
             import socket
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:
                 with socket.socket() as so:
                     so.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(so.getsockname()[1])
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        phase("gloo group up (%d ranks)" % world)
+        dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+        phase("gloo group up (%d ranks)" % E.world)
 
+    from yadcc_amd import binding
+    # One rank per GPU; if the launcher narrowed this process to a single visible device it is
+    # 0, and with more ranks than devices (the 1-GPU test box) ranks share devices.
+    E.n_dev = binding.device_count()
+    E.device = E.local_rank % E.n_dev if E.n_dev else E.local_rank
+    E.ranks_per_device = -(-E.world // E.n_dev) if E.n_dev else 1
+    E.ctx = binding.Context(device=E.device)
+    if not E.use_dist:
+        return E
+    torch, dist = E.torch, E.dist
+
+    def everybody(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0]) == 1
+
+    want_rccl = args.transport in ("auto", "rccl")
+    if want_rccl and args.transport == "auto" and E.ranks_per_device > 1:
+        # RCCL refuses two ranks on one device: do not wait for its bootstrap to time out.
+        want_rccl = False
+        E.group_note = "RCCL skipped: %d ranks on %d device(s)" % (E.world, E.n_dev)
+    if want_rccl:
+        # One node: RCCL's bootstrap only has to find the loopback interface (probing the
+        # other interfaces / InfiniBand takes minutes on some boxes); the data path is xGMI.
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        ok = False
+        try:
+            ids = [binding.group_unique_id() if E.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            # The communicator bootstrap is a blocking C call: give it a deadline instead
+            # of hanging the whole scaling run (the thread is abandoned if it never returns).
+            import threading
+            box = {}
+            ctx0 = E.ctx
+
+            def _init():
+                try:
+                    ctx0.group_init(ids[0], E.rank, E.world)
+                    box["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = e
+
+            phase("RCCL unique id shared")
+            th = E.init_thread = threading.Thread(target=_init, daemon=True)
+            t_rccl = time.perf_counter()
+            th.start()
+            th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
+            ok = bool(box.get("ok"))
+            if not ok:
+                E.group_note = "RCCL group init failed after %.0f s (%s)" % (
+                    time.perf_counter() - t_rccl,
+                    box.get("err") or "ncclCommInitRank did not return in time")
+        except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
+            E.group_note = "RCCL group init failed (%s)" % e
+        all_ok = everybody(ok)
+        if all_ok:
+            E.sharded, E.transport = True, "rccl"
+            E.rccl_ranks, E.is_rccl = E.ctx.group_size()  # ncclCommCount of the communicator
+        else:
+            E.group_note = E.group_note or "another rank could not join the RCCL group"
+            if E.init_thread is not None and E.init_thread.is_alive():
+                # still inside ncclCommInitRank: leave that context alone, take a fresh one
+                E.abandoned.append(E.ctx)
+                E.ctx = binding.Context(device=E.device)
+            elif ok:
+                E.ctx.group_destroy()
+        phase(E.group_note or "RCCL communicator up")
+    if not E.sharded and args.transport != "rccl":
+        # The RCCL-free transport: mailboxes written by the peers' kernels (ydc_group_ipc_export
+        # / ydc_group_init_ipc), handles all-gathered over gloo. Same protocol, same results.
+        # (every rank takes part in every collective below, whatever happened to it locally)
+        note = E.group_note
+        try:
+            mine = E.ctx.group_ipc_export(E.rank, E.world)
+        except binding.YdcError as e:
+            mine = None
+            note = (note + "; " if note else "") + str(e)
+        handles = [None] * E.world
+        dist.all_gather_object(handles, mine)
+        kinds = [binding.TRANSPORT_IPC_DEVICE, binding.TRANSPORT_IPC_HOST]
+        if args.transport == "ipc-host":
+            kinds = kinds[1:]
+        for kind in kinds if all(h is not None for h in handles) else []:
+            try:
+                E.ctx.group_init_ipc(handles, E.rank, E.world, kind)
+                ok = True
+            except binding.YdcError as e:
+                ok = False
+                note = (note + "; " if note else "") + str(e)
+            if everybody(ok):
+                E.sharded, E.transport = True, binding.TRANSPORT_NAMES[kind]
+                break
+        E.group_note = note
+        phase("mailbox transport: %s" % (E.transport if E.sharded else "unavailable"))
+    if not E.sharded:
+        E.group_note = (E.group_note or "no transport") + ": ranks ran independent batches"
+    return E
+
+
+def measure_config(E, args, config, scaling, steps, warmup, detail):
+    """Times `steps` batches of `config` on the run's context(s). detail "full": the driver's
+    line (end-to-end loops, CPU baseline, >= 100 latency samples); "compact": a sub-record of
+    it (resident loop, synchronous latencies, per-kernel events, parity against the committed
+    fixture). Returns the record on rank 0, None elsewhere."""
     from yadcc_amd import binding, pack, synth
+    dist, torch, ctx = E.dist, E.torch, E.ctx
+    rank, world = E.rank, E.world
+    full = detail == "full"
 
     def barrier():
         if dist:
@@ -237,130 +464,42 @@ def main():
     # Weak: one global batch of G x (the config's requests) on G x (the config's servants).
     # Strong: the config's own batch and pool. Either way rank r owns the r-th range of the
     # batch (arrival order).
-    n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[args.config]
-    n_envs = args.digests or n_envs
-    mult = world if args.scaling == "weak" else 1
+    n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[config]
+    n_envs = (args.digests if full else 0) or n_envs
+    shared = args.shared_ip_frac if full else 0.0
+    mult = world if scaling == "weak" else 1
     n_all = n_cfg * mult
     sv = synth.make_servants(s_cfg * mult, n_tasks_hint=n_all, n_envs=n_envs, seed=42,
-                             shared_ip_frac=args.shared_ip_frac)
+                             shared_ip_frac=shared)
     tk_all = synth.make_tasks(n_all, sv, n_envs=n_envs, unknown_env_frac=unk)
     lo, hi = n_all * rank // world, n_all * (rank + 1) // world
     tk = {k: v[lo:hi] for k, v in tk_all.items()}
     n_tasks, n_serv = hi - lo, len(sv["version"])
-    # One rank per GPU; if the launcher narrowed this process to a single visible device it is 0.
-    n_dev = binding.device_count()
-    if n_dev and local_rank >= n_dev:
-        local_rank = local_rank % n_dev
-    ctx = binding.Context(device=local_rank)
     ctx.upload_servants(pack.to_abi_columns(sv))
-    group_note = None
-    sharded = False
-    init_thread = None
-    rccl_ranks, is_rccl = 0, False
-    transport = "none"
-    abandoned = []  # contexts stuck inside a communicator bootstrap: never torn down
-    if use_dist:
-        def everybody(ok):
-            t = torch.tensor([1 if ok else 0], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return int(t[0]) == 1
-
-        if args.transport in ("auto", "rccl"):
-            # One node: RCCL's bootstrap only has to find the loopback interface (probing the
-            # other interfaces / InfiniBand takes minutes on some boxes); the data path is xGMI.
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("NCCL_IB_DISABLE", "1")
-            ok = False
-            try:
-                ids = [binding.group_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                # The communicator bootstrap is a blocking C call: give it a deadline instead
-                # of hanging the whole scaling run (the thread is abandoned if it never returns).
-                import threading
-                box = {}
-
-                def _init():
-                    try:
-                        ctx.group_init(ids[0], rank, world)
-                        box["ok"] = True
-                    except Exception as e:  # noqa: BLE001
-                        box["err"] = e
-
-                phase("registry uploaded, RCCL unique id shared")
-                th = init_thread = threading.Thread(target=_init, daemon=True)
-                t_rccl = time.perf_counter()
-                th.start()
-                th.join(float(os.environ.get("YDC_BENCH_RCCL_TIMEOUT", "240")))
-                ok = bool(box.get("ok"))
-                if not ok:
-                    group_note = "RCCL group init failed after %.0f s (%s)" % (
-                        time.perf_counter() - t_rccl,
-                        box.get("err") or "ncclCommInitRank did not return in time")
-            except Exception as e:  # noqa: BLE001  (keep the scaling run alive, say what happened)
-                group_note = "RCCL group init failed (%s)" % e
-            all_ok = everybody(ok)
-            if all_ok:
-                sharded, transport = True, "rccl"
-                rccl_ranks, is_rccl = ctx.group_size()  # ncclCommCount of the communicator
-            else:
-                group_note = group_note or "another rank could not join the RCCL group"
-                if init_thread is not None and init_thread.is_alive():
-                    # still inside ncclCommInitRank: leave that context alone, take a fresh one
-                    abandoned.append(ctx)
-                    ctx = binding.Context(device=local_rank)
-                    ctx.upload_servants(pack.to_abi_columns(sv))
-                elif ok:
-                    ctx.group_destroy()
-            phase(group_note or "RCCL communicator up")
-        if not sharded and args.transport != "rccl":
-            # The RCCL-free transport: mailboxes written by the peers' kernels (ydc_group_ipc_export
-            # / ydc_group_init_ipc), handles all-gathered over gloo. Same protocol, same results.
-            # (every rank takes part in every collective below, whatever happened to it locally)
-            try:
-                mine = ctx.group_ipc_export(rank, world)
-            except binding.YdcError as e:
-                mine = None
-                group_note = (group_note + "; " if group_note else "") + str(e)
-            handles = [None] * world
-            dist.all_gather_object(handles, mine)
-            kinds = [binding.TRANSPORT_IPC_DEVICE, binding.TRANSPORT_IPC_HOST]
-            if args.transport == "ipc-host":
-                kinds = kinds[1:]
-            for kind in kinds if all(h is not None for h in handles) else []:
-                try:
-                    ctx.group_init_ipc(handles, rank, world, kind)
-                    ok = True
-                except binding.YdcError as e:
-                    ok = False
-                    group_note = (group_note + "; " if group_note else "") + str(e)
-                if everybody(ok):
-                    sharded, transport = True, binding.TRANSPORT_NAMES[kind]
-                    break
-            phase("mailbox transport: %s" % (transport if sharded else "unavailable"))
-        if not sharded:
-            group_note = (group_note or "no transport") + ": ranks ran independent batches"
     DA = binding.DeviceArray
-    d_env = DA.from_numpy(tk["env_id"], local_rank)
-    d_minv = DA.from_numpy(tk["min_version"], local_rank)
-    d_ip = DA.from_numpy(tk["requestor_ip"], local_rank)
-    d_out = DA(n_tasks, np.uint32, local_rank)
-    d_run = DA(n_serv, np.uint32, local_rank)
+    dev = E.device
+    d_env = DA.from_numpy(tk["env_id"], dev)
+    d_minv = DA.from_numpy(tk["min_version"], dev)
+    d_ip = DA.from_numpy(tk["requestor_ip"], dev)
+    d_out = DA(n_tasks, np.uint32, dev)
+    d_run = DA(n_serv, np.uint32, dev)
+    sharded = E.sharded
 
-    def step():
+    def step(commit=False):
         # Returns after the batch's results are final in HBM (stream sync inside).
         if sharded:
-            ctx.dispatch_sharded(d_env, d_minv, d_ip, d_out, None, d_run)
+            ctx.dispatch_sharded(d_env, d_minv, d_ip, d_out, None, d_run, commit=commit)
         else:
-            ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run)
+            ctx.dispatch_device(d_env, d_minv, d_ip, d_out, None, d_run, commit=commit)
 
     # One GPU: the steps are pipelined two deep (ydc_dispatch_device_async / ydc_dispatch_wait):
     # batch k + 1 is enqueued before the host looks at the outcome of batch k, each into its own
     # result buffers. Every step still places the whole batch and waits for its results inside
     # the timed region; what disappears is the device idling while the host turns around.
     # (--no-pipeline: one synchronous call per step, as in rounds 1 and 2.)
-    pipelined = not sharded and not use_dist and not args.no_pipeline and args.steps >= 2
-    d_out2 = DA(n_tasks, np.uint32, local_rank) if pipelined else None
-    d_run2 = DA(n_serv, np.uint32, local_rank) if pipelined else None
+    pipelined = not sharded and not E.use_dist and not args.no_pipeline and steps >= 2
+    d_out2 = DA(n_tasks, np.uint32, dev) if pipelined else None
+    d_run2 = DA(n_serv, np.uint32, dev) if pipelined else None
 
     def run_steps(k):
         if k <= 0:
@@ -378,17 +517,18 @@ def main():
             ctx.dispatch_wait()
         ctx.dispatch_wait()
 
-    run_steps(args.warmup)
+    run_steps(warmup)
     ctx.synchronize()
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(steps)
     ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     # Per-batch latency (p50 / p99): synchronous calls, one batch in flight.
+    n_lat = 100 if full else 30
     lat = []
-    for _ in range(min(args.steps, 1000) if pipelined else 0):
+    for _ in range((min(steps, 1000) if full else n_lat) if pipelined else 0):
         s0 = time.perf_counter()
         step()
         lat.append(time.perf_counter() - s0)
@@ -398,7 +538,7 @@ def main():
     if not pipelined:
         # (N > 1: the timed steps are synchronous; their own latencies serve)
         barrier()
-        for _ in range(min(args.steps, 100)):
+        for _ in range(min(steps, n_lat)):
             s0 = time.perf_counter()
             step()
             lat.append(time.perf_counter() - s0)
@@ -410,9 +550,10 @@ def main():
         g = torch.tensor([granted_all], dtype=torch.float64)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         elapsed, granted_all = float(t[0]), float(g[0])
-    # p50 / p99 want >= 100 samples whatever --steps is (extra batches, outside the timed region).
+    # p50 / p99 want >= 100 samples on the driver's line whatever --steps is (extra batches,
+    # outside the timed region).
     lat_all = list(lat)
-    while len(lat_all) < 100:
+    while len(lat_all) < n_lat:
         barrier()
         s0 = time.perf_counter()
         step()
@@ -422,17 +563,17 @@ def main():
     # the host, through the host-buffer entry point ydc_dispatch (H2D of 12 B/request over
     # PCIe, kernels, D2H of 4 B/request). Reported in `end_to_end`, next to `value`.
     e2e = None
-    if not use_dist and not args.resident_only:
+    if not E.use_dist and not args.resident_only:
         # (columns and the result array are the caller's and stay the same from batch to batch,
         # as in a scheduler loop; allocating them per call would time numpy, not the dispatch)
         # The scheduler's buffers are page-locked once (ydc_host_alloc): ydc_dispatch then reads
         # the columns and writes the placement in place — no staging copy on either side. The
         # same call with pageable numpy arrays (staged through the library's own pinned arenas)
-        # is reported beside it.
+        # is reported beside it (driver's line only).
         def host_loop(cols, res):
             ctx.dispatch(cols, want_util=False, want_running=False, out_idx=res)
             hl = []
-            for _ in range(max(100, min(1000, args.steps))):
+            for _ in range(max(100, min(1000, steps)) if full else n_lat):
                 s0 = time.perf_counter()
                 ctx.dispatch(cols, want_util=False, want_running=False, out_idx=res)
                 hl.append(time.perf_counter() - s0)
@@ -442,26 +583,57 @@ def main():
                         "batches": len(hl)}
 
         tk_c = {k: np.ascontiguousarray(v, dtype=np.uint32) for k, v in tk.items()}
-        res = np.empty(len(tk_c["env_id"]), np.uint32)
-        _, pageable = host_loop(tk_c, res)
         tk_p = {k: binding.pinned_empty(len(v), np.uint32) for k, v in tk_c.items()}
         for k in tk_c:
             tk_p[k][:] = tk_c[k]
-        res_p = binding.pinned_empty(len(res), np.uint32)
+        res_p = binding.pinned_empty(n_tasks, np.uint32)
+        if full:
+            res = np.empty(n_tasks, np.uint32)
+            _, pageable = host_loop(tk_c, res)
         _, e2e = host_loop(tk_p, res_p)
-        e2e_same = bool(np.array_equal(res_p, res))
         e2e["definition"] = ("ydc_dispatch with the caller's page-locked host buffers (ydc_host_alloc), "
                              "batch visible to the dispatcher -> placement visible to the host: the "
                              "kernels read the columns and write the results over PCIe in place, "
                              "SURVEY.md 8(d)")
-        e2e["same_placement_as_pageable"] = e2e_same
-        pageable["definition"] = ("the same call with pageable numpy arrays: staged through the "
-                                  "library's pinned arenas (two host memcpys + two copy commands)")
-        e2e["pageable_buffers"] = pageable
+        if full:
+            e2e["same_placement_as_pageable"] = bool(np.array_equal(res_p, res))
+            pageable["definition"] = ("the same call with pageable numpy arrays: staged through the "
+                                      "library's pinned arenas (two host memcpys + two copy commands)")
+            e2e["pageable_buffers"] = pageable
+        else:
+            e2e["same_placement_as_resident"] = bool(np.array_equal(res_p, d_out.numpy()))
+
+    # Steady state (driver's line, one GPU): every batch COMMITs — the next batch sees the
+    # previous one's grants, the dependency a scheduler has between batches — and the grants are
+    # released again (ydc_release_slots, what FreeTask feeds the device) before the next one.
+    steady = None
+    if full and not E.use_dist and not args.no_extra_configs:
+        granted_idx = d_out.numpy()
+        granted_idx = granted_idx[granted_idx < binding.IDX_ENV_NOT_FOUND]
+        run0 = ctx.get_running()
+        k_st = max(20, min(200, steps))
+        for _ in range(3):
+            step(commit=True)
+            ctx.release_slots(granted_idx)
+        ctx.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(k_st):
+            step(commit=True)
+            ctx.release_slots(granted_idx)
+        ctx.synchronize()
+        dt = time.perf_counter() - s0
+        steady = {"ms_per_step": 1e3 * dt / k_st, "steps": k_st,
+                  "assignments_per_s": len(granted_idx) * k_st / dt,
+                  "registry_restored": bool(np.array_equal(ctx.get_running(), run0)),
+                  "same_placement": bool(np.array_equal(
+                      d_out.numpy()[d_out.numpy() < binding.IDX_ENV_NOT_FOUND], granted_idx)),
+                  "definition": "synchronous ydc_dispatch_device with YDC_DISPATCH_COMMIT followed by "
+                                "ydc_release_slots of the batch's grants (%d servant indexes from the "
+                                "host), every step" % len(granted_idx)}
 
     # N > 1: the placement of the whole batch against the oracle (one more step, gathered).
     parity_oracle = None
-    if use_dist and dist:
+    if E.use_dist and dist:
         step()
         parts = [None] * world if rank == 0 else None
         dist.gather_object(d_out.numpy(), parts, dst=0)
@@ -475,7 +647,7 @@ def main():
     # the events do not perturb the timed region.
     ctx.set_profiling(True)
     per_step = {}
-    n_prof = max(3, min(40, args.steps))
+    n_prof = max(3, min(40, steps)) if full else 3
     for _ in range(n_prof):
         step()
         for k, (cnt, ms) in ctx.kernel_profile().items():
@@ -489,105 +661,201 @@ def main():
         cnt = int(np.median([c for c, _ in v]))
         prof[k] = [cnt * n_prof, float(np.median([m for _, m in v])) * n_prof]
 
-    if rank == 0:
-        host_idx = d_out.numpy()
-        shape = "%d pending requests x %d servants" % (n_all, n_serv)
-        out = {
-            "metric": METRIC,
-            "value": granted_all * args.steps / elapsed,
-            "unit": "assignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "u32" if st["key_bits"] <= 32 else "u64",
-            "data": "synthetic",
-            "value_definition": "HBM-resident: request columns, servant table and results stay in "
-                                "HBM (kernels + one 200-byte outcome read-back per batch)%s; the "
-                                "host-buffer rate of SURVEY.md 8(d) is in end_to_end" % (
-                                    ", two batches in flight (ydc_dispatch_device_async: the next "
-                                    "batch is enqueued before the host reads the previous outcome; "
-                                    "ms_per_step_synchronous = one batch at a time)" if pipelined else ""),
-            "pipeline_depth": 2 if pipelined else 1,
-            "ms_per_step_synchronous": sync_ms,
-            "config": {"workload": "%s%s%s: %s%s, %d classes" % (
-                           args.config, " with %d digests" % args.digests if args.digests else "",
-                           "" if world == 1 else " (%s scaling)" % args.scaling, shape,
-                           ", %.0f %% of the servants on shared hosts" % (100 * args.shared_ip_frac)
-                           if args.shared_ip_frac else "", st["n_classes"]),
-                       "parallelism": "1 GPU" if world == 1 else
-                                      ("one global batch of %d requests x %d servants sharded by "
-                                       "rank range over %d GPUs, %s all-gather of boundary states "
-                                       "and servant-slot deltas" % (
-                                           n_all, n_serv, world,
-                                           "RCCL" if transport == "rccl" else "mailbox (%s)" % transport)
-                                       if sharded else group_note),
-                       "inputs": "request columns + servant table resident in HBM; results in HBM"},
-            "p99_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.99),
-            "p50_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.50),
-            "latency_samples": len(lat_all),
-            "stats": {k: v for k, v in st.items() if k != "stage_ms"},
-            "stage_ms": stage_ms,
-            "kernels_us_per_step": {k: 1e3 * v[1] / n_prof for k, v in prof.items()},
-            "kernel_launches_per_step": {k: v[0] / n_prof for k, v in prof.items()},
-        }
-        if e2e:
-            out["end_to_end"] = e2e
-            out["host_buffers_assignments_per_s"] = e2e["assignments_per_s"]
-        if use_dist:
-            # sharded: the N ranks placed ONE global batch through ydc_dispatch_sharded (false:
-            # no transport came up and every rank placed its own batch — not a scaling result).
-            out["sharded"] = bool(sharded)
-            out["transport"] = {"ipc-host": "ipc"}.get(transport, transport)
-            out["transport_detail"] = transport + ("" if not group_note else " (%s)" % group_note)
-            out["rccl_ranks"] = rccl_ranks
-            out["rccl"] = is_rccl
-            out["parity_vs_oracle"] = parity_oracle
-        if prof:
-            dom = max(prof, key=lambda k: prof[k][1])
-            launches, total_ms = prof[dom]
-            # bytes(batch) = 16 N + 40 S; one launch of the dominant kernel
-            # (a matching pass) works on the whole batch of this rank.
-            alg_bytes = 16 * n_tasks + 40 * n_serv
-            avg_launch_s = (total_ms / launches) * 1e-3
-            ach = alg_bytes / avg_launch_s / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0,
-                               "traffic": pmc_traffic(dom, args.config),
-                               "algorithmic_bytes_per_launch": alg_bytes,
-                               "avg_launch_us": avg_launch_s * 1e6,
-                               "launches_per_step": launches / n_prof,
-                               # The same bytes against the whole step (all kernels + host
-                               # turn-around): what a batch achieves, whatever the launch count.
-                               "per_step_GBps": alg_bytes / (elapsed / args.steps) / 1e9,
-                               "note": "k_match_pass: matching passes 0 + 1 are one launch on one "
-                                       "GPU (two until round 2: half the duration per launch, the "
-                                       "same per batch); dependency-bound, see DESIGN.md 3.4"}
-        if world == 1 and not args.no_cpu_baseline:
-            ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
-            out["cpu_baseline"] = base
-            out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
-        line = json.dumps(out)
-    else:
-        line = None
-    stuck = init_thread is not None and init_thread.is_alive()  # still inside ncclCommInitRank
-    if sharded:
-        if dist:
-            dist.barrier()  # nobody unmaps a mailbox a peer may still be writing to
-        ctx.group_destroy()
-    ctx.close()
+    if rank != 0:
+        return None
+    host_idx = d_out.numpy()
+    host_run = d_run.numpy()
+    shape = "%d pending requests x %d servants" % (n_all, n_serv)
+    out = {
+        "metric": METRIC,
+        "value": granted_all * steps / elapsed,
+        "unit": "assignments/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "u32" if st["key_bits"] <= 32 else "u64",
+        "data": "synthetic",
+        "value_definition": "HBM-resident: request columns, servant table and results stay in "
+                            "HBM (kernels + one 200-byte outcome read-back per batch)%s; the "
+                            "host-buffer rate of SURVEY.md 8(d) is in end_to_end" % (
+                                ", two batches in flight (ydc_dispatch_device_async: the next "
+                                "batch is enqueued before the host reads the previous outcome; "
+                                "ms_per_step_synchronous = one batch at a time)" if pipelined else ""),
+        "pipeline_depth": 2 if pipelined else 1,
+        "ms_per_step_synchronous": sync_ms,
+        "config": {"workload": "%s%s%s: %s%s, %d classes" % (
+                       config, " with %d digests" % n_envs if full and args.digests else "",
+                       "" if world == 1 else " (%s scaling)" % scaling, shape,
+                       ", %.0f %% of the servants on shared hosts" % (100 * shared) if shared else "",
+                       st["n_classes"]),
+                   "parallelism": "1 GPU" if world == 1 else
+                                  ("one global batch of %d requests x %d servants sharded by "
+                                   "rank range over %d ranks on %d GPU(s), %s all-gather of boundary "
+                                   "states and servant-slot deltas" % (
+                                       n_all, n_serv, world, min(world, max(E.n_dev, 1)),
+                                       "RCCL" if E.transport == "rccl" else "mailbox (%s)" % E.transport)
+                                   if sharded else E.group_note),
+                   "inputs": "request columns + servant table resident in HBM; results in HBM"},
+        "p99_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.99),
+        "p50_dispatch_latency_ms": 1e3 * percentile(lat_all, 0.50),
+        "latency_samples": len(lat_all),
+        "stats": {k: v for k, v in st.items() if k != "stage_ms"},
+        "granted_all_ranks": int(granted_all),
+        "kernels_us_per_step": {k: 1e3 * v[1] / n_prof for k, v in prof.items()},
+        "kernel_launches_per_step": {k: v[0] / n_prof for k, v in prof.items()},
+    }
+    # The three rates side by side, whichever of them `value` is.
+    out["value_pipelined"] = out["value"] if pipelined else None
+    out["value_synchronous"] = (st["granted"] / (sync_ms * 1e-3) if sync_ms else
+                                (None if pipelined else out["value"]))
+    out["value_end_to_end"] = e2e["assignments_per_s"] if e2e else None
+    if full:
+        out["stage_ms"] = stage_ms
+    if e2e:
+        out["end_to_end"] = e2e
+        out["host_buffers_assignments_per_s"] = e2e["assignments_per_s"]
+    if steady:
+        out["steady_state_commit"] = steady
+    if E.use_dist:
+        # sharded: the N ranks placed ONE global batch through ydc_dispatch_sharded (false:
+        # no transport came up and every rank placed its own batch — not a scaling result).
+        out["sharded"] = bool(sharded)
+        out["transport"] = {"ipc-host": "ipc"}.get(E.transport, E.transport)
+        out["transport_detail"] = E.transport + ("" if not E.group_note else " (%s)" % E.group_note)
+        out["rccl_ranks"] = E.rccl_ranks
+        out["rccl"] = E.is_rccl
+        out["parity_vs_oracle"] = parity_oracle
+        out["devices"] = E.n_dev
+        out["ranks_per_device"] = E.ranks_per_device
+    # Pinned to the verbatim reference without a CPU replay: the committed placement of the
+    # first 50k requests of this very batch (a sequential batch's prefix is the prefix batch),
+    # and conservation: running_tasks after the batch - before = histogram of the placement.
+    if world == 1:
+        ref = fixture_prefix(config, sv, tk_all)
+        if ref is not None:
+            out["parity_vs_reference_fixture"] = bool(np.array_equal(host_idx[:len(ref)], ref))
+            out["fixture_requests"] = int(len(ref))
+        ok = host_idx < binding.IDX_ENV_NOT_FOUND
+        out["conservation"] = bool(np.array_equal(
+            host_run.astype(np.int64) - sv["running_tasks"].astype(np.int64),
+            np.bincount(host_idx[ok], minlength=n_serv)))
+    if prof:
+        dom = max(prof, key=lambda k: prof[k][1])
+        launches, total_ms = prof[dom]
+        # bytes(batch) = 16 N + 40 S; one launch of the dominant kernel
+        # (a matching pass) works on the whole batch of this rank.
+        alg_bytes = 16 * n_tasks + 40 * n_serv
+        avg_launch_s = (total_ms / launches) * 1e-3
+        ach = alg_bytes / avg_launch_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0,
+                           "unit": "GB/s", "frac": ach / 8000.0,
+                           "traffic": pmc_traffic(dom, config),
+                           "algorithmic_bytes_per_launch": alg_bytes,
+                           "avg_launch_us": avg_launch_s * 1e6,
+                           "launches_per_step": launches / n_prof,
+                           # The same bytes against the whole step (all kernels + host
+                           # turn-around): what a batch achieves, whatever the launch count.
+                           "per_step_GBps": alg_bytes / (elapsed / steps) / 1e9}
+        if full:
+            out["roofline"]["note"] = ("the dominant kernel is bound by the dependency chain of the "
+                                       "greedy merge, not by bandwidth: see DESIGN.md 3.4")
+    if full and world == 1 and not args.no_cpu_baseline:
+        ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
+        out["cpu_baseline"] = base
+        out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
+    return out
+
+
+COMPACT_KEYS = ("value", "unit", "ms_per_step", "ms_per_step_synchronous", "steps", "warmup", "scaling",
+                "n_gpus", "dtype", "p50_dispatch_latency_ms", "p99_dispatch_latency_ms",
+                "latency_samples", "kernels_us_per_step", "kernel_launches_per_step",
+                "parity_vs_reference_fixture", "fixture_requests", "fixture_ticks", "conservation",
+                "parity_vs_oracle", "sharded", "transport", "value_end_to_end")
+
+
+def compact(rec):
+    """A sub-record of the driver's line: what was timed, how long it took, whether it is right."""
+    if rec is None:
+        return None
+    c = {k: rec[k] for k in COMPACT_KEYS if k in rec}
+    c["workload"] = rec["config"]["workload"]
+    c["rounds"] = rec["stats"].get("rounds")
+    c["granted"] = rec["stats"].get("granted")
+    if "end_to_end" in rec:
+        c["end_to_end_ms"] = rec["end_to_end"]["ms_per_batch"]
+        c["end_to_end_p99_ms"] = rec["end_to_end"]["p99_ms"]
+    if "roofline" in rec:
+        c["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic",
+                                                         "avg_launch_us", "launches_per_step",
+                                                         "algorithmic_bytes_per_launch")
+                         if k in rec["roofline"]}
+    return c
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        # Never print a line whose n_gpus is not what was asked for.
+        print("[bench] --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to run"
+              % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.config == "cfg5":
+        if world != 1:
+            print("[bench] cfg5 (streaming) is a single-GPU configuration", file=sys.stderr)
+            return 2
+        out = stream_record(args, args.steps, args.warmup, 0 if args.no_cpu_baseline else 30,
+                            device=int(os.environ.get("LOCAL_RANK", 0)))
+        print(json.dumps(out))
+        return 0
+
+    E = setup(args)
+    out = measure_config(E, args, args.config, args.scaling, args.steps, args.warmup, "full")
+    extra = not args.no_extra_configs and not args.digests and not args.shared_ip_frac
+    if extra and E.world > 1 and E.sharded and not (args.config == "cfg4" and args.scaling == "strong"):
+        # BASELINE.json configs[3] as specified: 4M requests x 16k servants cut over the ranks.
+        E.phase("%s (%s) timed; cfg4 strong next" % (args.config, args.scaling))
+        k = max(3, min(args.steps, 20))
+        rec = measure_config(E, args, "cfg4", "strong", k, min(args.warmup, 3), "compact")
+        if out is not None:
+            out["strong_cfg4"] = compact(rec)
+    if extra and E.world == 1 and not E.use_dist and args.config == "cfg2" and not args.resident_only:
+        # The other single-GPU configurations of BASELINE.json on the same line.
+        out["configs"] = {}
+        for cfg in ("cfg3", "cfg4"):
+            k = max(5, min(args.steps, 20))
+            out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 3, "compact"))
+    line_obj = out
+    stuck = E.init_thread is not None and E.init_thread.is_alive()  # still inside ncclCommInitRank
+    if E.sharded:
+        if E.dist:
+            E.dist.barrier()  # nobody unmaps a mailbox a peer may still be writing to
+        E.ctx.group_destroy()
+    E.ctx.close()
+    if line_obj is not None and "configs" in line_obj:
+        rec = stream_record(args, 200, 20, 0, device=E.device)
+        c = compact(rec)
+        c["value_definition"] = rec["value_definition"]
+        line_obj["configs"]["cfg5"] = c
     # ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C
     # stdio, which would otherwise be flushed behind it at exit. Every rank flushes before the
     # last barrier; rank 0 prints after it.
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if line:
-        print(line, flush=True)
+    if E.dist:
+        E.dist.barrier()
+        E.dist.destroy_process_group()
+    if line_obj is not None:
+        print(json.dumps(line_obj), flush=True)
     if stuck:
         os._exit(0)  # (do not tear the context down under a bootstrap that never returned)
+    return 0
 
 
 def pmc_traffic(kernel, config):
@@ -609,4 +877,4 @@ def pmc_traffic(kernel, config):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -43,16 +43,23 @@ def validate(j, steps=None, streaming=False, cpu_baseline=True):
         assert j["parity_vs_cpu_baseline"] is True
     if not streaming:
         # value = granted requests x steps / wall time of the timed region
-        assert abs(j["value"] - j["stats"]["granted"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+        assert abs(j["value"] - j["granted_all_ranks"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+        if j["n_gpus"] == 1:
+            assert j["granted_all_ranks"] == j["stats"]["granted"]
         assert "HBM-resident" in j["value_definition"]
         assert j["latency_samples"] >= 100
         assert j["p99_dispatch_latency_ms"] >= j["p50_dispatch_latency_ms"] > 0
 
 
 def run_bench(*args, env=None, timeout=420):
+    e = dict(os.environ)
+    for k, v in (env or {}).items():
+        if v is None:
+            e.pop(k, None)
+        else:
+            e[k] = v
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT,
-                         env=dict(os.environ, **(env or {})), capture_output=True, text=True,
-                         timeout=timeout)
+                         env=e, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "bench.py must print exactly ONE JSON line: %r" % out.stdout[-800:]
@@ -72,6 +79,55 @@ def test_bench_cfg2_line():
     assert abs(e["assignments_per_s"] - j["stats"]["granted"] / (e["ms_per_batch"] * 1e-3)) < 1e-6 * e[
         "assignments_per_s"]
     assert j["roofline"]["kernel"] in j["kernels_us_per_step"]
+    # the three rates side by side, whichever of them `value` is
+    assert j["value_pipelined"] == j["value"] and j["value_synchronous"] > 0
+    assert j["value_end_to_end"] == e["assignments_per_s"]
+    # steady state: every batch COMMITs and its grants are released again
+    s = j["steady_state_commit"]
+    assert s["registry_restored"] is True and s["same_placement"] is True and s["ms_per_step"] > 0
+    # the other single-GPU configurations of BASELINE.json, timed in the same run and pinned to
+    # the committed fixtures of the verbatim reference
+    c = j["configs"]
+    assert set(c) == {"cfg3", "cfg4", "cfg5"}
+    assert "1000000 pending requests x 8000 servants" in c["cfg3"]["workload"]
+    assert "4000000 pending requests x 16000 servants" in c["cfg4"]["workload"]
+    for k in ("cfg3", "cfg4"):
+        r = c[k]
+        assert r["parity_vs_reference_fixture"] is True and r["fixture_requests"] == 50000
+        assert r["conservation"] is True and r["value"] > 0 and r["ms_per_step"] > 0
+        assert r["p99_dispatch_latency_ms"] >= r["p50_dispatch_latency_ms"] > 0
+        assert r["roofline"]["kernel"] in r["kernels_us_per_step"] and 0 < r["roofline"]["frac"] < 1
+        assert r["end_to_end_ms"] > 0
+    assert c["cfg5"]["parity_vs_reference_fixture"] is True and c["cfg5"]["fixture_ticks"] == 200
+    assert c["cfg5"]["steps"] == 200 and c["cfg5"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver would type it, no torch.distributed.run around
+    it: bench.py starts its two ranks itself; on the 1-GPU box they share device 0 and exchange
+    over the mailbox transport. ONE line, n_gpus 2, one global batch through ydc_dispatch_sharded,
+    the gathered placement equal to the oracle's — and BASELINE.json configs[3] (cfg4, strong)
+    timed beside the weak figure."""
+    env = {k: None for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    j = run_bench("--gpus", "2", "--steps", "3", "--warmup", "2", env=env, timeout=900)
+    validate(j, steps=3, cpu_baseline=False)
+    assert j["n_gpus"] == 2 and j["sharded"] is True and j["parity_vs_oracle"] is True
+    assert j["transport"] in ("ipc", "ipc-device", "rccl"), j["transport_detail"]
+    assert "200000 pending requests x 4000 servants" in j["config"]["workload"]
+    s = j["strong_cfg4"]
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["sharded"] is True
+    assert "4000000 pending requests x 16000 servants" in s["workload"]
+    assert s["parity_vs_oracle"] is True and s["value"] > 0
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus N under a launcher that started another number of ranks: no line at all rather
+    than a line whose n_gpus is not what was asked for (no GPU needed: refused before any)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 2 and "refusing" in out.stderr and "{" not in out.stdout
 
 
 @pytest.mark.gpu
@@ -79,6 +135,7 @@ def test_bench_cfg5_streaming_line():
     j = run_bench("--config", "cfg5", "--steps", "40", "--warmup", "5")
     validate(j, steps=40, streaming=True)
     assert j["parity_ticks"] >= 20 and "hipGraph" in j["config"]["workload"]
+    assert j["parity_vs_reference_fixture"] is True and j["fixture_ticks"] == 45
 
 
 @pytest.mark.gpu
