@@ -26,6 +26,13 @@ namespace yadcc::scheduler {
 class SchedulerServiceImpl_TokenWithIntersection_Test {
  public:
   static std::string Dump(TaskDispatcher* d) { return d->DumpInternals().Dump(); }
+  // The same door reaches the registry: presets `running_tasks` of the servant registered last
+  // (what millions of priming grants would leave there, without the minutes they take). Only
+  // placement reads it afterwards (GetCapacityAvailable, the pick); no TaskDesc stands behind
+  // the count, so such a registry is for dispatch-only cases.
+  static void PresetRunningOfLast(TaskDispatcher* d, std::size_t running) {
+    d->servants_.servants.back()->running_tasks = running;
+  }
 };
 }  // namespace yadcc::scheduler
 
@@ -38,6 +45,8 @@ struct ref_dispatcher {
 };
 
 namespace {
+
+constexpr std::uint32_t kPresetRunningFrom = 1u << 20;
 
 std::string Dotted(std::uint32_t ip, std::uint32_t port, bool with_port) {
   char buf[64];
@@ -188,7 +197,9 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
     auto location = Dotted(ip[i], port[i], true);
     bool is_new = d->index_of.count(location) == 0;
     std::uint32_t prime = (running_tasks && is_new) ? running_tasks[i] : 0;
-    if (prime) {
+    // Millions of priming grants take minutes: such counts are preset through the friend door.
+    const bool preset = prime >= kPresetRunningFrom;
+    if (prime && !preset) {
       // Install a wide-open personality under a digest only this servant has,
       // grant `prime` tasks to it, then install the real personality.
       ServantPersonality s{};
@@ -225,6 +236,8 @@ void ref_load_servants_wide(ref_dispatcher* d, size_t n, const uint32_t* version
     s.priority = static_cast<yadcc::scheduler::ServantPriority>(priority[i]);
     s.not_accepting_task_reason = yadcc::scheduler::NOT_ACCEPTING_TASK_REASON_UNKNOWN;
     d->impl.KeepServantAlive(s, 30s);
+    if (preset)
+      yadcc::scheduler::SchedulerServiceImpl_TokenWithIntersection_Test::PresetRunningOfLast(&d->impl, prime);
     d->index_of.emplace(location, static_cast<std::uint32_t>(d->index_of.size()));
   }
 }

@@ -121,6 +121,31 @@ def handmade_cases():
     return out
 
 
+def huge_capacity_pool(seed=31, n_servants=40, n_tasks=2500, n_envs=2):
+    """Capacities of 2^21 .. 2^23 with all but a few dozen slots taken: the fp64-key path
+    (task_dispatcher.cc:440-447 divides doubles; the integer key of the smaller pools is not
+    exact here). Utilisations differ in the 6th .. 7th digit; dedicated servants with
+    2 r < nproc and user servants, foreign load around `running` so that capacity moves with r."""
+    rng = np.random.default_rng(seed)
+    sv = synth.make_servants(n_servants, n_envs=n_envs, seed=seed)
+    nproc = rng.integers(1 << 21, 1 << 23, n_servants)
+    dedicated = sv["priority"] == synth.PRIORITY_DEDICATED
+    max_tasks = np.where(dedicated, (nproc * 95) // 100, (nproc * 40) // 100)
+    headroom = rng.integers(1, 90, n_servants)
+    # dedicated servants: some start below the half-way mark (tier 0) and cross it inside the
+    # batch (their max_tasks ends a few dozen slots above it), some start above
+    low = dedicated & (rng.random(n_servants) < 0.5)
+    max_tasks = np.where(low, nproc // 2 + rng.integers(1, 60, n_servants), max_tasks)
+    run = np.where(low, nproc // 2 - headroom, max_tasks - headroom)
+    sv["num_processors"] = nproc.astype(np.uint32)
+    sv["max_tasks"] = max_tasks.astype(np.uint32)
+    sv["running_tasks"] = run.astype(np.uint32)
+    sv["current_load"] = np.maximum(0, run + rng.integers(-40, 40, n_servants)).astype(np.uint32)
+    sv["memory_available"][:] = 64 * GIB
+    tk = synth.make_tasks(n_tasks, sv, n_envs=n_envs, seed=seed + 100, self_frac=0.2)
+    return sv, tk
+
+
 # ---------------------------------------------------------------------------
 # Full-size pools pinned to the VERBATIM reference: tests/golden/ref_cfg{3,4}_prefix_50k.npz hold
 # the reference's placement of the first 50k requests of the cfg3 / cfg4 batches (generated by

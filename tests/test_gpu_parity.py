@@ -51,6 +51,38 @@ def test_handmade_cases(ctx, name, sv, tk):
     check(ctx, sv, tk, "scan")
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_fp64_key_path_against_the_verbatim_reference(ctx, seed):
+    """Capacities of 2^21 .. 2^23 (key_bits == 64): the HIP path against the reference class itself
+    (oracle/_ref travels to the GPU box; its running_tasks are preset through the FRIEND_TEST
+    door of oracle/ref_driver.cc), and against the literal restatement."""
+    from oracle import refbind as R
+    sv, tk = cases.huge_capacity_pool(seed=seed)
+    st = check(ctx, sv, tk, "scan")
+    assert st["key_bits"] == 64
+    if not R.available():
+        pytest.skip("oracle/_ref is not built on this box")
+    d = R.RefDispatcher()
+    d.load_servants(sv)
+    ref_idx, _, _, _ = d.dispatch_batch(tk)
+    d.close()
+    got, _, _ = run_gpu(ctx, sv, tk)
+    assert np.array_equal(got, ref_idx)
+
+
+def test_handmade_huge_capacity_against_the_verbatim_reference(ctx):
+    from oracle import refbind as R
+    if not R.available():
+        pytest.skip("oracle/_ref is not built on this box")
+    name, sv, tk = [c for c in cases.handmade_cases() if c[0] == "huge_capacity"][0]
+    d = R.RefDispatcher()
+    d.load_servants(sv)
+    ref_idx, _, _, _ = d.dispatch_batch(tk)
+    d.close()
+    got, _, _ = run_gpu(ctx, sv, tk)
+    assert ctx.stats()["key_bits"] == 64 and np.array_equal(got, ref_idx)
+
+
 @pytest.mark.parametrize("shape", ["cfg2", "ragged", "oversubscribed"])
 def test_dispatch_device_caller_owned_outputs(ctx, shape):
     """ydc_dispatch_device — the entry point bench.py times — called directly: request columns

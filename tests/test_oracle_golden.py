@@ -203,12 +203,28 @@ def test_restatement_equals_verbatim_reference(name, kw):
 @pytest.mark.parametrize("name,sv,tk", cases.handmade_cases(),
                          ids=[c[0] for c in cases.handmade_cases()])
 def test_handmade_equals_verbatim_reference(name, sv, tk):
-    if name == "huge_capacity":
-        pytest.skip("priming millions of running tasks through the reference takes minutes")
+    # (huge_capacity — capacities >= 2^21, the fp64-key path — presets its millions of running
+    # tasks through the FRIEND_TEST door of oracle/ref_driver.cc instead of priming them)
     d = R.RefDispatcher()
     d.load_servants(sv)
     ref_idx, _, _, _ = d.dispatch_batch(tk)
     d.close()
+    for method in ("scan", "sorted"):
+        idx, _, _ = O.dispatch(sv, tk, method)
+        assert np.array_equal(idx, ref_idx), method
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_fp64_key_pools_equal_verbatim_reference(seed):
+    """Capacities >= 2^21 (the fp64-key path): both restatements against the reference itself,
+    whose running_tasks are preset through the FRIEND_TEST door of oracle/ref_driver.cc."""
+    sv, tk = cases.huge_capacity_pool(seed=seed)
+    d = R.RefDispatcher()
+    d.load_servants(sv)
+    ref_idx, _, _, _ = d.dispatch_batch(tk)
+    d.close()
+    assert (ref_idx < R.IDX_ENV_NOT_FOUND).sum() > 500 and (ref_idx == R.IDX_TIMEOUT).sum() > 0
     for method in ("scan", "sorted"):
         idx, _, _ = O.dispatch(sv, tk, method)
         assert np.array_equal(idx, ref_idx), method

@@ -175,6 +175,12 @@ def test_stream_wide_masks_env_change_and_append_inside_a_tick():
         if t == 4:
             with pytest.raises(binding.YdcError, match="ydc_stream_tick_wide"):
                 ctx.stream_tick(who, rows, rel, tk)  # narrow rows cannot introduce a servant here
+            # ... nor behind a structural heartbeat of a known servant (the scan for structure
+            # stops there; the newcomer must still be seen and refused, not read out of bounds)
+            rows2 = rows.copy()
+            rows2["version"][0] += 1
+            with pytest.raises(binding.YdcError, match="ydc_stream_tick_wide"):
+                ctx.stream_tick(who, rows2, rel, tk)
         got = ctx.stream_tick(who, rows, rel, tk, env_masks=masks)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (t, bad[:5], got[bad[:5]], want[bad[:5]])

@@ -5,8 +5,10 @@ Draws registries and batches from the seeded families of tests/cases.py with ran
 (1..8 digests — one or two half of the time: few classes, long class lists —, shared hosts,
 oversubscription, initial running_tasks, unknown digests, self requests, forced chunk and ring
 sizes, batches committed in two halves) for a given number of seconds and reports every mismatch.
-    python tests/tools/fuzz_parity.py [seconds=60] [first_seed=1000]
-Needs the GPU; the oracle is the checker (test infrastructure)."""
+    python tests/tools/fuzz_parity.py [seconds=60] [first_seed=1000] [max_cases=0]
+max_cases > 0 ends the run after that many cases (tests/test_fuzz_gpu.py: a bounded run inside
+`pytest -m gpu`, same seeds every time). Needs the GPU; the oracle is the checker (test
+infrastructure)."""
 import os
 import sys
 import time
@@ -22,11 +24,12 @@ from yadcc_amd import binding, pack  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     t_end = time.time() + budget
     n_cases = n_bad = 0
     ctxs = {}
     shapes = {}
-    while time.time() < t_end:
+    while time.time() < t_end and not (max_cases and n_cases >= max_cases):
         rng = np.random.default_rng(seed)
         kw = dict(seed=seed,
                   n_tasks=int(rng.choice([1, 63, 64, 65, 700, 5000, 30000, 120000])),

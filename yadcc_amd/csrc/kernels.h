@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
   // Pre-launched behind the matching passes: only takes effect once they have converged (and,
   // with a sharded sort, only if every rank's key window covered what its requests reached).
   const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss &&
-                     !(ra.pipelined && prm->pipeline_broken);
+                     !(ra.pipelined && (prm->pipeline_broken || prm->overflow));
   if (ra.pipelined && !final && blockIdx.x == req_blocks && threadIdx.x == 0) prm->pipeline_broken = 1;
   if (blockIdx.x < req_blocks) {
     if (!final) return;

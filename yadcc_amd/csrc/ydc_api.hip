@@ -325,7 +325,19 @@ namespace {
 void stream_release(ydc_context* c);  // streaming mode, defined further down
 void group_release(ydc_context* c);   // multi-GPU group, defined further down
 
-std::string g_create_error;  // errors raised before a context exists
+// Errors raised before (or without) a context: process-wide, written from any thread.
+std::mutex g_create_error_mu;
+std::string g_create_error_text;
+void set_create_error(std::string text) {
+  std::lock_guard<std::mutex> lk(g_create_error_mu);
+  g_create_error_text = std::move(text);
+}
+const char* create_error_cstr() {
+  static thread_local std::string copy;  // (the caller reads it after the lock is gone)
+  std::lock_guard<std::mutex> lk(g_create_error_mu);
+  copy = g_create_error_text;
+  return copy.c_str();
+}
 
 // Page-locked host ranges the device can address (ydc_host_register / ydc_host_alloc, or found
 // pinned by the caller's own means): ydc_dispatch hands such buffers to the kernels as they are —
@@ -352,9 +364,15 @@ void* pinned_device_pointer(const void* p, size_t bytes) {
   for (auto* np : g_not_pinned)
     if (np == p) return nullptr;
   // Pinned by the caller itself (hipHostMalloc / hipHostRegister outside this library)?
-  hipPointerAttribute_t a{};
-  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
-    return a.devicePointer;  // (asked again next time: its owner may free it behind our back)
+  // The whole range must lie in ONE pinned allocation: the last byte is asked about too and must
+  // map where the first one's mapping continues (a column longer than its pinned part is staged).
+  hipPointerAttribute_t a{}, z{};
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) {
+    if (bytes <= 1 ||
+        (hipPointerGetAttributes(&z, q + bytes - 1) == hipSuccess && z.type == hipMemoryTypeHost &&
+         z.devicePointer == (char*)a.devicePointer + (bytes - 1)))
+      return a.devicePointer;  // (asked again next time: its owner may free it behind our back)
+  }
   (void)hipGetLastError();
   if (g_not_pinned.size() >= 64) g_not_pinned.clear();
   g_not_pinned.push_back(p);
@@ -538,14 +556,14 @@ const char* ydc_strerror(int code) {
 }
 
 const char* ydc_last_error(const ydc_context* ctx) {
-  return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+  return ctx ? ctx->last_error.c_str() : create_error_cstr();
 }
 
 int ydc_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
-    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    set_create_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     return 0;
   }
   return n;
@@ -557,7 +575,7 @@ int ydc_device_malloc(int device, size_t bytes, void** out) {
   if (hipSetDevice(device) != hipSuccess) return YDC_ERR_NO_DEVICE;
   hipError_t e = hipMalloc(out, bytes ? bytes : 1);
   if (e != hipSuccess) {
-    g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    set_create_error(std::string("hipMalloc: ") + hipGetErrorString(e));
     return YDC_ERR_HIP;
   }
   return YDC_OK;
@@ -581,8 +599,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   int n_dev = 0;
   hipError_t de = hipGetDeviceCount(&n_dev);
   if (de != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
-    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(de) + ", " +
-                     std::to_string(n_dev) + " device(s), asked for " + std::to_string(device);
+    set_create_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(de) + ", " +
+                     std::to_string(n_dev) + " device(s), asked for " + std::to_string(device));
     return YDC_ERR_NO_DEVICE;
   }
   if (hipSetDevice(device) != hipSuccess) return YDC_ERR_NO_DEVICE;
@@ -1816,21 +1834,33 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
   pd.launched = 0;
   // A batch behind one that already has to be replayed is not worth enqueueing.
   const bool behind_rerun = c->pend_count == 1 && c->pend[c->pend_head].rerun;
-  if (int rc = plan_batch(c, N, &pd.plan)) return rc;
+  // A batch that cannot be enqueued completely is not outstanding: nothing of it can take effect
+  // without its finalise, which is enqueued last; the slot is free again.
+  auto give_up = [&](int rc) {
+    pd.active = false;
+    return rc;
+  };
+  if (int rc = plan_batch(c, N, &pd.plan)) return give_up(rc);
   if (behind_rerun || !pd.plan.wave_path || c->profiling || c->debug_verify_binsort) {
     // (registries without the wave path have host-checked rounds: placed when waited for)
     pd.rerun = true;
   } else {
-    if (int rc = enqueue_front(c, pd.plan, &pd.tk)) return rc;
+    if (int rc = enqueue_front(c, pd.plan, &pd.tk)) return give_up(rc);
     const uint32_t group = std::max(2u, std::min(c->round_hint, 16u));
     for (uint32_t r = 0; r < group; ++r) enqueue_pass(c, pd.plan, r, 1u);
     pd.launched = group;
     c->enqueue_pipelined = true;
     int rc = enqueue_finalize(c, pd.plan, flags, d_out_idx, d_out_util, d_out_running, (group - 1) & 63);
     c->enqueue_pipelined = false;
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(pd.h_outcome, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipEventRecord(pd.ev, c->stream));
+    if (rc) return give_up(rc);
+    // (from here on the batch may take effect: a failing copy / event leaves it to be waited for
+    // the slow way — a stream synchronise instead of the event)
+    if (hipMemcpyAsync(pd.h_outcome, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, c->stream) !=
+            hipSuccess ||
+        hipEventRecord(pd.ev, c->stream) != hipSuccess) {
+      (void)hipStreamSynchronize(c->stream);
+      return give_up(fail(c, YDC_ERR_HIP, "could not enqueue the outcome read-back of a pipelined batch"));
+    }
   }
   ++c->pend_count;
   return YDC_OK;
@@ -1853,8 +1883,15 @@ int ydc_dispatch_wait(ydc_context* c) {
     HIP_TRY(c, hipEventSynchronize(pd.ev));
     const DeviceParams& o = *pd.h_outcome;
     if (o.overflow) {
+      // Took no effect and latched the pipeline (k_finalize's gate includes overflow for
+      // pipelined batches), so the batch behind it has not taken any either: drain, clear the
+      // latch, leave that batch to be replayed when it is waited for, report this one.
+      const uint32_t bound = pd.plan.slot_bound;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->pipeline_broken, 0, 4, c->stream));
+      if (c->pend_count == 2) c->pend[c->pend_head ^ 1].rerun = true;
       pop();
-      return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", pd.plan.slot_bound);
+      return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", bound);
     }
     miss = o.pipeline_broken || (pd.plan.binsort && o.window_miss) || o.n_changed[(pd.launched - 1) & 63] != 0;
     if (!miss) {
@@ -1977,14 +2014,14 @@ int ydc_host_register(void* p, size_t bytes) {
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+    set_create_error(std::string("hipHostRegister: ") + hipGetErrorString(e));
     return YDC_ERR_HIP;
   }
   void* dev = nullptr;
   if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess || !dev) {
     (void)hipGetLastError();
     (void)hipHostUnregister(p);
-    g_create_error = "hipHostGetDevicePointer failed for a registered range";
+    set_create_error("hipHostGetDevicePointer failed for a registered range");
     return YDC_ERR_HIP;
   }
   std::lock_guard<std::mutex> lk(g_pinned_mu);
@@ -2011,7 +2048,7 @@ int ydc_host_alloc(size_t bytes, void** out) {
   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+    set_create_error(std::string("hipHostMalloc: ") + hipGetErrorString(e));
     return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? YDC_ERR_NO_DEVICE : YDC_ERR_HIP;
   }
   void* dev = nullptr;
@@ -2115,6 +2152,24 @@ int group_all_gather(ydc_context* c, const void* send, void* recv, size_t bytes)
     return YDC_OK;
   }
   return fail(c, YDC_ERR_INVALID_ARGUMENT, "context is not part of a group");
+}
+
+// The mailbox transport reports a late peer only through DeviceParams::exchange_timeout (the
+// words it waited for read as 0): whoever turns gathered words into sizes or inputs on the host
+// asks here first. Waits for the stream.
+int group_exchange_check(ydc_context* c) {
+  auto& g = c->group;
+  if (!g.box.kind) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return YDC_OK;
+  }
+  uint32_t late = 0;
+  HIP_TRY(c, hipMemcpyAsync(&late, &c->d_prm.p->exchange_timeout, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (late)
+    return fail(c, YDC_ERR_HIP, "a peer's data did not arrive within the mailbox time-out (rank %d of %d)",
+                g.rank, g.n_ranks);
+  return YDC_OK;
 }
 
 // What a rank hands its peers (ydc_group_ipc_export; YDC_IPC_HANDLE_BYTES).
@@ -2223,17 +2278,19 @@ extern "C" {
 int ydc_group_unique_id(void* out_id128) {
   if (!out_id128) return YDC_ERR_INVALID_ARGUMENT;
   static_assert(sizeof(ncclUniqueId) == 128, "ydc_group_unique_id hands out 128 bytes");
-  void* h = open_rccl(&g_create_error);
+  std::string rccl_err;
+  void* h = open_rccl(&rccl_err);
+  if (!h) set_create_error(rccl_err);
   if (!h) return YDC_ERR_HIP;
   auto fn = (decltype(&ncclGetUniqueId))dlsym(h, "ncclGetUniqueId");
   if (!fn) {
-    g_create_error = "librccl has no ncclGetUniqueId";
+    set_create_error("librccl has no ncclGetUniqueId");
     return YDC_ERR_HIP;
   }
   ncclUniqueId id;
   ncclResult_t r = fn(&id);
   if (r != ncclSuccess) {
-    g_create_error = "ncclGetUniqueId failed";
+    set_create_error("ncclGetUniqueId failed");
     return YDC_ERR_HIP;
   }
   std::memcpy(out_id128, &id, sizeof(id));
@@ -2501,7 +2558,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
     if (int rc = group_all_gather(c, g.d_totals.p + G, g.d_totals.p, 4)) return rc;
     std::vector<uint32_t> sizes(G);
     HIP_TRY(c, hipMemcpyAsync(sizes.data(), g.d_totals.p, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = group_exchange_check(c)) return rc;  // (a late peer's size would read as 0)
     uint32_t max_n = 1, total = 0, my_off = 0;
     for (uint32_t r = 0; r < G; ++r) {
       max_n = std::max(max_n, sizes[r]);
@@ -2528,6 +2585,8 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
         off += sizes[r];
       }
     }
+    // (... and a late peer's columns as zeros: nothing is placed, let alone committed, on them)
+    if (int rc = group_exchange_check(c)) return rc;
     ydc_task_soa all{g.d_all[0].p, g.d_all[1].p, g.d_all[2].p};
     if (int rc = ydc_dispatch_device(c, &all, total, flags, g.d_all_idx.p,
                                      d_out_util ? g.d_all_util.p : nullptr, d_out_running))
@@ -2941,12 +3000,14 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
   // environments, and a NEW servant (which would silently have none) is refused.
   const uint32_t EW = c->env_words;
   bool structural = false;
+  if (!upd_env_masks && EW > 1)  // (every entry is looked at: the scan below stops at the first structural one)
+    for (uint32_t i = 0; i < n_upd; ++i)
+      if (upd_idx[i] >= c->n_servants)
+        return fail(c, YDC_ERR_INVALID_ARGUMENT, "a tick that adds a servant to a table with %u mask "
+                    "words needs its environments: use ydc_stream_tick_wide", EW);
   for (uint32_t i = 0; i < n_upd && !structural; ++i) {
     const uint32_t s = upd_idx[i];
     if (s >= c->n_servants) {
-      if (!upd_env_masks && EW > 1)
-        return fail(c, YDC_ERR_INVALID_ARGUMENT, "a tick that adds a servant to a table with %u mask "
-                    "words needs its environments: use ydc_stream_tick_wide", EW);
       structural = true;
       break;
     }
@@ -2975,7 +3036,8 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
       // Rows without masks on a wide table: the (known) servants keep their environments.
       std::vector<uint64_t> env((size_t)n_upd * EW, 0);
       for (uint32_t i = 0; i < n_upd; ++i)
-        std::copy_n(&c->h_env[(size_t)upd_idx[i] * EW], EW, &env[(size_t)i * EW]);
+        if (upd_idx[i] < c->n_servants)  // (new servants were refused above)
+          std::copy_n(&c->h_env[(size_t)upd_idx[i] * EW], EW, &env[(size_t)i * EW]);
       if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, env.data(), EW, n_upd)) return rc;
     }
     graph_upd = 0;
