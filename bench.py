@@ -217,6 +217,88 @@ def stream_record(args, steps, warmup, ref_ticks, device=0):
     return out
 
 
+def td_surface(with_reference=True):
+    """The preserved TaskDispatcher surface (ydc_td_*: strings in, grant ids and location strings
+    out — what SchedulerServiceImpl would call) timed natively by tools/td_native_bench, one
+    caller thread: requests/s through ydc_td_wait_for_starting_new_tasks in batches of 10k and
+    100k, KeepServantAlive + NotifyServantRunningTasks per second and GetRunningTasks per second
+    at 16k servants / 10^6 live leases and at 2k servants / 10^5 leases — the
+    scale at which the verbatim reference is timed beside it (a bounded sample: its heartbeat is
+    two scans over every lease, task_dispatcher.cc:222-277,453-476)."""
+    tool = os.path.join(ROOT, "tools", "td_native_bench")
+    if not os.path.exists(tool):
+        return {"error": "tools/td_native_bench is not built (make native)"}
+    out = {"unit": "calls/s, one caller thread", "tool": "tools/td_native_bench (C++, through the C-ABI)"}
+    for name, argv in (("wait_batch_10k", ["wait", "2000", "10000", "50"]),
+                       ("wait_batch_100k", ["wait", "2000", "100000", "20"]),
+                       ("heartbeat_16k_servants_1M_leases", ["heartbeat", "16000", "1000000", "3"]),
+                       ("heartbeat_2k_servants_100k_leases", ["heartbeat", "2000", "100000", "5"])):
+        try:
+            r = subprocess.run([tool] + argv, capture_output=True, text=True, timeout=300, cwd=ROOT)
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {
+                "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
+    if with_reference:
+        try:
+            out["reference"] = reference_td_surface()
+        except Exception as e:  # noqa: BLE001
+            out["reference"] = {"error": str(e)}
+        ref, ours = out["reference"], out.get("heartbeat_2k_servants_100k_leases", {})
+        if "heartbeats_per_s" in ref and "heartbeats_per_s" in ours:
+            out["heartbeat_speedup_vs_reference_same_scale"] = ours["heartbeats_per_s"] / ref["heartbeats_per_s"]
+            # (per listed entry: the reference's sample only has the sampled servants' reports)
+            out["get_running_tasks_entries_speedup_vs_reference"] = (
+                ours["get_running_tasks_per_s"] * ours["running_tasks_listed"] /
+                (ref["get_running_tasks_per_s"] * max(ref["running_tasks_listed"], 1)))
+    return out
+
+
+def reference_td_surface(n_servants=2000, n_leases=100_000, heartbeats=150):
+    """The verbatim reference class (oracle/_ref) on the host: 2k servants, 10^5 live leases;
+    KeepServantAlive + NotifyServantRunningTasks of `heartbeats` servants, each reporting the
+    grants it holds, then GetRunningTasks. cpu_baseline leg: the oracle is the thing timed here,
+    never the product."""
+    from oracle import refbind as R
+    from yadcc_amd import synth
+    if not R.available():
+        return {"error": "oracle/_ref is not built"}
+    sv = synth.make_servants(n_servants, n_tasks_hint=2 * n_leases, n_envs=4, seed=42)
+    tk = synth.make_tasks(n_leases, sv, n_envs=4)
+    d = R.RefDispatcher()
+    d.load_servants(sv)
+    idx, ids, wait_secs, _ = d.dispatch_batch(tk)
+    ok = idx < R.IDX_ENV_NOT_FOUND
+    order = np.argsort(idx[ok], kind="stable")
+    held_idx, held_ids = idx[ok][order], ids[ok][order]
+    starts = np.searchsorted(held_idx, np.arange(n_servants + 1))
+    who = np.linspace(0, n_servants - 1, heartbeats).astype(np.int64)
+    rows = [{k: v[s:s + 1] for k, v in sv.items()} for s in who]
+    locs = ["%d.%d.%d.%d:%d" % (ip >> 24, (ip >> 16) & 255, (ip >> 8) & 255, ip & 255, port)
+            for ip, port in zip(sv["ip"][who].tolist(), sv["port"][who].tolist())]
+    reported = 0
+    t0 = time.perf_counter()
+    for s, row, loc in zip(who, rows, locs):
+        d.load_servants(row)  # KeepServantAlive of a known location (renewal)
+        mine = held_ids[starts[s]:starts[s + 1]]
+        unknown = d.notify_servant_running_tasks(loc, mine)
+        reported += len(mine) - len(unknown)
+    hb_secs = time.perf_counter() - t0
+    polls = 10
+    t0 = time.perf_counter()
+    for _ in range(polls):
+        listed = len(d.get_running_tasks(cap=n_leases))
+    poll_secs = time.perf_counter() - t0
+    d.close()
+    return {"kind": "reference", "cores": 1, "servants": n_servants, "leases": int(ok.sum()),
+            "wait_for_starting_new_task_per_s": float(ok.sum()) / wait_secs,
+            "heartbeats_per_s": heartbeats / hb_secs, "us_per_heartbeat": 1e6 * hb_secs / heartbeats,
+            "reported_tasks_per_heartbeat": reported / heartbeats,
+            "get_running_tasks_per_s": polls / poll_secs, "running_tasks_listed": listed,
+            "sample": "%d heartbeats (KeepServantAlive + NotifyServantRunningTasks), %d GetRunningTasks "
+                      "calls, %.1f s" % (heartbeats, polls, hb_secs + poll_secs)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -830,6 +912,9 @@ def main():
         for cfg in ("cfg3", "cfg4"):
             k = max(5, min(args.steps, 20))
             out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 3, "compact"))
+    if extra and E.world == 1 and not E.use_dist and not args.resident_only:
+        E.ctx.close()  # (the native tool opens its own context on the device)
+        out["td_surface"] = td_surface(with_reference=not args.no_cpu_baseline)
     line_obj = out
     stuck = E.init_thread is not None and E.init_thread.is_alive()  # still inside ncclCommInitRank
     if E.sharded:

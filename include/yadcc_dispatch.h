@@ -366,6 +366,9 @@ int ydc_td_wait_for_starting_new_tasks(ydc_td* td, size_t n, const char* const* 
 int ydc_td_keep_task_alive(ydc_td* td, uint64_t task_id, int64_t new_expires_in_ns);
 /* FreeTask, task_dispatcher.h:154. */
 int ydc_td_free_task(ydc_td* td, uint64_t task_id);
+/* n FreeTask calls under one lock acquisition (what the handler of a FreeTask RPC carrying
+ * several grant ids does in a loop, scheduler_service_impl.cc:307-309). */
+int ydc_td_free_tasks(ydc_td* td, const uint64_t* task_ids, size_t n);
 /* NotifyServantRunningTasks, task_dispatcher.h:175-176: returns the number of grant ids
  * unknown to the dispatcher; the first min(count, unknown_cap) are written to out_unknown. */
 int64_t ydc_td_notify_servant_running_tasks(ydc_td* td, const char* servant_location,
@@ -377,6 +380,16 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
                                  uint64_t* out_grant_ids, char* out_locations,
                                  size_t location_stride, char* out_digests, size_t digest_stride,
                                  size_t cap);
+/* Where the host class spent its time so far (cumulative, nanoseconds of the steady clock):
+ * device_ns inside the device API (registry deltas + ydc_dispatch), host_ns in the class itself
+ * (string lookups, lease records, results), both over `requests` placed requests in `batches`
+ * device batches; heartbeats seen / heartbeats that changed no device column; rebuilds of the
+ * flattened GetRunningTasks list (the rest of the calls shared the previous one). */
+typedef struct ydc_td_stats {
+  uint64_t requests, batches, device_ns, host_ns;
+  uint64_t heartbeats, heartbeats_unchanged, bookkeeper_rebuilds;
+} ydc_td_stats;
+int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out);
 /* OnExpirationTimer, task_dispatcher.cc:498-536 (for hosts that drive the 1 s tick themselves). */
 int ydc_td_on_expiration_timer(ydc_td* td);
 /* DumpInternals, task_dispatcher.cc:538-614, as JSON. Valid until the next call on td. */

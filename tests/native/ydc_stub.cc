@@ -161,6 +161,13 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
 
 int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
+  // Host-side profiling (tools/td_native_bench_stub): no placement at all — request i goes to
+  // servant i mod S — so that what is left on the clock is the host class itself.
+  static const bool round_robin = std::getenv("YDC_STUB_ROUND_ROBIN") != nullptr;
+  if (round_robin && c->n()) {
+    for (uint32_t i = 0; i < N; ++i) out_idx[i] = i % c->n();
+    return YDC_OK;
+  }
   std::vector<uint32_t> run(c->n());
   int rc = model_dispatch_alias(c->n(), c->version.data(), c->nproc.data(), c->load.data(),
                                 c->max_tasks.data(), c->running.data(), c->flags.data(), c->env.data(),

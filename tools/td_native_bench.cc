@@ -1,91 +1,275 @@
-// Developer tool: throughput of the host class path in C++ (no Python marshalling):
-// GpuTaskDispatcher::WaitForStartingNewTasks on a registry of 2000 servants with 4 compiler
-// digests, batches of `batch` requests from distinct requestor hosts, every grant freed again
-// before the next batch. Prints requests/s per stage. Needs the GPU.
-//   tools/td_native_bench [batch=10000] [reps=20]
+// Throughput of the preserved TaskDispatcher surface (ydc_td_*, include/yadcc_dispatch.h) measured
+// natively — strings in, grant ids and location strings out, one caller thread, no Python
+// marshalling in the way. bench.py runs it and puts the numbers into `td_surface` beside the
+// verbatim reference's (oracle/_ref through oracle/refbind.py, bounded samples).
+//
+//   td_native_bench wait <servants> <batch> <reps>
+//       WaitForStartingNewTask x batch as one ydc_td_wait_for_starting_new_tasks call, every grant
+//       freed again (ydc_td_free_tasks) before the next batch; twice: every request from its own
+//       requestor address with the digests interleaved (worst case for the lookups), and in runs
+//       of 16 requests that share address and digest (what one WaitForStartingTask RPC asks for,
+//       scheduler_service_impl.cc:228-264).
+//   td_native_bench heartbeat <servants> <leases> <rounds>
+//       `leases` live grants spread over the pool, then rounds x (KeepServantAlive +
+//       NotifyServantRunningTasks of every servant, each reporting the grants it holds), then
+//       GetRunningTasks polls (task_dispatcher.cc:190-277, running_task_bookkeeper.cc:36-43).
+// Links libydc.so (GPU) or tests/native/libtd_stub.so (CPU model of the device API: host-side
+// profiling without a GPU). Prints one JSON object.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
 
-#include "gpu_task_dispatcher.h"
+#include "yadcc_dispatch.h"
 
-using namespace ydc;
-using namespace std::literals;
 using Clk = std::chrono::steady_clock;
+static double Secs(Clk::time_point a, Clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+static std::vector<std::string> g_digests;
+static const char* g_env_ptrs[4];
+
+static std::string Location(int i) {
+  return "10." + std::to_string(i >> 16) + "." + std::to_string((i >> 8) & 255) + "." + std::to_string(i & 255) + ":8335";
+}
+
+// The pool of SURVEY.md 8(d): core counts 64..256 (scaled by `scale`), 30 % dedicated, 95 % / 40 %
+// of the cores offered, a random subset of 4 digests per servant.
+static void Register(ydc_td* td, int n, std::mt19937_64& rng, int scale, std::vector<ydc_td_servant>* keep,
+                     std::vector<std::string>* locations, std::vector<std::vector<const char*>>* envs) {
+  const std::uint32_t nprocs[] = {64, 96, 128, 192, 256};
+  keep->resize(n);
+  locations->resize(n);
+  envs->resize(n);
+  for (int i = 0; i < n; ++i) {
+    ydc_td_servant& s = (*keep)[i];
+    std::memset(&s, 0, sizeof s);
+    (*locations)[i] = Location(i);
+    s.version = 20;
+    s.observed_location = s.reported_location = (*locations)[i].c_str();
+    s.num_processors = nprocs[rng() % 5] * scale;
+    const bool dedicated = rng() % 10 < 3;
+    s.priority = dedicated ? 1 : 2;
+    s.max_tasks = s.num_processors * (dedicated ? 95 : 40) / 100;
+    s.current_load = rng() % (s.num_processors / 2);
+    s.total_memory_in_bytes = 256ull << 30;
+    s.memory_available_in_bytes = 64ull << 30;
+    for (int d = 0; d < 4; ++d)
+      if (rng() % 2) (*envs)[i].push_back(g_env_ptrs[d]);
+    if ((*envs)[i].empty()) (*envs)[i].push_back(g_env_ptrs[0]);
+    s.env_digests = (*envs)[i].data();
+    s.n_envs = (*envs)[i].size();
+    if (ydc_td_keep_servant_alive(td, &s, 3600ll * 1000000000ll) != YDC_OK) std::exit(3);
+  }
+}
+
+static ydc_td* Create() {
+  ydc_td* td = nullptr;
+  if (ydc_td_create(0, nullptr, /*start_timer=*/0, /*fake_clock=*/0, &td) != YDC_OK || !td) {
+    std::fprintf(stderr, "ydc_td_create failed\n");
+    std::exit(2);
+  }
+  if (ydc_td_device_status(td) != YDC_OK) {
+    std::fprintf(stderr, "no device (status %d)\n", ydc_td_device_status(td));
+    std::exit(2);
+  }
+  return td;
+}
+
+struct WaitNumbers {
+  double requests_per_s, ms_per_batch, free_per_s, granted_per_batch, host_ns_per_request, device_ns_per_request;
+};
+
+static WaitNumbers TimeWait(ydc_td* td, std::size_t batch, int reps, bool rpc_runs) {
+  std::vector<std::string> ips(batch);
+  std::vector<const char*> ip_ptrs(batch), digest_ptrs(batch);
+  std::vector<std::uint32_t> minv(batch, 20);
+  for (std::size_t i = 0; i < batch; ++i) {
+    const std::size_t who = rpc_runs ? i / 16 : i;
+    ips[i] = "172." + std::to_string(16 + ((who >> 16) & 15)) + "." + std::to_string((who >> 8) & 255) + "." +
+             std::to_string(who & 255);
+    // (runs share the pointers, as the requests of one RPC share the strings of its message)
+    ip_ptrs[i] = rpc_runs && i % 16 ? ip_ptrs[i - 1] : ips[i].c_str();
+    digest_ptrs[i] = g_env_ptrs[who % 4];
+  }
+  std::vector<std::int32_t> status(batch);
+  std::vector<std::uint64_t> ids(batch), granted_ids;
+  constexpr std::size_t kStride = 32;
+  std::vector<char> locs(batch * kStride);
+  granted_ids.reserve(batch);
+  double wait_s = 0, free_s = 0;
+  std::size_t granted = 0;
+  ydc_td_stats s0{}, s1{};
+  for (int rep = -2; rep < reps; ++rep) {  // two warm-up rounds
+    if (rep == 0) ydc_td_host_stats(td, &s0);
+    auto t0 = Clk::now();
+    int rc = ydc_td_wait_for_starting_new_tasks(td, batch, ip_ptrs.data(), minv.data(), digest_ptrs.data(),
+                                                15ll * 1000000000ll, nullptr, status.data(), ids.data(),
+                                                locs.data(), kStride);
+    auto t1 = Clk::now();
+    if (rc < 0) {
+      std::fprintf(stderr, "device error %d\n", rc);
+      std::exit(1);
+    }
+    granted_ids.clear();
+    for (std::size_t i = 0; i < batch; ++i)
+      if (status[i] == YDC_TD_GRANTED) granted_ids.push_back(ids[i]);
+    auto t2 = Clk::now();
+    ydc_td_free_tasks(td, granted_ids.data(), granted_ids.size());
+    auto t3 = Clk::now();
+    if (rep >= 0) {
+      wait_s += Secs(t0, t1);
+      free_s += Secs(t2, t3);
+      granted += granted_ids.size();
+    }
+  }
+  ydc_td_host_stats(td, &s1);
+  const double reqs = (double)(s1.requests - s0.requests);
+  return {batch * reps / wait_s, 1e3 * wait_s / reps, granted / free_s, (double)granted / reps,
+          reqs ? (s1.host_ns - s0.host_ns) / reqs : 0, reqs ? (s1.device_ns - s0.device_ns) / reqs : 0};
+}
+
+static void PrintWait(const char* name, const WaitNumbers& w, bool last) {
+  std::printf("\"%s\": {\"requests_per_s\": %.0f, \"ms_per_batch\": %.4f, \"granted_per_batch\": %.1f, "
+              "\"free_tasks_per_s\": %.0f, \"host_ns_per_request\": %.1f, \"device_ns_per_request\": %.1f}%s",
+              name, w.requests_per_s, w.ms_per_batch, w.granted_per_batch, w.free_per_s, w.host_ns_per_request,
+              w.device_ns_per_request, last ? "" : ", ");
+}
+
+static int WaitMode(int n_servants, std::size_t batch, int reps) {
+  ydc_td* td = Create();
+  std::mt19937_64 rng(1);
+  std::vector<ydc_td_servant> sv;
+  std::vector<std::string> locations;
+  std::vector<std::vector<const char*>> envs;
+  // capacity ~ 1.5 x the batch so that (almost) every request is granted
+  const int scale = std::max<int>(1, (int)(batch * 3 / 2 / ((std::size_t)n_servants * 70) + 1));
+  Register(td, n_servants, rng, scale, &sv, &locations, &envs);
+  const WaitNumbers distinct = TimeWait(td, batch, reps, false);
+  const WaitNumbers runs = TimeWait(td, batch, reps, true);
+  std::printf("{\"mode\": \"wait\", \"servants\": %d, \"batch\": %zu, \"reps\": %d, ", n_servants, batch, reps);
+  PrintWait("distinct_requestors", distinct, false);
+  PrintWait("rpc_runs_of_16", runs, true);
+  std::printf("}\n");
+  ydc_td_destroy(td);
+  return 0;
+}
+
+static int HeartbeatMode(int n_servants, std::size_t leases, int rounds) {
+  ydc_td* td = Create();
+  std::mt19937_64 rng(2);
+  std::vector<ydc_td_servant> sv;
+  std::vector<std::string> locations;
+  std::vector<std::vector<const char*>> envs;
+  const int scale = std::max<int>(1, (int)(leases * 2 / ((std::size_t)n_servants * 70) + 1));
+  Register(td, n_servants, rng, scale, &sv, &locations, &envs);
+  // Grants: batches of 100k requests until `leases` are live; the location string of every grant
+  // says which servant holds it ("10.a.b.c:8335" -> index).
+  std::vector<std::vector<ydc_td_running_task>> held(n_servants);
+  std::string task_digest(64, 'a');
+  {
+    const std::size_t batch = std::min<std::size_t>(leases, 100000);
+    std::vector<std::string> ips(batch);
+    std::vector<const char*> ip_ptrs(batch), digest_ptrs(batch);
+    std::vector<std::uint32_t> minv(batch, 20);
+    for (std::size_t i = 0; i < batch; ++i) {
+      ips[i] = "172.16." + std::to_string((i >> 8) & 255) + "." + std::to_string(i & 255);
+      ip_ptrs[i] = ips[i].c_str();
+      digest_ptrs[i] = g_env_ptrs[i % 4];
+    }
+    std::vector<std::int32_t> status(batch);
+    std::vector<std::uint64_t> ids(batch);
+    constexpr std::size_t kStride = 32;
+    std::vector<char> locs(batch * kStride);
+    std::size_t live = 0;
+    while (live < leases) {
+      const std::size_t n = std::min(batch, leases - live);
+      int rc = ydc_td_wait_for_starting_new_tasks(td, n, ip_ptrs.data(), minv.data(), digest_ptrs.data(),
+                                                  3600ll * 1000000000ll, nullptr, status.data(), ids.data(),
+                                                  locs.data(), kStride);
+      if (rc < 0) {
+        std::fprintf(stderr, "device error %d\n", rc);
+        return 1;
+      }
+      std::size_t got = 0;
+      for (std::size_t i = 0; i < n; ++i) {
+        if (status[i] != YDC_TD_GRANTED) continue;
+        unsigned a, b, c, d;
+        if (std::sscanf(locs.data() + i * kStride, "%u.%u.%u.%u", &a, &b, &c, &d) != 4) return 1;
+        const int s = (int)((b << 16) | (c << 8) | d);
+        ydc_td_running_task t{};
+        t.servant_task_id = held[s].size();
+        t.task_grant_id = ids[i];
+        t.servant_location = locations[s].c_str();
+        t.task_digest = task_digest.c_str();
+        held[s].push_back(t);
+        ++got;
+      }
+      if (!got) {
+        std::fprintf(stderr, "pool exhausted at %zu leases\n", live);
+        return 1;
+      }
+      live += got;
+    }
+  }
+  std::vector<std::uint64_t> unknown(1024);
+  // Round 0 fills the bookkeeper (every list is new); the following rounds report the same lists
+  // with a new load figure, which is what steady-state heartbeats look like.
+  double first_s = 0, steady_s = 0;
+  std::size_t unknown_total = 0;
+  for (int r = 0; r < rounds + 1; ++r) {
+    auto t0 = Clk::now();
+    for (int s = 0; s < n_servants; ++s) {
+      sv[s].current_load = (sv[s].current_load + 1) % (sv[s].num_processors / 2);
+      ydc_td_keep_servant_alive(td, &sv[s], 3600ll * 1000000000ll);
+      const std::int64_t u = ydc_td_notify_servant_running_tasks(td, locations[s].c_str(), held[s].data(),
+                                                               held[s].size(), unknown.data(), unknown.size());
+      unknown_total += (std::size_t)std::max<std::int64_t>(u, 0);
+    }
+    const double dt = Secs(t0, Clk::now());
+    if (r == 0) first_s = dt; else steady_s += dt;
+  }
+  // GetRunningTasks: ids only, and with the location strings.
+  std::vector<std::uint64_t> st(leases), gr(leases);
+  std::vector<char> locs(leases * 32);
+  const int polls = 20;
+  auto p0 = Clk::now();
+  std::int64_t total = 0;
+  for (int i = 0; i < polls; ++i) total = ydc_td_get_running_tasks(td, st.data(), gr.data(), nullptr, 0, nullptr, 0, leases);
+  auto p1 = Clk::now();
+  for (int i = 0; i < polls; ++i) total = ydc_td_get_running_tasks(td, st.data(), gr.data(), locs.data(), 32, nullptr, 0, leases);
+  auto p2 = Clk::now();
+  ydc_td_stats hs{};
+  ydc_td_host_stats(td, &hs);
+  std::printf("{\"mode\": \"heartbeat\", \"servants\": %d, \"leases\": %zu, \"rounds\": %d, "
+              "\"heartbeats_per_s\": %.0f, \"us_per_heartbeat\": %.3f, \"first_round_heartbeats_per_s\": %.0f, "
+              "\"reported_tasks_per_heartbeat\": %.1f, \"unknown_reported\": %zu, "
+              "\"get_running_tasks_per_s\": %.1f, \"get_running_tasks_with_locations_per_s\": %.1f, "
+              "\"running_tasks_listed\": %lld, \"bookkeeper_rebuilds\": %llu}\n",
+              n_servants, leases, rounds, (double)n_servants * rounds / steady_s,
+              1e6 * steady_s / ((double)n_servants * rounds), n_servants / first_s,
+              (double)leases / n_servants, unknown_total, polls / Secs(p0, p1), polls / Secs(p1, p2),
+              (long long)total, (unsigned long long)hs.bookkeeper_rebuilds);
+  ydc_td_destroy(td);
+  return 0;
+}
 
 int main(int argc, char** argv) {
-  const std::size_t batch = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 10000;
-  const int reps = argc > 2 ? std::atoi(argv[2]) : 20;
-  GpuTaskDispatcher::Options opt;
-  opt.device = 0;
-  opt.start_expiration_timer = false;
-  GpuTaskDispatcher td(opt);
-  if (td.device_status() != 0) {
-    std::fprintf(stderr, "no device: %s\n", td.device_error_message().c_str());
-    return 2;
-  }
-  std::mt19937_64 rng(1);
-  std::vector<std::string> digests;
   for (int i = 0; i < 4; ++i) {
     char b[80];
     std::snprintf(b, sizeof b, "%064x", 0xc0ffee + i);
-    digests.push_back(b);
+    g_digests.push_back(b);
   }
-  const std::uint32_t nprocs[] = {64, 96, 128, 192, 256};
-  for (int i = 0; i < 2000; ++i) {
-    ServantPersonality s;
-    s.version = 20;
-    s.observed_location = s.reported_location =
-        "10." + std::to_string(i >> 16) + "." + std::to_string((i >> 8) & 255) + "." + std::to_string(i & 255) + ":8335";
-    s.num_processors = nprocs[rng() % 5];
-    const bool dedicated = rng() % 10 < 3;
-    s.priority = dedicated ? kServantPriorityDedicated : kServantPriorityUser;
-    s.max_tasks = s.num_processors * (dedicated ? 95 : 40) / 100;
-    s.current_load = rng() % s.num_processors;
-    s.total_memory_in_bytes = 256ull << 30;
-    s.memory_available_in_bytes = 64ull << 30;
-    for (auto&& d : digests)
-      if (rng() % 2) s.environments.push_back(d);
-    if (s.environments.empty()) s.environments.push_back(digests[0]);
-    td.KeepServantAlive(s, 30s);
-  }
-  std::vector<TaskPersonality> reqs(batch);
-  for (std::size_t i = 0; i < batch; ++i) {
-    reqs[i].requestor_ip = "172.16." + std::to_string((i >> 8) & 255) + "." + std::to_string(i & 255);
-    reqs[i].min_version = 20;
-    reqs[i].compiler_digest = digests[i % 4];
-  }
-  const std::vector<bool> prefetching(batch, false);
-  double wait_s = 0, free_s = 0;
-  std::size_t granted = 0;
-  for (int rep = -2; rep < reps; ++rep) {  // two warm-up rounds
-    auto t0 = Clk::now();
-    auto rs = td.WaitForStartingNewTasks(reqs, 15s, prefetching);
-    auto t1 = Clk::now();
-    std::size_t g = 0;
-    for (auto&& r : rs) {
-      if (r.device_error) {
-        std::fprintf(stderr, "device error %d\n", r.device_error);
-        return 1;
-      }
-      if (r) {
-        td.FreeTask(r->task_id);
-        ++g;
-      }
-    }
-    auto t2 = Clk::now();
-    if (rep >= 0) {
-      wait_s += std::chrono::duration<double>(t1 - t0).count();
-      free_s += std::chrono::duration<double>(t2 - t1).count();
-      granted += g;
-    }
-  }
-  std::printf("{\"batch\": %zu, \"reps\": %d, \"granted_per_batch\": %.1f, "
-              "\"wait_requests_per_s\": %.0f, \"wait_ms_per_batch\": %.3f, \"free_tasks_per_s\": %.0f}\n",
-              batch, reps, (double)granted / reps, batch * reps / wait_s, 1e3 * wait_s / reps,
-              granted / free_s);
-  return 0;
+  for (int i = 0; i < 4; ++i) g_env_ptrs[i] = g_digests[i].c_str();
+  const std::string mode = argc > 1 ? argv[1] : "wait";
+  if (mode == "wait")
+    return WaitMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 10000,
+                    argc > 4 ? std::atoi(argv[4]) : 20);
+  if (mode == "heartbeat")
+    return HeartbeatMode(argc > 2 ? std::atoi(argv[2]) : 16000, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 1000000,
+                         argc > 4 ? std::atoi(argv[4]) : 3);
+  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat ...\n");
+  return 2;
 }

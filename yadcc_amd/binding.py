@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (YDC_LIB: a measurement build of the same library, e.g. libydc_probe.so — tools/phase_probe.py)
 LIB_PATH = os.environ.get("YDC_LIB") or os.path.join(_HERE, "libydc.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 IPC_HANDLE_BYTES = 256
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_LOCAL, TRANSPORT_IPC_DEVICE, TRANSPORT_IPC_HOST = range(5)
 TRANSPORT_NAMES = ("none", "rccl", "local", "ipc", "ipc-host")
@@ -41,6 +41,7 @@ ABI_SYMBOLS = (
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
+    "ydc_td_free_tasks", "ydc_td_host_stats",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
     "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
 )

@@ -108,26 +108,135 @@ const char* ReasonName(int r) {  // NotAcceptingTaskReason_Name, api/scheduler.p
 // ---------------------------------------------------------------------------
 void RunningTaskBookkeeper::SetServantRunningTasks(const std::string& servant_location,
                                                    std::vector<RunningTask> tasks) {
-  std::scoped_lock _(lock_);
-  running_tasks_[servant_location] = std::move(tasks);
-  flattened_valid_ = false;
+  std::vector<RunningTaskView> views(tasks.size());
+  std::vector<std::uint32_t> keep(tasks.size());
+  for (std::size_t i = 0; i != tasks.size(); ++i) {
+    views[i] = {tasks[i].servant_task_id, tasks[i].task_grant_id, tasks[i].servant_location,
+                tasks[i].task_digest};
+    keep[i] = (std::uint32_t)i;
+  }
+  SetServantRunningTasks(servant_location, views.data(), keep.data(), keep.size());
 }
 
-void RunningTaskBookkeeper::DropServant(const std::string& servant_location) {
+void RunningTaskBookkeeper::SetServantRunningTasks(std::string_view servant_location,
+                                                   const RunningTaskView* tasks,
+                                                   const std::uint32_t* keep, std::size_t n_keep) {
   std::scoped_lock _(lock_);
-  if (running_tasks_.erase(servant_location)) flattened_valid_ = false;
+  std::vector<RunningTask>* have = running_tasks_.find(servant_location);
+  if (have && have->size() == n_keep) {
+    // The report of a second ago, most of the time: nothing to replace, nothing to invalidate
+    // (the reference erases and re-inserts, running_task_bookkeeper.cc:24-29 — same content).
+    bool same = true;
+    for (std::size_t k = 0; k != n_keep && same; ++k) {
+      const RunningTaskView& t = tasks[keep[k]];
+      const RunningTask& h = (*have)[k];
+      same = h.task_grant_id == t.task_grant_id && h.servant_task_id == t.servant_task_id &&
+             h.servant_location == t.servant_location && h.task_digest == t.task_digest;
+    }
+    if (same) return;
+  }
+  if (!have) have = running_tasks_.emplace(servant_location, {}).first;
+  have->resize(n_keep);
+  for (std::size_t k = 0; k != n_keep; ++k) {
+    const RunningTaskView& t = tasks[keep[k]];
+    RunningTask& h = (*have)[k];
+    h.servant_task_id = t.servant_task_id;
+    h.task_grant_id = t.task_grant_id;
+    h.servant_location.assign(t.servant_location.data(), t.servant_location.size());
+    h.task_digest.assign(t.task_digest.data(), t.task_digest.size());
+  }
+  flattened_.reset();
 }
 
-std::vector<RunningTask> RunningTaskBookkeeper::GetRunningTasks() const {
+void RunningTaskBookkeeper::DropServant(std::string_view servant_location) {
   std::scoped_lock _(lock_);
-  if (!flattened_valid_) {
+  const std::vector<RunningTask>* have = running_tasks_.find(servant_location);
+  if (!have) return;
+  const bool had_tasks = !have->empty();
+  running_tasks_.erase(servant_location);
+  if (had_tasks) flattened_.reset();
+}
+
+RunningTaskBookkeeper::Snapshot RunningTaskBookkeeper::GetRunningTasksShared() const {
+  std::scoped_lock _(lock_);
+  if (!flattened_) {
     // Order across servants is unspecified in the reference (hash-map order,
     // running_task_bookkeeper.cc:39-41); order within a servant is kept.
-    flattened_.clear();
-    for (auto&& [k, v] : running_tasks_) flattened_.insert(flattened_.end(), v.begin(), v.end());
-    flattened_valid_ = true;
+    auto flat = std::make_shared<std::vector<RunningTask>>();
+    std::size_t total = 0;
+    running_tasks_.for_each([&](const std::string&, const std::vector<RunningTask>& v) { total += v.size(); });
+    flat->reserve(total);
+    running_tasks_.for_each([&](const std::string&, const std::vector<RunningTask>& v) {
+      flat->insert(flat->end(), v.begin(), v.end());
+    });
+    flattened_ = std::move(flat);
+    ++rebuilds_;
   }
   return flattened_;
+}
+
+std::vector<RunningTask> RunningTaskBookkeeper::GetRunningTasks() const { return *GetRunningTasksShared(); }
+
+// ---------------------------------------------------------------------------
+// Task records
+// ---------------------------------------------------------------------------
+GpuTaskDispatcher::Task* GpuTaskDispatcher::TaskTable::find(std::uint64_t id) {
+  const std::uint64_t page = id >> kPageBits;
+  if (page < first_page_ || page - first_page_ >= pages_.size()) return nullptr;
+  Page* p = pages_[page - first_page_].get();
+  if (!p) return nullptr;
+  Task* t = &p->tasks[id & ((1u << kPageBits) - 1)];
+  return t->live ? t : nullptr;
+}
+
+GpuTaskDispatcher::Task* GpuTaskDispatcher::TaskTable::create(std::uint64_t id) {
+  const std::uint64_t page = id >> kPageBits;
+  if (pages_.empty()) first_page_ = page;
+  while (page - first_page_ >= pages_.size()) pages_.emplace_back();
+  auto& p = pages_[page - first_page_];
+  if (!p) {
+    if (!spare_.empty()) {
+      p = std::move(spare_.back());
+      spare_.pop_back();
+    } else {
+      p.reset(new Page);  // (records are initialised one by one as they are created)
+    }
+    p->live = 0;
+  }
+  Task* t = &p->tasks[id & ((1u << kPageBits) - 1)];
+  t->prev = kNoTask;
+  t->zombie = false;
+  t->live = true;
+  ++p->live;
+  ++live_;
+  return t;
+}
+
+void GpuTaskDispatcher::TaskTable::erase(std::uint64_t id) {
+  Task* t = find(id);
+  if (!t) return;
+  t->live = false;
+  --live_;
+  auto& p = pages_[(id >> kPageBits) - first_page_];
+  if (--p->live == 0) {
+    // (the page ids are still being handed out from stays: it is the back)
+    if (&p != &pages_.back()) {
+      if (spare_.size() < 64) spare_.push_back(std::move(p));
+      p.reset();
+    }
+    while (pages_.size() > 1 && !pages_.front()) {
+      pages_.pop_front();
+      ++first_page_;
+    }
+  }
+}
+
+std::uint32_t GpuTaskDispatcher::NamePool::intern(std::string_view s) {
+  if (const std::uint32_t* id = ids_.find(s)) return *id;
+  const std::uint32_t id = (std::uint32_t)names_.size();
+  names_.emplace_back(s);
+  ids_.emplace(s, id);
+  return id;
 }
 
 // ---------------------------------------------------------------------------
@@ -177,6 +286,13 @@ void GpuTaskDispatcher::TimerLoop() {
   }
 }
 
+GpuTaskDispatcher::HostStats GpuTaskDispatcher::host_stats() const {
+  std::scoped_lock _(allocation_lock_);
+  HostStats s = host_stats_;
+  s.bookkeeper_rebuilds = running_task_bookkeeper_.rebuilds();
+  return s;
+}
+
 std::size_t GpuTaskDispatcher::CapacityAvailable(const Servant& s) const {
   // GetCapacityAvailable, task_dispatcher.cc:283-313 (for DumpInternals only;
   // the dispatch path evaluates the same formula on the device).
@@ -188,21 +304,19 @@ std::size_t GpuTaskDispatcher::CapacityAvailable(const Servant& s) const {
   return std::min<std::size_t>(p.max_tasks, (std::size_t)cap);
 }
 
-std::uint32_t GpuTaskDispatcher::InternIp(const std::string& ip, bool create) {
-  auto it = ip_ids_.find(ip);
-  if (it != ip_ids_.end()) return it->second;
+std::uint32_t GpuTaskDispatcher::InternIp(std::string_view ip, bool create) {
+  if (const std::uint32_t* id = ip_ids_.find(ip)) return *id;
   if (!create) return 0;  // 0: no servant lives there
-  std::uint32_t id = (std::uint32_t)ip_ids_.size() + 1;
+  const std::uint32_t id = (std::uint32_t)ip_ids_.size() + 1;
   ip_ids_.emplace(ip, id);
   return id;
 }
 
-std::uint32_t GpuTaskDispatcher::RequestorId(const std::string& ip) {
+std::uint32_t GpuTaskDispatcher::RequestorId(std::string_view ip) {
   if (!shorter_prefix_refs_.empty()) {
     // Some location answers to `ip` through one of its shorter prefixes: from now on that is an
     // entry of the device's lookup table (next UnsafeSyncDevice).
-    auto a = alias_ids_.find(ip);
-    if (a != alias_ids_.end()) return a->second;
+    if (const std::uint32_t* a = alias_ids_.find(ip)) return *a;
     if (shorter_prefix_refs_.count(ip)) {
       const std::uint32_t id = InternIp(ip, true);
       alias_ids_.emplace(ip, id);
@@ -213,9 +327,8 @@ std::uint32_t GpuTaskDispatcher::RequestorId(const std::string& ip) {
   return InternIp(ip, false);
 }
 
-std::uint32_t GpuTaskDispatcher::LookupEnv(const std::string& digest) const {
-  auto it = env_ids_.find(digest);
-  return it == env_ids_.end() ? 0xFFFFFFFFu : it->second.first;  // unknown: nobody has it
+const GpuTaskDispatcher::EnvEntry* GpuTaskDispatcher::LookupEnv(std::string_view digest) const {
+  return env_ids_.find(digest);  // null: nobody has it
 }
 
 // Interns the digests a servant advertises: one bit number per digest, as many 64-bit mask
@@ -223,34 +336,37 @@ std::uint32_t GpuTaskDispatcher::LookupEnv(const std::string& digest) const {
 // EnvironmentDesc per servant, task_dispatcher.h:93-94 — no limit here either). Returns
 // the bit numbers in listing order; a digest listed twice holds two references, and
 // ReleaseEnvBits walks the same list.
-std::vector<std::uint32_t> GpuTaskDispatcher::AcquireEnvBits(const std::vector<std::string>& digests) {
+template <class Strings>
+std::vector<std::uint32_t> GpuTaskDispatcher::AcquireEnvBits(const Strings& digests, std::size_t n) {
   std::vector<std::uint32_t> bits;
-  bits.reserve(digests.size());
-  for (auto&& d : digests) {
-    auto it = env_ids_.find(d);
-    if (it == env_ids_.end()) {
-      std::uint32_t bit;
+  bits.reserve(n);
+  for (std::size_t i = 0; i != n; ++i) {
+    const std::string_view d = digests[i];
+    EnvEntry* e = env_ids_.find(d);
+    if (!e) {
+      EnvEntry fresh;
       if (!free_env_bits_.empty()) {
-        bit = free_env_bits_.back();
+        fresh.bit = free_env_bits_.back();
         free_env_bits_.pop_back();
       } else {
-        bit = next_env_bit_++;
+        fresh.bit = next_env_bit_++;
       }
-      it = env_ids_.emplace(d, std::make_pair(bit, 0u)).first;
+      fresh.name = names_.intern(d);
+      e = env_ids_.emplace(d, fresh).first;
     }
-    ++it->second.second;
-    bits.push_back(it->second.first);
+    ++e->refs;
+    bits.push_back(e->bit);
   }
   return bits;
 }
 
 void GpuTaskDispatcher::ReleaseEnvBits(const std::vector<std::string>& digests) {
   for (auto&& d : digests) {
-    auto it = env_ids_.find(d);
-    if (it == env_ids_.end()) continue;
-    if (--it->second.second == 0) {
-      free_env_bits_.push_back(it->second.first);
-      env_ids_.erase(it);
+    EnvEntry* e = env_ids_.find(d);
+    if (!e) continue;
+    if (--e->refs == 0) {
+      free_env_bits_.push_back(e->bit);
+      env_ids_.erase(d);
     }
   }
 }
@@ -260,31 +376,90 @@ void GpuTaskDispatcher::ReleaseEnvBits(const std::vector<std::string>& digests) 
 // ---------------------------------------------------------------------------
 void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
                                          std::chrono::nanoseconds expires_in) {
+  std::vector<std::string_view> envs(servant.environments.begin(), servant.environments.end());
+  ServantView v;
+  v.version = servant.version;
+  v.observed_location = servant.observed_location;
+  v.reported_location = servant.reported_location;
+  v.environments = envs.data();
+  v.n_environments = envs.size();
+  v.num_processors = servant.num_processors;
+  v.current_load = servant.current_load;
+  v.total_memory_in_bytes = servant.total_memory_in_bytes;
+  v.memory_available_in_bytes = servant.memory_available_in_bytes;
+  v.max_tasks = servant.max_tasks;
+  v.priority = servant.priority;
+  v.not_accepting_task_reason = servant.not_accepting_task_reason;
+  KeepServantAlive(v, expires_in);
+}
+
+void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono::nanoseconds expires_in) {
   std::scoped_lock _(allocation_lock_);
   auto now = Now();
-  auto it = index_of_location_.find(servant.observed_location);
+  ++host_stats_.heartbeats;
+  auto assign_scalars = [&](ServantPersonality& p) {
+    p.version = servant.version;
+    p.num_processors = servant.num_processors;
+    p.current_load = servant.current_load;
+    p.total_memory_in_bytes = servant.total_memory_in_bytes;
+    p.memory_available_in_bytes = servant.memory_available_in_bytes;
+    p.max_tasks = servant.max_tasks;
+    p.priority = servant.priority;
+    p.not_accepting_task_reason = servant.not_accepting_task_reason;
+  };
   std::uint32_t idx;
-  if (it != index_of_location_.end()) {
+  if (const std::uint32_t* known = index_of_location_.find(servant.observed_location)) {
     // Renewal: the personality is replaced wholesale, running_tasks,
     // ever_assigned_tasks, discovered_at and the registry position stay
-    // (task_dispatcher.cc:195-201).
-    idx = it->second;
+    // (task_dispatcher.cc:195-201). Most renewals repeat the environments (and often
+    // everything else) of the last one: the digests are only interned anew when the list
+    // changed, and a row whose device columns did not move is not sent again.
+    idx = *known;
     Servant* e = servants_[idx].get();
-    auto bits = AcquireEnvBits(servant.environments);
-    ReleaseEnvBits(e->personality.environments);
-    e->personality = servant;
-    e->env_bits = std::move(bits);
+    ServantPersonality& p = e->personality;
     e->expires_at = now + expires_in;
+    bool same_envs = p.environments.size() == servant.n_environments;
+    for (std::size_t k = 0; same_envs && k != servant.n_environments; ++k)
+      same_envs = std::string_view(p.environments[k]) == servant.environments[k];
+    const bool low_mem_was = p.total_memory_in_bytes != 0 && p.memory_available_in_bytes < min_memory_for_new_task_;
+    const bool low_mem_is = servant.total_memory_in_bytes != 0 &&
+                            servant.memory_available_in_bytes < min_memory_for_new_task_;
+    const bool same_row = same_envs && p.version == servant.version &&
+                          p.num_processors == servant.num_processors &&
+                          p.current_load == servant.current_load && p.max_tasks == servant.max_tasks &&
+                          p.priority == servant.priority && low_mem_was == low_mem_is;
+    if (!same_envs) {
+      auto bits = AcquireEnvBits(servant.environments, servant.n_environments);
+      ReleaseEnvBits(p.environments);
+      p.environments.assign(servant.environments, servant.environments + servant.n_environments);
+      e->env_bits = std::move(bits);
+    }
+    assign_scalars(p);
+    if (std::string_view(p.reported_location) != servant.reported_location)
+      p.reported_location.assign(servant.reported_location.data(), servant.reported_location.size());
+    if (same_row) {
+      ++host_stats_.heartbeats_unchanged;
+      return;
+    }
   } else {
     idx = (std::uint32_t)servants_.size();
     auto added = std::make_unique<Servant>();
     added->uid = next_servant_uid_++;
-    added->personality = servant;
+    added->index = idx;
+    ServantPersonality& p = added->personality;
+    assign_scalars(p);
+    p.observed_location.assign(servant.observed_location.data(), servant.observed_location.size());
+    p.reported_location.assign(servant.reported_location.data(), servant.reported_location.size());
+    if (p.observed_location.size() < sizeof(added->location_short)) {
+      added->location_len = (std::uint8_t)p.observed_location.size();
+      std::memcpy(added->location_short, p.observed_location.c_str(), p.observed_location.size() + 1);
+    }
+    p.environments.assign(servant.environments, servant.environments + servant.n_environments);
     added->discovered_at = now;
     added->expires_at = now + expires_in;
     added->running_tasks = 0;  // :210
-    added->env_bits = AcquireEnvBits(servant.environments);
-    auto prefixes = RequestorPrefixes(servant.observed_location);
+    added->env_bits = AcquireEnvBits(servant.environments, servant.n_environments);
+    auto prefixes = RequestorPrefixes(p.observed_location);
     // No ':' in the location: an id of its own that no requestor address can map to.
     added->ip_id = !prefixes.empty()
                        ? InternIp(prefixes.front(), true)
@@ -294,8 +469,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
       if (alias_ids_.count(prefixes[k])) aliases_dirty_ = true;
       added->shorter_prefixes.push_back(std::move(prefixes[k]));
     }
-    index_of_location_.emplace(servant.observed_location, idx);
-    index_of_uid_.emplace(added->uid, idx);
+    index_of_location_.emplace(p.observed_location, idx);
     servants_.push_back(std::move(added));
     row_is_dirty_.push_back(0);
   }
@@ -310,36 +484,42 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
 
 std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(
     const std::string& servant_location, std::vector<RunningTask> tasks) {
-  std::vector<std::uint64_t> task_grant_ids;
-  task_grant_ids.reserve(tasks.size());
-  for (auto&& t : tasks) task_grant_ids.push_back(t.task_grant_id);
+  std::vector<RunningTaskView> views(tasks.size());
+  for (std::size_t i = 0; i != tasks.size(); ++i)
+    views[i] = {tasks[i].servant_task_id, tasks[i].task_grant_id, tasks[i].servant_location,
+                tasks[i].task_digest};
+  return NotifyServantRunningTasks(std::string_view(servant_location), views.data(), views.size());
+}
 
+std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(std::string_view servant_location,
+                                                                        const RunningTaskView* tasks,
+                                                                        std::size_t n) {
+  std::vector<std::uint64_t> unknown_tasks;
   std::scoped_lock _(allocation_lock_);
-  auto it = index_of_location_.find(servant_location);
-  if (it == index_of_location_.end()) return task_grant_ids;  // :241-243
-  Servant* servant = servants_[it->second].get();
+  const std::uint32_t* known = index_of_location_.find(servant_location);
+  if (!known) {  // :241-243: the servant itself has expired — every reported id comes back
+    unknown_tasks.reserve(n);
+    for (std::size_t i = 0; i != n; ++i) unknown_tasks.push_back(tasks[i].task_grant_id);
+    return unknown_tasks;
+  }
+  Servant* servant = servants_[*known].get();
 
-  UnsafeSweepZombiesOf(servant, {task_grant_ids.begin(), task_grant_ids.end()});
+  UnsafeSweepZombiesOf(servant, tasks, n);
 
   // Tasks reported by the servant but not (or no longer) granted on it are
-  // returned, in report order (:256-273). `grants` is the per-servant index the
-  // reference rebuilds with a scan over every task.
-  std::vector<std::uint64_t> unknown_tasks;
-  std::vector<RunningTask> kept;
-  kept.reserve(tasks.size());
-  for (auto&& t : tasks) {
-    bool permitted = false;
-    if (servant->grants.count(t.task_grant_id)) {
-      auto ti = tasks_.find(t.task_grant_id);
-      permitted = ti != tasks_.end() && !ti->second.zombie;
-    }
-    if (permitted) {
-      kept.push_back(std::move(t));
+  // returned, in report order (:256-273). The task record names its servant: no
+  // scan over every task as in the reference.
+  static thread_local std::vector<std::uint32_t> kept;
+  kept.clear();
+  for (std::size_t i = 0; i != n; ++i) {
+    const Task* t = tasks_.find(tasks[i].task_grant_id);
+    if (t && t->servant == servant && !t->zombie) {
+      kept.push_back((std::uint32_t)i);
     } else {
-      unknown_tasks.push_back(t.task_grant_id);
+      unknown_tasks.push_back(tasks[i].task_grant_id);
     }
   }
-  running_task_bookkeeper_.SetServantRunningTasks(servant_location, std::move(kept));
+  running_task_bookkeeper_.SetServantRunningTasks(servant_location, tasks, kept.data(), kept.size());
   return unknown_tasks;
 }
 
@@ -352,43 +532,61 @@ std::vector<RunningTask> GpuTaskDispatcher::GetRunningTasks() const {
 // ---------------------------------------------------------------------------
 bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanoseconds new_expires_in) {
   std::scoped_lock _(allocation_lock_);
-  auto it = tasks_.find(task_id);
-  if (it == tasks_.end()) return false;  // :146-153
-  if (it->second.zombie) return false;   // :154-162
-  it->second.expires_at = Now() + new_expires_in;
+  Task* t = tasks_.find(task_id);
+  if (!t) return false;        // :146-153
+  if (t->zombie) return false;  // :154-162
+  t->expires_at = Now() + new_expires_in;
   return true;
 }
 
 void GpuTaskDispatcher::FreeTask(std::uint64_t task_id) {
   std::scoped_lock _(allocation_lock_);
-  UnsafeFreeTasks({task_id});
+  UnsafeFreeTasks(&task_id, 1);
 }
 
-void GpuTaskDispatcher::UnsafeFreeTasks(const std::vector<std::uint64_t>& task_ids) {
-  for (auto id : task_ids) {
-    auto it = tasks_.find(id);
-    if (it == tasks_.end()) return;  // quirk kept: bails out, no wake-up (:176-180)
-    auto si = index_of_uid_.find(it->second.servant_uid);
-    if (si != index_of_uid_.end()) {
-      Servant* s = servants_[si->second].get();
-      --s->running_tasks;  // :181
-      s->grants.erase(id);
-      if (!need_full_upload_) pending_release_.push_back(si->second);
-    }
-    tasks_.erase(it);
+void GpuTaskDispatcher::FreeTasks(const std::uint64_t* task_ids, std::size_t n) {
+  std::scoped_lock _(allocation_lock_);
+  // (n calls, not one call with n ids: an unknown id ends a call, not the others — :176-180)
+  for (std::size_t i = 0; i != n; ++i) UnsafeFreeTasks(task_ids + i, 1);
+}
+
+void GpuTaskDispatcher::UnsafeFreeTasks(const std::uint64_t* task_ids, std::size_t n) {
+  for (std::size_t i = 0; i != n; ++i) {
+    const std::uint64_t id = task_ids[i];
+    Task* t = tasks_.find(id);
+    if (!t) return;  // quirk kept: bails out, no wake-up (:176-180)
+    Servant* s = t->servant;
+    --s->running_tasks;  // :181
+    // unlink from the servant's grant list
+    if (t->prev != kNoTask) tasks_.slot(t->prev)->next = t->next; else s->grants_head = t->next;
+    if (t->next != kNoTask) tasks_.slot(t->next)->prev = t->prev;
+    --s->n_grants;
+    if (t->zombie) --s->n_zombies;
+    if (!need_full_upload_ && !s->removed) pending_release_.push_back(s->index);
+    tasks_.erase(id);
   }
   ++wake_epoch_;
   allocation_cv_.notify_all();  // :187
 }
 
-void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant,
-                                             const std::unordered_set<std::uint64_t>& running) {
-  std::vector<std::uint64_t> sweeping;  // :453-476
-  for (auto id : servant->grants) {
-    auto ti = tasks_.find(id);
-    if (ti != tasks_.end() && ti->second.zombie && running.count(id) == 0) sweeping.push_back(id);
+void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant, const RunningTaskView* reported,
+                                             std::size_t n) {
+  if (servant->n_zombies == 0) {
+    // Nothing to sweep — but the reference's UnsafeFreeTasks still ends in notify_all for an
+    // empty list (:187,453-476): every heartbeat of a known servant wakes the waiters.
+    UnsafeFreeTasks(nullptr, 0);
+    return;
   }
-  UnsafeFreeTasks(sweeping);
+  std::unordered_set<std::uint64_t> running;
+  running.reserve(n);
+  for (std::size_t i = 0; i != n; ++i) running.insert(reported[i].task_grant_id);
+  std::vector<std::uint64_t> sweeping;  // :453-476
+  for (std::uint64_t id = servant->grants_head; id != kNoTask;) {
+    const Task* t = tasks_.find(id);
+    if (t->zombie && running.count(id) == 0) sweeping.push_back(id);
+    id = t->next;
+  }
+  UnsafeFreeTasks(sweeping.data(), sweeping.size());
 }
 
 void GpuTaskDispatcher::OnExpirationTimer() {
@@ -401,6 +599,7 @@ void GpuTaskDispatcher::OnExpirationTimer() {
   for (std::uint32_t i = 0; i != servants_.size(); ++i)
     if (servants_[i]->expires_at < now) expired.push_back(i);
   std::vector<std::uint64_t> orphans;
+  std::vector<std::unique_ptr<Servant>> removed;  // alive until their orphans are freed
   if (!expired.empty()) {
     // Device first, while the host rows still have their old positions: the deltas recorded
     // against those positions, then an order-preserving compaction of the resident columns on
@@ -417,13 +616,14 @@ void GpuTaskDispatcher::OnExpirationTimer() {
         Servant* s = servants_[i].get();
         running_task_bookkeeper_.DropServant(s->personality.observed_location);
         ReleaseEnvBits(s->personality.environments);
-        orphans.insert(orphans.end(), s->grants.begin(), s->grants.end());
+        for (std::uint64_t id = s->grants_head; id != kNoTask; id = tasks_.find(id)->next) orphans.push_back(id);
         for (auto&& p : s->shorter_prefixes) {
-          auto it = shorter_prefix_refs_.find(p);
-          if (it != shorter_prefix_refs_.end() && --it->second == 0) shorter_prefix_refs_.erase(it);
+          std::uint32_t* refs = shorter_prefix_refs_.find(p);
+          if (refs && --*refs == 0) shorter_prefix_refs_.erase(p);
         }
         index_of_location_.erase(s->personality.observed_location);
-        index_of_uid_.erase(s->uid);
+        s->removed = true;
+        removed.push_back(std::move(servants_[i]));
       } else {
         if (w != i) servants_[w] = std::move(servants_[i]);
         ++w;
@@ -431,8 +631,8 @@ void GpuTaskDispatcher::OnExpirationTimer() {
     }
     servants_.resize(w);
     for (std::uint32_t i = 0; i != servants_.size(); ++i) {
-      index_of_location_[servants_[i]->personality.observed_location] = i;
-      index_of_uid_[servants_[i]->uid] = i;
+      servants_[i]->index = i;
+      *index_of_location_.find(servants_[i]->personality.observed_location) = i;
     }
     dirty_rows_.clear();
     pending_release_.clear();
@@ -440,18 +640,24 @@ void GpuTaskDispatcher::OnExpirationTimer() {
     if (!alias_ids_.empty()) aliases_dirty_ = true;  // (rows moved: the device dropped its aliases)
   }
   // UnsafeSweepOrphans (:478-496): tasks of vanished servants are forgotten at
-  // once. Their ids are exactly the grant sets of the servants removed above. Called on every
+  // once. Their ids are exactly the grant lists of the servants removed above. Called on every
   // tick, like the reference's (:518-520): UnsafeFreeTasks ends in notify_all even for an empty
   // list, so every parked waiter re-runs its loop at least once a second — that is how it gets
   // to see a new servant, a lighter load, or EnvironmentNotFound after the last eligible
   // servant expired (a heartbeat alone wakes nobody, :190-220).
-  UnsafeFreeTasks(orphans);
+  // (the servants are gone from the registry — Servant::removed —: no slot is released on
+  // the device for them)
+  UnsafeFreeTasks(orphans.data(), orphans.size());
+  removed.clear();
 
   // Expired leases become zombies; they keep their slot until the servant's
   // next heartbeat no longer lists them (:523-535, task_dispatcher.h:207-214).
-  for (auto&& [id, t] : tasks_) {
-    if (t.expires_at < now) t.zombie = true;
-  }
+  tasks_.for_each([&](std::uint64_t, Task& t) {
+    if (!t.zombie && t.expires_at < now) {
+      t.zombie = true;
+      ++t.servant->n_zombies;
+    }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -530,9 +736,8 @@ int GpuTaskDispatcher::UnsafeSyncAliases() {
   std::vector<std::uint32_t> ids, rows;
   for (std::uint32_t i = 0; i != servants_.size(); ++i)
     for (auto&& p : servants_[i]->shorter_prefixes) {
-      auto a = alias_ids_.find(p);
-      if (a != alias_ids_.end()) {
-        ids.push_back(a->second);
+      if (const std::uint32_t* a = alias_ids_.find(p)) {
+        ids.push_back(*a);
         rows.push_back(i);
       }
     }
@@ -561,29 +766,131 @@ GpuTaskDispatcher::HostColumn::~HostColumn() {
   }
 }
 
-void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
-  if (batch.empty()) return;
-  const std::uint32_t n = (std::uint32_t)batch.size();
+namespace {
+inline std::uint64_t NowNs() {
+  return (std::uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
+  const std::uint32_t n = (std::uint32_t)batch.n;
   std::uint32_t *env = col_env_.ensure(n), *minv = col_minv_.ensure(n), *rip = col_rip_.ensure(n),
                 *out = col_out_.ensure(n);
-  std::fill(out, out + n, YDC_IDX_TIMEOUT);
   // (requestor ids first: an address presented for the first time may add table aliases, which
-  // the sync below sends along)
-  for (std::uint32_t i = 0; i != n; ++i) rip[i] = RequestorId(batch[i]->personality->requestor_ip);
+  // the sync below sends along). Consecutive requests of one RPC share the requestor and the
+  // digest (scheduler_service_impl.cc:228-264): the last answer is tried first.
+  std::string_view last_ip, last_digest;
+  std::uint32_t last_ip_id = 0, last_env = 0xFFFFFFFFu, last_name = 0;
+  col_digest_name_.resize(n);
+  bool have_ip = false, have_digest = false;
+  for (std::uint32_t i = 0; i != n; ++i) {
+    const RequestView& r = batch[i];
+    if (!have_ip || r.requestor_ip.data() != last_ip.data() || r.requestor_ip.size() != last_ip.size()) {
+      last_ip = r.requestor_ip;
+      last_ip_id = RequestorId(last_ip);
+      have_ip = true;
+    }
+    rip[i] = last_ip_id;
+  }
+  const std::uint64_t t0 = NowNs();
   int rc = UnsafeSyncDevice();
+  std::uint64_t device_ns = NowNs() - t0;
   if (rc == YDC_OK) {
+    // Digests: the same view as the request before (one RPC's requests), else one of the last
+    // four distinct string objects of this batch (same address and length within one call: same
+    // bytes), else the table.
+    struct Seen {
+      const char* p = nullptr;
+      std::size_t n = 0;
+      std::uint32_t env = 0, name = 0;
+    } seen[4];
+    unsigned next_seen = 0;
     for (std::uint32_t i = 0; i != n; ++i) {
-      const TaskPersonality& p = *batch[i]->personality;
-      env[i] = LookupEnv(p.compiler_digest);
-      minv[i] = p.min_version;
+      const RequestView& r = batch[i];
+      const char* dp = r.compiler_digest.data();
+      const std::size_t dn = r.compiler_digest.size();
+      if (!(have_digest && dp == last_digest.data() && dn == last_digest.size())) {
+        const Seen* hit = nullptr;
+        for (const Seen& s : seen)
+          if (s.p == dp && s.n == dn) hit = &s;
+        if (hit) {
+          last_env = hit->env;
+          last_name = hit->name;
+        } else {
+          const EnvEntry* e = LookupEnv(r.compiler_digest);
+          last_env = e ? e->bit : 0xFFFFFFFFu;  // unknown: nobody has it
+          last_name = e ? e->name : 0;
+          seen[next_seen++ & 3] = Seen{dp, dn, last_env, last_name};
+        }
+        last_digest = r.compiler_digest;
+        have_digest = true;
+      }
+      env[i] = last_env;
+      col_digest_name_[i] = last_name;
+      minv[i] = r.min_version;
     }
     ydc_task_soa soa{env, minv, rip};
+    const std::uint64_t t1 = NowNs();
     rc = ydc_dispatch(ctx_, &soa, n, YDC_DISPATCH_COMMIT, out, nullptr, nullptr);
+    device_ns += NowNs() - t1;
   }
+  host_stats_.device_ns += device_ns;
+  host_stats_.requests += n;
+  ++host_stats_.batches;
+  if (rc != YDC_OK) need_full_upload_ = true;  // the resident running_tasks may be stale now
+  return rc;
+}
+
+std::uint64_t GpuTaskDispatcher::UnsafeGrant(const RequestView& r, std::uint32_t digest_name,
+                                             std::uint32_t servant_index,
+                                             std::chrono::nanoseconds expires_in, Clock::time_point now) {
+  Servant* pick = servants_[servant_index].get();
+  ++pick->running_tasks;  // :123-124 (the device did the same on its column: COMMIT)
+  ++pick->ever_assigned_tasks;
+  const std::uint64_t task_id = next_task_id_++;  // :127
+  Task* t = tasks_.create(task_id);
+  t->servant = pick;
+  t->started_at = now;
+  t->expires_at = now + expires_in;
+  t->is_prefetch = r.prefetching;
+  t->digest_name = digest_name;  // (granted: some servant advertises the digest, so it has a name)
+  const std::size_t ip_len = r.requestor_ip.size();
+  const char* ip = r.requestor_ip.data();
+  t->ip_len = (std::uint8_t)ip_len;
+  if (ip_len >= 8 && ip_len <= 16) {  // (fixed-size overlapping copies: no call into memcpy)
+    std::memcpy(t->ip_inline, ip, 8);
+    std::memcpy(t->ip_inline + ip_len - 8, ip + ip_len - 8, 8);
+  } else if (ip_len < 8) {
+    for (std::size_t k = 0; k != ip_len; ++k) t->ip_inline[k] = ip[k];
+  } else {
+    t->ip_len = 0xFF;
+    const std::uint32_t name = names_.intern(r.requestor_ip);
+    std::memcpy(t->ip_inline, &name, 4);
+  }
+  t->next = pick->grants_head;
+  if (pick->grants_head != kNoTask) tasks_.slot(pick->grants_head)->prev = task_id;
+  pick->grants_head = task_id;
+  ++pick->n_grants;
+  return task_id;
+}
+
+std::string GpuTaskDispatcher::TaskRequestorIp(const Task& t) const {
+  if (t.ip_len != 0xFF) return std::string(t.ip_inline, t.ip_len);
+  std::uint32_t name;
+  std::memcpy(&name, t.ip_inline, 4);
+  return names_.name(name);
+}
+
+void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
+  if (batch.empty()) return;
+  const std::uint64_t t0 = NowNs(), dev0 = host_stats_.device_ns;
+  RequestSpan span;
+  span.pending = batch.data();
+  span.n = batch.size();
+  const int rc = UnsafePlace(span);
   if (rc != YDC_OK) {
-    // Fail loudly: every request of the batch gets the device error. The
-    // resident running_tasks may be stale now; rebuild it from the host's.
-    need_full_upload_ = true;
+    // Fail loudly: every request of the batch gets the device error.
     for (auto* r : batch) {
       r->done = true;
       r->result = WaitResult{};
@@ -592,8 +899,9 @@ void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
     }
     return;
   }
+  const std::uint32_t* out = col_out_.p;
   auto now = Now();
-  for (std::uint32_t i = 0; i != n; ++i) {
+  for (std::size_t i = 0; i != batch.size(); ++i) {
     Pending* r = batch[i];
     if (out[i] == YDC_IDX_ENV_NOT_FOUND) {
       r->done = true;  // :105-108
@@ -602,24 +910,13 @@ void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
     } else if (out[i] == YDC_IDX_TIMEOUT) {
       r->tried_epoch = wake_epoch_;  // stays pending until its deadline (:116-118)
     } else {
-      Servant* pick = servants_[out[i]].get();
-      ++pick->running_tasks;  // :123-124 (the device did the same on its column: COMMIT)
-      ++pick->ever_assigned_tasks;
-      const std::uint64_t task_id = next_task_id_++;  // :127
-      Task& t = tasks_[task_id];
-      t.task_id = task_id;
-      t.personality = *r->personality;
-      t.servant_uid = pick->uid;
-      t.started_at = now;
-      t.expires_at = now + r->expires_in;
-      t.is_prefetch = r->prefetching;
-      pick->grants.insert(task_id);
       r->done = true;
       r->result.ok = true;
-      r->result.allocation.task_id = task_id;
-      r->result.allocation.servant_location = pick->personality.observed_location;
+      r->result.allocation.task_id = UnsafeGrant(r->request, col_digest_name_[i], out[i], r->expires_in, now);
+      r->result.allocation.servant_location = servants_[out[i]]->personality.observed_location;
     }
   }
+  host_stats_.host_ns += (NowNs() - t0) - (host_stats_.device_ns - dev0);
 }
 
 void GpuTaskDispatcher::UnsafeDrainQueue() {
@@ -647,10 +944,9 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
                                                      std::chrono::nanoseconds expires_in,
                                                      Clock::time_point timeout, bool prefetching) {
   Pending req;
-  req.personality = &personality;
+  req.request = {personality.requestor_ip, personality.compiler_digest, personality.min_version, prefetching};
   req.expires_in = expires_in;
   req.deadline = timeout;
-  req.prefetching = prefetching;
   {
     // Concurrent callers queue up here; whoever holds allocation_lock_ next
     // places all of them as one batch.
@@ -691,31 +987,101 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
   }
 }
 
+// Places requests[0..n) as one device batch and registers the grants; sink(i, status, task id,
+// the granted servant or null) sees every request in order, under the lock. status:
+// 0 granted / 1 EnvironmentNotFound / 2 Timeout (timeout == now), or the negative YDC_ERR_* of a
+// failed device batch. A sink that returns false gives the grant back at once.
+template <class Sink>
+int GpuTaskDispatcher::UnsafePlaceAndGrant(std::size_t n, const RequestView* requests,
+                                           std::chrono::nanoseconds expires_in, Sink&& sink) {
+  UnsafeDrainQueue();  // earlier arrivals first
+  if (n == 0) return YDC_OK;
+  const std::uint64_t t0 = NowNs(), dev0 = host_stats_.device_ns;
+  RequestSpan span;
+  span.views = requests;
+  span.n = n;
+  const int rc = UnsafePlace(span);
+  if (rc != YDC_OK) {
+    for (std::size_t i = 0; i != n; ++i) sink(i, rc, ~0ull, nullptr);
+    return rc;
+  }
+  const std::uint32_t* out = col_out_.p;
+  auto now = Now();
+  int worst = YDC_OK;
+  for (std::size_t i = 0; i != n; ++i) {
+    if (out[i] >= YDC_IDX_ENV_NOT_FOUND) {
+      // EnvironmentNotFound (:105-108) / Timeout — timeout == now (:116-118)
+      sink(i, out[i] == YDC_IDX_ENV_NOT_FOUND ? 1 : 2, ~0ull, nullptr);
+      continue;
+    }
+    const std::uint64_t id = UnsafeGrant(requests[i], col_digest_name_[i], out[i], expires_in, now);
+    if (!sink(i, 0, id, servants_[out[i]].get())) {
+      UnsafeFreeTasks(&id, 1);
+      worst = YDC_ERR_CAPACITY;
+    }
+  }
+  host_stats_.host_ns += (NowNs() - t0) - (host_stats_.device_ns - dev0);
+  return worst;
+}
+
+int GpuTaskDispatcher::WaitForStartingNewTasksInto(std::size_t n, const RequestView* requests,
+                                                   std::chrono::nanoseconds expires_in,
+                                                   std::int32_t* out_status, std::uint64_t* out_task_ids,
+                                                   char* out_locations, std::size_t location_stride) {
+  std::unique_lock lk(allocation_lock_);
+  return UnsafePlaceAndGrant(n, requests, expires_in,
+                             [&](std::size_t i, int status, std::uint64_t id, const Servant* pick) {
+    char* loc = out_locations && location_stride ? out_locations + i * location_stride : nullptr;
+    out_status[i] = status;
+    if (out_task_ids) out_task_ids[i] = id;
+    if (!loc) return true;
+    if (!pick) {
+      loc[0] = 0;
+      return true;
+    }
+    if (pick->location_len != 0xFF && location_stride >= sizeof(pick->location_short)) {
+      std::memcpy(loc, pick->location_short, sizeof(pick->location_short));  // (fixed size, NUL inside)
+      return true;
+    }
+    const std::string* where = &pick->personality.observed_location;
+    if (where->size() < location_stride) {
+      std::memcpy(loc, where->c_str(), where->size() + 1);
+      return true;
+    }
+    // A grant whose servant the caller cannot name is useless: it is given back at once
+    // instead of leaking the slot until the lease runs out.
+    std::memcpy(loc, where->data(), location_stride - 1);
+    loc[location_stride - 1] = 0;
+    if (out_task_ids) out_task_ids[i] = ~0ull;
+    out_status[i] = YDC_ERR_CAPACITY;
+    return false;
+  });
+}
+
 std::vector<WaitResult> GpuTaskDispatcher::WaitForStartingNewTasks(
     const std::vector<TaskPersonality>& personalities, std::chrono::nanoseconds expires_in,
     const std::vector<bool>& prefetching) {
-  std::vector<Pending> reqs(personalities.size());
+  const std::size_t n = personalities.size();
+  std::vector<RequestView> views(n);
+  for (std::size_t i = 0; i != n; ++i)
+    views[i] = {personalities[i].requestor_ip, personalities[i].compiler_digest,
+                personalities[i].min_version, i < prefetching.size() && prefetching[i]};
+  std::vector<WaitResult> out(n);
   std::unique_lock lk(allocation_lock_);
-  auto now = Now();
-  std::vector<Pending*> batch;
-  batch.reserve(reqs.size());
-  for (std::size_t i = 0; i != reqs.size(); ++i) {
-    reqs[i].personality = &personalities[i];
-    reqs[i].expires_in = expires_in;
-    reqs[i].deadline = now;
-    reqs[i].prefetching = i < prefetching.size() && prefetching[i];
-    batch.push_back(&reqs[i]);
-  }
-  UnsafeDrainQueue();  // earlier arrivals first
-  UnsafeDispatch(batch);
-  std::vector<WaitResult> out(reqs.size());
-  for (std::size_t i = 0; i != reqs.size(); ++i) {
-    if (reqs[i].done) {
-      out[i] = reqs[i].result;
+  UnsafePlaceAndGrant(n, views.data(), expires_in,
+                      [&](std::size_t i, int status, std::uint64_t id, const Servant* pick) {
+    if (status == 0) {
+      out[i].ok = true;
+      out[i].allocation.task_id = id;
+      out[i].allocation.servant_location = pick->personality.observed_location;
+    } else if (status < 0) {
+      out[i].device_error = status;
+      out[i].status = WaitStatus::Timeout;
     } else {
-      out[i].status = WaitStatus::Timeout;  // timeout == now
+      out[i].status = status == 1 ? WaitStatus::EnvironmentNotFound : WaitStatus::Timeout;
     }
-  }
+    return true;
+  });
   return out;
 }
 
@@ -782,24 +1148,23 @@ std::string GpuTaskDispatcher::DumpInternals() {
   }
   j += "],\"tasks\":{";
   bool first = true;
-  for (auto&& [k, v] : tasks_) {
+  tasks_.for_each([&](std::uint64_t k, Task& v) {
     if (!first) j += ",";
     first = false;
-    j += "\"" + std::to_string(k) + "\":{\"task_id\":" + std::to_string(v.task_id);
+    j += "\"" + std::to_string(k) + "\":{\"task_id\":" + std::to_string(k);
     j += ",\"requestor_ip\":";
-    JsonEscape(v.personality.requestor_ip, &j);
+    JsonEscape(TaskRequestorIp(v), &j);
     j += ",\"compiler_digest\":";
-    JsonEscape(v.personality.compiler_digest, &j);
+    JsonEscape(names_.name(v.digest_name), &j);
     j += ",\"started_at\":";
     JsonEscape(format_time(v.started_at), &j);
     j += ",\"expires_at\":";
     JsonEscape(format_time(v.expires_at), &j);
     j += std::string(",\"prefetched_task\":") + (v.is_prefetch ? "true" : "false");
-    auto si = index_of_uid_.find(v.servant_uid);
     j += ",\"servant_location\":";
-    JsonEscape(si == index_of_uid_.end() ? std::string() : servants_[si->second]->personality.observed_location, &j);
+    JsonEscape(v.servant->personality.observed_location, &j);
     j += std::string(",\"zombie\":") + (v.zombie ? "true" : "false") + "}";
-  }
+  });
   j += "}";
   j += ",\"servants_up\":" + std::to_string(servants_.size());
   j += ",\"running_tasks\":" + std::to_string(total_running);

@@ -24,10 +24,13 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+
+#include "flat_string_map.h"
 
 struct ydc_context;
 
@@ -87,21 +90,58 @@ struct WaitResult {
   WaitStatus error() const { return status; }
 };
 
+// ---- string-view forms of the inputs ----
+// What the RPC layer holds are bytes on the wire; building std::strings out of them only to
+// look them up costs more than the lookups. The C-ABI wrappers (td_api.cc) and the batch entry
+// points below pass views; the std::string methods above them are the reference's signatures.
+struct RequestView {
+  std::string_view requestor_ip;
+  std::string_view compiler_digest;
+  std::uint32_t min_version = 0;
+  bool prefetching = false;
+};
+
+struct ServantView {
+  int version = 0;
+  std::string_view observed_location, reported_location;
+  const std::string_view* environments = nullptr;
+  std::size_t n_environments = 0;
+  std::size_t num_processors = 0, current_load = 0, total_memory_in_bytes = 0,
+              memory_available_in_bytes = 0, max_tasks = 0;
+  int priority = kServantPriorityUnknown;
+  int not_accepting_task_reason = 0;
+};
+
+struct RunningTaskView {
+  std::uint64_t servant_task_id = 0;
+  std::uint64_t task_grant_id = 0;
+  std::string_view servant_location, task_digest;
+};
+
 // running_task_bookkeeper.h:28-43. The flattened list is cached between
 // changes: every daemon polls GetRunningTasks once a second
 // (daemon/local/running_task_keeper.cc:31-33) while a servant's entry changes
-// only with its own heartbeat.
+// only with its own heartbeat — and most heartbeats report the list they
+// reported a second ago, so a report is compared with what is stored before
+// anything is replaced or invalidated.
 class RunningTaskBookkeeper {
  public:
+  using Snapshot = std::shared_ptr<const std::vector<RunningTask>>;
   void SetServantRunningTasks(const std::string& servant_location, std::vector<RunningTask> tasks);
-  void DropServant(const std::string& servant_location);
+  // The entries `keep[0..n_keep)` of `tasks` (report order).
+  void SetServantRunningTasks(std::string_view servant_location, const RunningTaskView* tasks,
+                              const std::uint32_t* keep, std::size_t n_keep);
+  void DropServant(std::string_view servant_location);
   std::vector<RunningTask> GetRunningTasks() const;
+  // The flattened list without the copy: shared with later callers until a report changes it.
+  Snapshot GetRunningTasksShared() const;
+  std::uint64_t rebuilds() const { return rebuilds_; }
 
  private:
   mutable std::mutex lock_;
-  std::unordered_map<std::string, std::vector<RunningTask>> running_tasks_;
-  mutable std::vector<RunningTask> flattened_;
-  mutable bool flattened_valid_ = false;
+  FlatStringMap<std::vector<RunningTask>> running_tasks_;
+  mutable Snapshot flattened_;
+  mutable std::uint64_t rebuilds_ = 0;
 };
 
 class GpuTaskDispatcher {
@@ -152,6 +192,33 @@ class GpuTaskDispatcher {
   std::vector<WaitResult> WaitForStartingNewTasks(const std::vector<TaskPersonality>& personalities,
                                                   std::chrono::nanoseconds expires_in,
                                                   const std::vector<bool>& prefetching);
+  // The same on views, results into the caller's arrays (no std::string per request on either
+  // side): out_status[i] = 0 granted / 1 EnvironmentNotFound / 2 Timeout, or the negative
+  // YDC_ERR_* of a failed device batch; out_task_ids[i] = the grant id or ~0; the location of
+  // the granted servant NUL-terminated at out_locations + i * location_stride (nullable). A
+  // location that does not fit its stride gives the grant back at once and reports
+  // YDC_ERR_CAPACITY for that request. Returns 0, or the last negative status.
+  int WaitForStartingNewTasksInto(std::size_t n, const RequestView* requests,
+                                  std::chrono::nanoseconds expires_in, std::int32_t* out_status,
+                                  std::uint64_t* out_task_ids, char* out_locations,
+                                  std::size_t location_stride);
+
+  // ---- view forms of the registry methods (same behaviour as the std::string ones) ----
+  void KeepServantAlive(const ServantView& servant, std::chrono::nanoseconds expires_in);
+  std::vector<std::uint64_t> NotifyServantRunningTasks(std::string_view servant_location,
+                                                       const RunningTaskView* tasks, std::size_t n);
+  RunningTaskBookkeeper::Snapshot GetRunningTasksShared() const {
+    return running_task_bookkeeper_.GetRunningTasksShared();
+  }
+  void FreeTasks(const std::uint64_t* task_ids, std::size_t n);  // n FreeTask calls, one lock
+
+  // Where the host class spends its time (cumulative): inside the device API (registry
+  // deltas + ydc_dispatch, the GPU's share) and in the class itself.
+  struct HostStats {
+    std::uint64_t requests = 0, batches = 0, device_ns = 0, host_ns = 0;
+    std::uint64_t heartbeats = 0, heartbeats_unchanged = 0, bookkeeper_rebuilds = 0;
+  };
+  HostStats host_stats() const;
 
   // task_dispatcher.cc:498-536. Public so that a host without the timer thread
   // (tests, a fiber runtime's own timer) can drive it.
@@ -160,54 +227,131 @@ class GpuTaskDispatcher {
   std::string DumpInternals();
 
  private:
+  static constexpr std::uint64_t kNoTask = ~0ull;
   struct Servant {
     std::uint64_t uid;  // stable identity (the reference's ServantDesc pointer)
+    std::uint32_t index = 0;  // current registry position
+    bool removed = false;     // expired: out of the registry, alive until its orphans are freed
     ServantPersonality personality;
     Clock::time_point discovered_at, expires_at;
     std::size_t running_tasks = 0;
     std::size_t ever_assigned_tasks = 0;
     std::vector<std::uint32_t> env_bits;  // interned digests (bit numbers), listing order
+    // observed_location again, NUL-terminated, when it fits: what a grant copies out.
+    char location_short[24] = {0};
+    std::uint8_t location_len = 0xFF;  // 0xFF: longer than that, read personality.observed_location
     std::uint32_t ip_id = 0;     // interned longest requestor address the location answers to
     // The shorter ones (location prefixes ending before an earlier ':'; none for "a.b.c.d:port").
     std::vector<std::string> shorter_prefixes;
-    std::unordered_set<std::uint64_t> grants;  // live task ids (incl. zombies) on this servant
+    // Live task ids (incl. zombies) on this servant: a doubly linked list threaded through the
+    // task records (Task::prev / next), newest first. What the reference rebuilds with a scan
+    // over every task per heartbeat (task_dispatcher.cc:257-262,453-476).
+    std::uint64_t grants_head = kNoTask;
+    std::size_t n_grants = 0, n_zombies = 0;
   };
-  struct Task {
-    std::uint64_t task_id;
-    TaskPersonality personality;
-    std::uint64_t servant_uid;
+  // One lease. The reference keeps TaskDesc{TaskPersonality (two strings), RefPtr<ServantDesc>, …}
+  // in an unordered_map node per grant (task_dispatcher.h:199-216); here a fixed-size record in
+  // a table indexed by the task id itself (ids are handed out in sequence, task_dispatcher.cc:127),
+  // strings as pool ids (digest) or in place (requestor addresses of up to 15 characters).
+  struct alignas(64) Task {  // one cache line
+    Servant* servant = nullptr;  // outlives the task: orphans are freed by the sweep that removes it
     Clock::time_point started_at, expires_at;
-    bool is_prefetch = false;
-    bool zombie = false;
+    std::uint64_t prev = kNoTask, next = kNoTask;  // neighbours in servant's grant list
+    std::uint32_t digest_name = 0;                 // NamePool id of the compiler digest
+    char ip_inline[16];       // the requestor address; or, pooled, its NamePool id in the first 4 bytes
+    std::uint8_t ip_len = 0;  // 0xFF: pooled
+    bool live = false, is_prefetch = false, zombie = false;
+  };
+  static_assert(sizeof(Task) == 64, "a lease is one cache line");
+  // Task records by id: pages of 4096 consecutive ids, a page is freed when its last task is.
+  class TaskTable {
+   public:
+    static constexpr unsigned kPageBits = 12;
+    Task* find(std::uint64_t id);
+    // The record of a task that is known to be live, by address arithmetic alone: a neighbour
+    // in a grant list is only ever WRITTEN through this (no load from its cold cache line).
+    Task* slot(std::uint64_t id) {
+      return &pages_[(id >> kPageBits) - first_page_]->tasks[id & ((1u << kPageBits) - 1)];
+    }
+    Task* create(std::uint64_t id);  // id = the next one in sequence
+    void erase(std::uint64_t id);
+    std::size_t size() const { return live_; }
+    template <class F>
+    void for_each(F&& f) {
+      for (std::size_t p = 0; p != pages_.size(); ++p) {
+        if (!pages_[p]) continue;
+        for (std::size_t k = 0; k != (1u << kPageBits); ++k)
+          if (pages_[p]->tasks[k].live) f(((first_page_ + p) << kPageBits) + k, pages_[p]->tasks[k]);
+      }
+    }
+
+   private:
+    struct Page {
+      Task tasks[1u << kPageBits];
+      std::uint32_t live = 0;
+    };
+    std::deque<std::unique_ptr<Page>> pages_;
+    std::vector<std::unique_ptr<Page>> spare_;  // emptied pages, reused before the allocator is asked
+    std::uint64_t first_page_ = 0;
+    std::size_t live_ = 0;
+  };
+  // Strings that task records refer to by number (permanent: bounded by the distinct digests
+  // servants ever advertised and the distinct long requestor addresses that were granted).
+  class NamePool {
+   public:
+    std::uint32_t intern(std::string_view s);
+    const std::string& name(std::uint32_t id) const { return names_[id]; }
+
+   private:
+    FlatStringMap<std::uint32_t> ids_;
+    std::deque<std::string> names_;
+  };
+  struct EnvEntry {
+    std::uint32_t bit = 0, refs = 0, name = 0;  // mask bit, servants' references, NamePool id
   };
   struct Pending {
-    const TaskPersonality* personality;
+    RequestView request;
     std::chrono::nanoseconds expires_in;
     Clock::time_point deadline;
-    bool prefetching;
     bool done = false;
     std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     WaitResult result;
   };
 
   std::size_t CapacityAvailable(const Servant& s) const;  // task_dispatcher.cc:283-313
-  std::uint32_t InternIp(const std::string& ip, bool create);
+  std::uint32_t InternIp(std::string_view ip, bool create);
   // Host id of a requestor address (0: no servant answers to it).
-  std::uint32_t RequestorId(const std::string& ip);
-  std::uint32_t LookupEnv(const std::string& digest) const;
-  std::vector<std::uint32_t> AcquireEnvBits(const std::vector<std::string>& digests);
+  std::uint32_t RequestorId(std::string_view ip);
+  const EnvEntry* LookupEnv(std::string_view digest) const;
+  template <class Strings>
+  std::vector<std::uint32_t> AcquireEnvBits(const Strings& digests, std::size_t n);
   void ReleaseEnvBits(const std::vector<std::string>& digests);
   // 64-bit words an environment mask needs for every bit number handed out so far.
   std::uint32_t EnvWords() const { return next_env_bit_ ? (next_env_bit_ + 63) / 64 : 1; }
-  void UnsafeFreeTasks(const std::vector<std::uint64_t>& task_ids);  // :167-188
-  void UnsafeSweepZombiesOf(Servant* servant, const std::unordered_set<std::uint64_t>& running);
-  void UnsafeSweepOrphans();
+  void UnsafeFreeTasks(const std::uint64_t* task_ids, std::size_t n);  // :167-188
+  void UnsafeSweepZombiesOf(Servant* servant, const RunningTaskView* reported, std::size_t n);
   int UnsafeSyncDevice();
   int UnsafeSyncAliases();
-  // Places `batch` (arrival order) as one device batch and registers the grants.
+  // A batch in arrival order: contiguous views, or the requests of parked / queued callers.
+  struct RequestSpan {
+    const RequestView* views = nullptr;
+    Pending* const* pending = nullptr;
+    std::size_t n = 0;
+    const RequestView& operator[](std::size_t i) const { return views ? views[i] : pending[i]->request; }
+  };
+  // Places the span as one device batch (COMMIT); the answers (registry index or YDC_IDX_*) are
+  // in col_out_. Returns YDC_OK or the device error.
+  int UnsafePlace(const RequestSpan& batch);
+  // Registers the grant of `r` on servants_[servant_index]; returns the task id.
+  std::uint64_t UnsafeGrant(const RequestView& r, std::uint32_t digest_name, std::uint32_t servant_index,
+                            std::chrono::nanoseconds expires_in, Clock::time_point now);
+  template <class Sink>
+  int UnsafePlaceAndGrant(std::size_t n, const RequestView* requests, std::chrono::nanoseconds expires_in,
+                          Sink&& sink);
   void UnsafeDispatch(const std::vector<Pending*>& batch);
   void UnsafeDrainQueue();
   void TimerLoop();
+  std::string TaskRequestorIp(const Task& t) const;
 
   Options options_;
   ydc_context* ctx_ = nullptr;
@@ -218,23 +362,23 @@ class GpuTaskDispatcher {
   mutable std::mutex allocation_lock_;           // task_dispatcher.h:289
   std::condition_variable allocation_cv_;        // task_dispatcher.h:290
   std::vector<std::unique_ptr<Servant>> servants_;  // registration order == tie-break order
-  std::unordered_map<std::string, std::uint32_t> index_of_location_;
-  std::unordered_map<std::uint64_t, std::uint32_t> index_of_uid_;
+  FlatStringMap<std::uint32_t> index_of_location_;
   std::uint64_t next_servant_uid_ = 1;
-  std::unordered_map<std::uint64_t, Task> tasks_;
+  TaskTable tasks_;
+  NamePool names_;
   std::uint64_t next_task_id_ = 0;  // task_dispatcher.h:218
   std::uint64_t wake_epoch_ = 0;  // bumped where the reference notifies its waiters (:187)
 
   // interning
-  std::unordered_map<std::string, std::uint32_t> ip_ids_;
+  FlatStringMap<std::uint32_t> ip_ids_;
   // A location with several ':' answers to several requestor addresses (IsNetworkAddressEqual,
   // task_dispatcher.cc:66-69: every prefix that ends right before a ':'). The servant's ip_id is
   // the longest of them; the shorter ones are counted here and become table aliases
   // (ydc_set_host_aliases) the first time a requestor actually presents one.
-  std::unordered_map<std::string, std::uint32_t> shorter_prefix_refs_;  // prefix -> servants having it
-  std::unordered_map<std::string, std::uint32_t> alias_ids_;            // presented ones -> host id
+  FlatStringMap<std::uint32_t> shorter_prefix_refs_;  // prefix -> servants having it
+  FlatStringMap<std::uint32_t> alias_ids_;            // presented ones -> host id
   bool aliases_dirty_ = false;
-  std::unordered_map<std::string, std::pair<std::uint32_t, std::uint32_t>> env_ids_;  // digest -> (bit, refs)
+  FlatStringMap<EnvEntry> env_ids_;  // digest -> (bit, refs, name)
   std::vector<std::uint32_t> free_env_bits_;
   std::uint32_t next_env_bit_ = 0;  // bit numbers handed out so far (freed ones are reused)
 
@@ -255,6 +399,7 @@ class GpuTaskDispatcher {
     ~HostColumn();
   };
   HostColumn col_env_, col_minv_, col_rip_, col_out_;
+  std::vector<std::uint32_t> col_digest_name_;  // NamePool id of every request's digest (known ones)
 
   // request combining
   std::mutex queue_lock_;
@@ -262,6 +407,7 @@ class GpuTaskDispatcher {
   std::vector<Pending*> waiting_;  // found no free servant; arrival order
 
   RunningTaskBookkeeper running_task_bookkeeper_;
+  HostStats host_stats_;  // guarded by allocation_lock_
 
   std::thread timer_;
   std::mutex timer_lock_;

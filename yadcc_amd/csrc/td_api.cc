@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "../../include/yadcc_dispatch.h"
@@ -23,7 +24,9 @@ namespace {
 // false: `s` does not fit (the buffer gets the truncated text; the caller reports it).
 bool CopyString(const std::string& s, char* out, size_t cap) {
   if (!out || !cap) return true;
-  std::snprintf(out, cap, "%s", s.c_str());
+  const size_t n = s.size() < cap ? s.size() : cap - 1;
+  std::memcpy(out, s.data(), n);
+  out[n] = 0;
   return s.size() < cap;
 }
 
@@ -71,12 +74,16 @@ int ydc_td_set_clock_ns(ydc_td* td, int64_t now_ns) {
 }
 
 int ydc_td_keep_servant_alive(ydc_td* td, const ydc_td_servant* s, int64_t expires_in_ns) {
-  if (!td || !s || !s->observed_location) return YDC_ERR_INVALID_ARGUMENT;
-  ydc::ServantPersonality p;
+  if (!td || !s || !s->observed_location || (s->n_envs && !s->env_digests)) return YDC_ERR_INVALID_ARGUMENT;
+  static thread_local std::vector<std::string_view> envs;
+  envs.clear();
+  for (size_t i = 0; i != s->n_envs; ++i) envs.emplace_back(s->env_digests[i]);
+  ydc::ServantView p;
   p.version = s->version;
   p.observed_location = s->observed_location;
   p.reported_location = s->reported_location ? s->reported_location : s->observed_location;
-  for (size_t i = 0; i != s->n_envs; ++i) p.environments.emplace_back(s->env_digests[i]);
+  p.environments = envs.data();
+  p.n_environments = envs.size();
   p.num_processors = s->num_processors;
   p.current_load = s->current_load;
   p.total_memory_in_bytes = s->total_memory_in_bytes;
@@ -121,29 +128,42 @@ int ydc_td_wait_for_starting_new_tasks(ydc_td* td, size_t n, const char* const* 
                                        size_t location_stride) {
   if (!td || (n && (!requestor_ips || !min_versions || !compiler_digests || !out_status)))
     return YDC_ERR_INVALID_ARGUMENT;
-  std::vector<ydc::TaskPersonality> ps(n);
-  std::vector<bool> pf(n, false);
+  // Views of the caller's strings: nothing is copied on the way in, and the results go
+  // straight into the caller's arrays (YDC_TD_* == the class's 0 / 1 / 2).
+  static thread_local std::vector<ydc::RequestView> views;
+  views.resize(n);
+  // (one RPC's requests usually share the two strings, and a batch names a handful of digests:
+  // the length of a string object seen a moment ago is not measured again)
+  const char* last_ip = nullptr;
+  size_t last_ip_len = 0;
+  struct {
+    const char* p = nullptr;
+    size_t n = 0;
+  } digests[4];
+  unsigned next_digest = 0, cur = 0;
   for (size_t i = 0; i != n; ++i) {
-    ps[i].requestor_ip = requestor_ips[i];
-    ps[i].min_version = min_versions[i];
-    ps[i].compiler_digest = compiler_digests[i];
-    if (prefetching) pf[i] = prefetching[i] != 0;
-  }
-  auto rs = td->impl->WaitForStartingNewTasks(ps, std::chrono::nanoseconds(expires_in_ns), pf);
-  int worst = YDC_OK;
-  for (size_t i = 0; i != n; ++i) {
-    out_status[i] = StatusOf(rs[i]);
-    if (out_status[i] < 0) worst = out_status[i];
-    if (out_task_ids) out_task_ids[i] = rs[i].ok ? rs[i].allocation.task_id : ~0ull;
-    if (out_locations && location_stride &&
-        !CopyString(rs[i].ok ? rs[i].allocation.servant_location : std::string(),
-                    out_locations + i * location_stride, location_stride)) {
-      td->impl->FreeTask(rs[i].allocation.task_id);  // (see the single-request wrapper)
-      if (out_task_ids) out_task_ids[i] = ~0ull;
-      out_status[i] = worst = YDC_ERR_CAPACITY;
+    if (requestor_ips[i] != last_ip) {
+      last_ip = requestor_ips[i];
+      last_ip_len = std::strlen(last_ip);
     }
+    const char* d = compiler_digests[i];
+    if (digests[cur].p != d) {
+      unsigned k = 0;
+      while (k != 4 && digests[k].p != d) ++k;
+      if (k == 4) {
+        k = next_digest++ & 3;
+        digests[k].p = d;
+        digests[k].n = std::strlen(d);
+      }
+      cur = k;
+    }
+    views[i].requestor_ip = std::string_view(last_ip, last_ip_len);
+    views[i].compiler_digest = std::string_view(d, digests[cur].n);
+    views[i].min_version = min_versions[i];
+    views[i].prefetching = prefetching && prefetching[i] != 0;
   }
-  return worst;
+  return td->impl->WaitForStartingNewTasksInto(n, views.data(), std::chrono::nanoseconds(expires_in_ns),
+                                               out_status, out_task_ids, out_locations, location_stride);
 }
 
 int ydc_td_keep_task_alive(ydc_td* td, uint64_t task_id, int64_t new_expires_in_ns) {
@@ -157,18 +177,28 @@ int ydc_td_free_task(ydc_td* td, uint64_t task_id) {
   return YDC_OK;
 }
 
+int ydc_td_free_tasks(ydc_td* td, const uint64_t* task_ids, size_t n) {
+  if (!td || (n && !task_ids)) return YDC_ERR_INVALID_ARGUMENT;
+  td->impl->FreeTasks(task_ids, n);
+  return YDC_OK;
+}
+
 int64_t ydc_td_notify_servant_running_tasks(ydc_td* td, const char* servant_location,
                                             const ydc_td_running_task* tasks, size_t n,
                                             uint64_t* out_unknown, size_t unknown_cap) {
   if (!td || !servant_location || (n && !tasks)) return YDC_ERR_INVALID_ARGUMENT;
-  std::vector<ydc::RunningTask> v(n);
+  static thread_local std::vector<ydc::RunningTaskView> v;
+  v.resize(n);
+  const std::string_view where(servant_location);
   for (size_t i = 0; i != n; ++i) {
     v[i].servant_task_id = tasks[i].servant_task_id;
     v[i].task_grant_id = tasks[i].task_grant_id;
-    v[i].servant_location = tasks[i].servant_location ? tasks[i].servant_location : servant_location;
-    if (tasks[i].task_digest) v[i].task_digest = tasks[i].task_digest;
+    v[i].servant_location = tasks[i].servant_location && tasks[i].servant_location != servant_location
+                                ? std::string_view(tasks[i].servant_location)
+                                : where;
+    v[i].task_digest = tasks[i].task_digest ? std::string_view(tasks[i].task_digest) : std::string_view();
   }
-  auto unknown = td->impl->NotifyServantRunningTasks(servant_location, std::move(v));
+  auto unknown = td->impl->NotifyServantRunningTasks(where, v.data(), n);
   for (size_t i = 0; i != unknown.size() && i < unknown_cap; ++i) out_unknown[i] = unknown[i];
   return (int64_t)unknown.size();
 }
@@ -178,7 +208,8 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
                                  size_t location_stride, char* out_digests, size_t digest_stride,
                                  size_t cap) {
   if (!td) return YDC_ERR_INVALID_ARGUMENT;
-  auto tasks = td->impl->GetRunningTasks();
+  const auto snapshot = td->impl->GetRunningTasksShared();  // (no copy of the list itself)
+  const auto& tasks = *snapshot;
   for (size_t i = 0; i != tasks.size() && i < cap; ++i) {
     if (out_servant_task_ids) out_servant_task_ids[i] = tasks[i].servant_task_id;
     if (out_grant_ids) out_grant_ids[i] = tasks[i].task_grant_id;
@@ -188,6 +219,19 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
       CopyString(tasks[i].task_digest, out_digests + i * digest_stride, digest_stride);
   }
   return (int64_t)tasks.size();
+}
+
+int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out) {
+  if (!td || !out) return YDC_ERR_INVALID_ARGUMENT;
+  const auto s = td->impl->host_stats();
+  out->requests = s.requests;
+  out->batches = s.batches;
+  out->device_ns = s.device_ns;
+  out->host_ns = s.host_ns;
+  out->heartbeats = s.heartbeats;
+  out->heartbeats_unchanged = s.heartbeats_unchanged;
+  out->bookkeeper_rebuilds = s.bookkeeper_rebuilds;
+  return YDC_OK;
 }
 
 int ydc_td_on_expiration_timer(ydc_td* td) {

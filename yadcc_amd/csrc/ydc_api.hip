@@ -590,7 +590,7 @@ int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
 }
-uint32_t ydc_abi_version(void) { return 3; }
+uint32_t ydc_abi_version(void) { return 4; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
                void* stream, ydc_context** out) {

@@ -18,6 +18,7 @@ TD_SYMBOLS = (
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
+    "ydc_td_free_tasks", "ydc_td_host_stats",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
     "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
 )
@@ -35,6 +36,11 @@ class _Servant(C.Structure):
 class _RunningTask(C.Structure):
     _fields_ = [("servant_task_id", C.c_uint64), ("task_grant_id", C.c_uint64),
                 ("servant_location", C.c_char_p), ("task_digest", C.c_char_p)]
+
+
+class _TdStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("requests", "batches", "device_ns", "host_ns", "heartbeats",
+                                          "heartbeats_unchanged", "bookkeeper_rebuilds")]
 
 
 def type_td_functions(L):
@@ -56,6 +62,8 @@ def type_td_functions(L):
             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.ydc_td_keep_task_alive.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
         L.ydc_td_free_task.argtypes = [C.c_void_p, C.c_uint64]
+        L.ydc_td_free_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ydc_td_host_stats.argtypes = [C.c_void_p, C.POINTER(_TdStats)]
         L.ydc_td_notify_servant_running_tasks.argtypes = [
             C.c_void_p, C.c_char_p, C.POINTER(_RunningTask), C.c_size_t, C.c_void_p, C.c_size_t]
         L.ydc_td_notify_servant_running_tasks.restype = C.c_int64
@@ -170,6 +178,15 @@ class GpuTaskDispatcher:
 
     def free_task(self, task_id):
         self._L.ydc_td_free_task(self._h, task_id)
+
+    def free_tasks(self, task_ids):
+        a = np.ascontiguousarray(task_ids, dtype=np.uint64)
+        assert self._L.ydc_td_free_tasks(self._h, a.ctypes.data, len(a)) == 0
+
+    def host_stats(self):
+        st = _TdStats()
+        assert self._L.ydc_td_host_stats(self._h, C.byref(st)) == 0
+        return {k: int(getattr(st, k)) for k, _ in _TdStats._fields_}
 
     def notify_servant_running_tasks(self, location, grant_ids, servant_task_ids=None,
                                      digests=None):
