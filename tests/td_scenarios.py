@@ -242,6 +242,67 @@ def location_that_does_not_fit_is_an_error(make):
     td.close()
 
 
+def lease_table_churn(make):
+    """Tens of thousands of leases through the table that is indexed by the grant id (pages of
+    4096 ids, freed and reused as their leases go): ids stay sequential (task_dispatcher.cc:127),
+    survivors of freed pages stay renewable, freed ids are forgotten, long addresses and digests
+    come back out of the dump, zombies are swept per servant, expiry frees the orphans."""
+    td = make()
+    digest = "d" * 64
+    long_ip = "2001:0db8:85a3:0000:0000:8a2e:0370:7334"  # does not fit the record: pooled
+    for i in range(3):
+        td.keep_servant_alive("10.0.0.%d:8335" % (i + 1), [digest], 20000, 20000, 0,
+                              memory_available=G50, expires_in_ms=10_000_000)
+    ids = []
+    for b in range(15):  # 15000 grants: pages 0..3
+        st, got, locs = td.wait_for_starting_new_tasks(
+            [long_ip if k == 0 else "172.16.%d.%d" % (b, k % 250) for k in range(1000)], [digest] * 1000,
+            [0] * 1000, expires_in_ms=(50 if b == 3 else 10_000_000))
+        assert (st == D.GRANTED).all()
+        ids.extend(int(x) for x in got)
+    assert ids == list(range(15000))
+    keep = set(ids[::1000]) | set(range(3000, 4000))  # a few per page + the short leases of batch 3
+    td.free_tasks([i for i in ids if i not in keep])
+    dump = td.dump_internals()
+    assert dump["running_tasks"] == len(keep) and len(dump["tasks"]) == len(keep)
+    assert dump["tasks"]["7000"]["requestor_ip"] == long_ip and dump["tasks"]["7000"]["compiler_digest"] == digest
+    assert dump["tasks"]["3001"]["requestor_ip"] == "172.16.3.1"
+    assert all(td.keep_task_alive(i, 10_000_000) for i in ids[::1000])
+    assert not td.keep_task_alive(1, 1000) and not td.keep_task_alive(14999, 1000)
+    assert not td.keep_task_alive(10 ** 9, 1000)  # beyond every page
+    # the short leases expire into zombies: not renewable, swept by their servants' next reports
+    td.clock_advance_ms(1000)
+    td.on_expiration_timer()
+    assert not td.keep_task_alive(3500, 1000)
+    zombies = {str(i): t for i, t in td.dump_internals()["tasks"].items() if t["zombie"]}
+    assert len(zombies) == 999 and "3000" not in zombies  # (3000 was renewed above)
+    by_loc = {}
+    for i, t in zombies.items():
+        by_loc.setdefault(t["servant_location"], []).append(int(i))
+    for loc, mine in by_loc.items():
+        still = mine[:2]  # the servant still lists two of them: those stay
+        unknown = td.notify_servant_running_tasks(loc, still)
+        assert unknown == still  # zombies are not "permitted": reported back (task_dispatcher.cc:256-262)
+    left = td.dump_internals()
+    assert sum(1 for t in left["tasks"].values() if t["zombie"]) == 2 * len(by_loc)
+    # new grants after the churn: ids go on, freed pages are reused
+    st, got, _ = td.wait_for_starting_new_tasks(["172.16.9.9"] * 5000, [digest] * 5000, [0] * 5000,
+                                                expires_in_ms=10_000_000)
+    assert (st == D.GRANTED).all() and [int(x) for x in got] == list(range(15000, 20000))
+    td.free_tasks([int(x) for x in got])
+    td.free_tasks(sorted(int(i) for i in left["tasks"]))
+    assert td.dump_internals()["running_tasks"] == 0 and td.dump_internals()["tasks"] == {}
+    # expiry of a servant frees its orphans
+    st, got, locs = td.wait_for_starting_new_tasks(["172.16.9.9"] * 300, [digest] * 300, [0] * 300,
+                                                   expires_in_ms=10_000_000)
+    assert (st == D.GRANTED).all()
+    td.clock_advance_ms(20_000_000)
+    td.on_expiration_timer()
+    d = td.dump_internals()
+    assert d["servants_up"] == 0 and d["tasks"] == {}
+    td.close()
+
+
 def address_forms(make):
     """IsNetworkAddressEqual (task_dispatcher.cc:66-69): `location` starts with the requestor
     address followed by ':'. A location without ':' matches nobody — not even an empty

@@ -37,6 +37,10 @@ def test_golden_load_balance(td):
     S.golden_load_balance(td)
 
 
+def test_lease_table_churn():
+    S.lease_table_churn(make)
+
+
 def test_blocking_wait_is_woken_by_free_task():
     S.blocking_wait_is_woken_by_free_task(make)
 

@@ -56,6 +56,10 @@ def test_golden_load_balance(td):
     S.golden_load_balance(td)
 
 
+def test_lease_table_churn():
+    S.lease_table_churn(make)
+
+
 def test_blocking_wait_is_woken_by_free_task():
     S.blocking_wait_is_woken_by_free_task(make)
 
@@ -106,3 +110,13 @@ def test_sanitizer_build(san):
                          timeout=600)
     assert out.returncode == 0 and "TD-CONCURRENCY-OK" in out.stdout, (out.stdout[-2000:],
                                                                      out.stderr[-4000:])
+
+
+def test_flat_string_map_against_unordered_map():
+    """The host class's string tables (yadcc_amd/csrc/flat_string_map.h: open addressing, backward
+    shift on erase, miss filter) against std::unordered_map under random inserts / lookups /
+    erases, ASan + UBSan build (tests/native/flat_map_test.cc)."""
+    out = subprocess.run(["make", "-s", "-C", NATIVE, "flatmap"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "FLAT-MAP-OK" in out.stdout, (out.stdout[-2000:],
+                                                                 out.stderr[-4000:])
