@@ -31,6 +31,20 @@ struct HostTables {
   std::vector<uint32_t> ip_sorted;  // ip table, sorted by (ip, servant); >= n entries (aliases)
   std::vector<uint32_t> ip_servant;
   bool any_shared_ip = false;       // some host runs more than one servant
+  // The same table as an open-addressing hash (what the request classification probes: one
+  // 8-byte load answers most lookups, where the binary search took log2(n) dependent ones).
+  // Slot i = {ip_hash[2 i], ip_hash[2 i + 1]} = {host id, value}; value kNone: empty slot;
+  // value < 2^31: the ONE servant on that host; value = 2^31 | k: several, the first of them is
+  // entry k of ip_sorted. Home slot of a host id: (id * 0x9E3779B1) >> ip_hash_shift, linear
+  // probing, at most half full.
+  std::vector<uint32_t> ip_hash;
+  uint32_t ip_hash_shift = 28;
+  // One bit per host id in front of it (eight bits per slot, i.e. >= 16 per host: 32 KB for 16k
+  // hosts — it stays in a CU's L1, where a probe of the table itself costs a cache line from
+  // L2 per LANE): bit (id * 0x85EBCA6B) >> ip_filter_shift. Nine requestors in ten are nobody's
+  // host and never touch the table.
+  std::vector<uint32_t> ip_filter;
+  uint32_t ip_filter_shift = 25;
   // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
   // class versions (and a table of at most 2^20 words): ver_sorted = the distinct class versions ascending,
   // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` (one of
@@ -201,6 +215,25 @@ struct HostTables {
       ip_servant[i] = byip[i].second;
       if (i && byip[i].first == byip[i - 1].first) any_shared_ip = true;
     }
+    uint32_t bits = 4;
+    while ((1u << bits) < 2 * n_ip) ++bits;
+    ip_hash_shift = 32 - bits;
+    ip_hash.assign((size_t)2 << bits, kNone);
+    for (uint32_t i = 0; i < n_ip;) {
+      uint32_t j = i + 1;
+      while (j < n_ip && ip_sorted[j] == ip_sorted[i]) ++j;
+      uint32_t h = (ip_sorted[i] * 0x9E3779B1u) >> ip_hash_shift;
+      while (ip_hash[2 * h + 1] != kNone) h = (h + 1) & ((1u << bits) - 1);
+      ip_hash[2 * h] = ip_sorted[i];
+      ip_hash[2 * h + 1] = j - i == 1 ? ip_servant[i] : (0x80000000u | i);
+      i = j;
+    }
+    ip_filter_shift = 32 - (bits + 3);
+    ip_filter.assign((size_t)1 << (bits + 3 - 5), 0u);
+    for (uint32_t i = 0; i < n_ip; ++i) {
+      const uint32_t f = (ip_sorted[i] * 0x85EBCA6Bu) >> ip_filter_shift;
+      ip_filter[f >> 5] |= 1u << (f & 31);
+    }
   }
 
   uint32_t n_classes() const { return (uint32_t)cls_ver.size(); }
@@ -218,8 +251,12 @@ struct KeyFormat {
 
 // n_comp > 1: the part id (HostTables::cls_comp) rides above the slot key. The fp64 key has no
 // room for it: such registries are treated as one part (*n_comp is set to 1).
+// fuse_cls_bits != 0: the class partition wants to ride on the LAST key pass (kernels.h:
+// k_radix_scatter_classed — one scatter pass fewer), which needs its digit to leave that many
+// bits free: the earlier passes are widened until it does, where the pass count allows
+// (23-bit keys + 5 class bits: 9 + 9 + (5 + 5) instead of 8 + 8 + 7 and a pass of its own).
 inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 11,
-                                   uint32_t* n_comp = nullptr) {
+                                   uint32_t* n_comp = nullptr, uint32_t fuse_cls_bits = 0) {
   KeyFormat f;
   f.exact = cap_bits <= kMaxExactCapBits;
   f.cap_bits = cap_bits;
@@ -236,6 +273,13 @@ inline KeyFormat choose_key_format(uint32_t cap_bits, uint32_t max_radix_bits = 
   }
   f.passes = (f.key_bits + max_radix_bits - 1) / max_radix_bits;
   f.bits_per_pass = (f.key_bits + f.passes - 1) / f.passes;
+  if (fuse_cls_bits && fuse_cls_bits < max_radix_bits && f.passes >= 2) {
+    const uint32_t room = max_radix_bits - fuse_cls_bits;  // key bits the last digit may hold
+    if (f.key_bits - (f.passes - 1) * f.bits_per_pass > room) {
+      const uint32_t bpp = (f.key_bits - room + f.passes - 2) / (f.passes - 1);
+      if (bpp <= max_radix_bits && bpp * (f.passes - 1) < f.key_bits) f.bits_per_pass = bpp;
+    }
+  }
   return f;
 }
 

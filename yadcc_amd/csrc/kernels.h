@@ -34,6 +34,23 @@ constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;  // most; a pass may use fewer (SortIn::items) for more, smaller tiles
 constexpr int kSortWaves = kSortThreads / 64;
 
+// Sort tiles and the 8 XCDs. Workgroups go to the XCDs round-robin and every XCD has an L2 of
+// its own. What tile t writes continues what tile t - 1 wrote: its run of every digit in the
+// scatter's output, its column of the digit-major histogram table — word for word, so the two
+// share 32-byte sectors and 128-byte lines. Handed to different XCDs the halves of a sector
+// leave from two caches as masked writes (WRITE_SIZE 2.2 - 2.4x the bytes written, rounds 1-3);
+// workgroup b therefore takes tile (b mod 8) * ceil(n / 8) + b / 8: every XCD works through a
+// contiguous range of tiles in order, and neighbours in memory meet in one L2.
+constexpr uint32_t kXcds = 8;
+__host__ __device__ __forceinline__ uint32_t xcd_grid(uint32_t n_tiles) {
+  return (n_tiles + kXcds - 1) / kXcds * kXcds;
+}
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t block, uint32_t n_tiles, uint32_t on = 1) {
+  if (!on) return block;
+  return (block % kXcds) * ((n_tiles + kXcds - 1) / kXcds) + block / kXcds;  // >= n_tiles: nothing to do
+}
+
+
 // Device-resident scalars produced and consumed by the kernels.
 struct DeviceParams {
   uint32_t n_slots;       // M: free slots of this batch
@@ -321,6 +338,14 @@ struct ClassifyArgs {
   // every entry written — nothing to reset) and the chunk prefix adds the waves of a chunk up.
   uint32_t by_servant, per_wave;
   uint32_t n_ip;  // entries of the ip table (>= n_servants: a servant may answer to several host ids)
+  // The ip table as a hash (host_tables.h: ip_hash): {host id, value} per slot.
+  const uint2* ip_hash;
+  uint32_t ip_hash_shift;
+  const uint32_t* ip_filter;  // one bit per host id in front of the table (host_tables.h)
+  uint32_t ip_filter_shift;
+  // Requests per thread (1, or 4: task_classify_block_multi — workgroups of 4 x 256 requests).
+  uint32_t per_thread;
+  uint32_t xcd_gen;  // (k_slot_gen's slot tiles in XCD-contiguous order)
   // Nullable (lookup form only): row of the (digest, version threshold) lookup the request
   // falls into (kNone: a digest nobody has) — k_sim_wide's eligible-class lists (host_tables.h).
   uint32_t* row_out;
@@ -330,10 +355,20 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
                                                     DeviceParams* prm) {
   const uint32_t t = block * blockDim.x + threadIdx.x;
   if (t >= a.n_tasks) return;
+  // A wave is as slow as its slowest lane, and what it waits for here are dependent memory
+  // round trips (~1 us each on a busy chip), not bytes: the three columns are fetched at once,
+  // the requestor's host is ONE probe of the hashed ip table for almost every lane (the
+  // binary search over 16k hosts was 14 dependent loads — and nine lanes in ten skipping it
+  // did not help their wave), and that probe and the mask row are in flight together.
+  const uint32_t env = a.tk.env_id[t], minv = a.tk.min_version[t], rip = a.tk.requestor_ip[t];
+  const uint32_t hmask = (1u << (32 - a.ip_hash_shift)) - 1;
+  uint32_t hslot = (rip * 0x9E3779B1u) >> a.ip_hash_shift;
+  const uint32_t fbit = (rip * 0x85EBCA6Bu) >> a.ip_filter_shift;
+  uint2 probe = make_uint2(0u, kNone);
+  if (a.ip_filter[fbit >> 5] >> (fbit & 31) & 1u) probe = a.ip_hash[hslot];
   uint64_t any = 0;
   uint32_t first_cls = 0;  // an eligible class (names the request's part of the registry)
   {
-    const uint32_t env = a.tk.env_id[t], minv = a.tk.min_version[t];
     if (a.env_ver_mask) {
       uint32_t vi = 0;  // class versions below min_version
       for (uint32_t j = 0; j < a.n_versions; ++j) vi += a.ver_sorted[j] < minv;
@@ -363,17 +398,19 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
     }
   }
   uint32_t lo = kNone, hi = kNone;
-  const uint32_t rip = a.tk.requestor_ip[t];
-  const uint32_t i = lower_bound_u32(a.ip_sorted, a.n_ip, rip);
-  if (i < a.n_ip && a.ip_sorted[i] == rip) {
-    if (i + 1 < a.n_ip && a.ip_sorted[i + 1] == rip) {
-      lo = i;  // several servants on the host: `self` is resolved at replay time
+  while (probe.y != kNone && probe.x != rip) {  // (a collision: the next slot)
+    hslot = (hslot + 1) & hmask;
+    probe = a.ip_hash[hslot];
+  }
+  if (probe.y != kNone) {
+    if (probe.y & 0x80000000u) {
+      lo = probe.y & 0x7FFFFFFFu;  // several servants on the host: `self` is resolved at replay time
       hi = kSelfShared;
     } else if (a.by_servant) {
-      lo = a.ip_servant[i];
+      lo = probe.y;
       hi = kSelfServant;
     } else {
-      const uint32_t s = a.ip_servant[i];
+      const uint32_t s = probe.y;
       const uint32_t b = a.slot_base[s], e = a.slot_base[s + 1];
       if (e > b) {
         lo = b;
@@ -416,6 +453,102 @@ __device__ __forceinline__ void task_classify_block(const ClassifyArgs& a, uint3
       if ((threadIdx.x & 63) == leader)
         atomicAdd(&a.chunk_consuming[(size_t)(t / a.chunk_size) * a.n_parts + g], (uint32_t)__popcll(same));
       consuming &= ~same;
+    }
+  }
+}
+
+// The same classification with R requests per thread (thread j of workgroup b: requests
+// b * 256 R + k * 256 + j, k < R — every wave still holds 64 consecutive requests per k), for
+// the large batches of the radix path: the lookup form with one mask word, slot ranges of own
+// servants, counts per chunk. Every step issues its loads for all R requests before anything
+// waits, so a wave has R round trips in flight where the one-request form has one; what the
+// wave count of a 4M-request batch (62.5k waves, 8 rounds of a full chip) made a chain of
+// ~8 us per round becomes two rounds (cfg4: 62 -> see profiles/r04).
+template <int R>
+__device__ __forceinline__ void task_classify_block_multi(const ClassifyArgs& a, uint32_t block,
+                                                          DeviceParams* prm) {
+  const uint32_t t0 = block * (blockDim.x * R) + threadIdx.x;
+  const uint32_t last = a.n_tasks - 1;  // (n_tasks > 0: no workgroup otherwise)
+  uint32_t env[R], minv[R], rip[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t t = min(t0 + k * blockDim.x, last);
+    env[k] = a.tk.env_id[t];
+    minv[k] = a.tk.min_version[t];
+    rip[k] = a.tk.requestor_ip[t];
+  }
+  const uint32_t hmask = (1u << (32 - a.ip_hash_shift)) - 1;
+  const uint32_t n_env = 64 * a.env_words;  // digests >= n_env: nobody has them
+  uint32_t hslot[R], fbit[R], fword[R];
+  uint2 probe[R];
+  uint64_t m[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    hslot[k] = (rip[k] * 0x9E3779B1u) >> a.ip_hash_shift;
+    fbit[k] = (rip[k] * 0x85EBCA6Bu) >> a.ip_filter_shift;
+    fword[k] = a.ip_filter[fbit[k] >> 5];
+    uint32_t vi = 0;  // class versions below min_version
+    for (uint32_t j = 0; j < a.n_versions; ++j) vi += a.ver_sorted[j] < minv[k];
+    m[k] = a.env_ver_mask[(size_t)min(env[k], n_env - 1) * (a.n_versions + 1) + vi];
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    probe[k] = make_uint2(0u, kNone);
+    if (fword[k] >> (fbit[k] & 31) & 1u) probe[k] = a.ip_hash[hslot[k]];
+  }
+  uint32_t s[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    while (probe[k].y != kNone && probe[k].x != rip[k]) {  // (a collision: the next slot)
+      hslot[k] = (hslot[k] + 1) & hmask;
+      probe[k] = a.ip_hash[hslot[k]];
+    }
+    s[k] = probe[k].y < 0x80000000u ? probe[k].y : 0u;  // the one servant on the host (0: none, read anyway)
+  }
+  uint32_t b[R], e[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    b[k] = a.slot_base[s[k]];
+    e[k] = a.slot_base[s[k] + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t t = t0 + k * blockDim.x;
+    const bool live = t < a.n_tasks;
+    const uint64_t any = live && env[k] < n_env ? m[k] : 0;
+    uint32_t lo = kNone, hi = kNone;
+    if (probe[k].y != kNone) {
+      if (probe[k].y & 0x80000000u) {
+        lo = probe[k].y & 0x7FFFFFFFu;  // several servants on the host: resolved at replay time
+        hi = kSelfShared;
+      } else if (e[k] > b[k]) {
+        lo = b[k];
+        hi = e[k];
+      }
+    }
+    if (live) {
+      a.mask[t] = any;
+      a.self_lo[t] = lo;
+      a.self_hi[t] = hi;
+    }
+    // (chunk_size is a multiple of 64 and the waves of a k start at multiples of 64: all lanes
+    // of a wave fall into the same chunk — one atomic per wave, k and part)
+    uint64_t consuming = __ballot(any != 0);
+    const bool leader = (threadIdx.x & 63) == 0;
+    const uint32_t t_wave = t - (threadIdx.x & 63);
+    if (a.n_parts <= 1) {
+      if (consuming && leader) atomicAdd(&a.chunk_consuming[t / a.chunk_size], (uint32_t)__popcll(consuming));
+      if (a.chunk_tail && (t_wave + 64) % a.chunk_size == 0 && t_wave + 64 <= a.n_tasks && leader)
+        a.chunk_tail[t / a.chunk_size] = (uint32_t)__popcll(consuming >> (64 - a.tail_len));
+    } else {
+      const uint32_t part = any ? a.cls_comp[(uint32_t)__builtin_ctzll(any)] : 0xFFFFFFFFu;
+      while (consuming) {
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(consuming));
+        const uint64_t same = __ballot(part == g);
+        if (leader)
+          atomicAdd(&a.chunk_consuming[(size_t)(t / a.chunk_size) * a.n_parts + g], (uint32_t)__popcll(same));
+        consuming &= ~same;
+      }
     }
   }
 }
@@ -506,8 +639,10 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
 #else
 #define YDC_GEN_PROBE_END() do { } while (0)
 #endif
-  if (blockIdx.x >= gen_blocks) {
-    task_classify_block(ca, blockIdx.x - gen_blocks, prm);
+  const uint32_t gen_grid = xcd_grid(gen_blocks);
+  if (blockIdx.x >= gen_grid) {
+    if (ca.per_thread == 4) task_classify_block_multi<4>(ca, blockIdx.x - gen_grid, prm);
+    else task_classify_block(ca, blockIdx.x - gen_grid, prm);
     YDC_GEN_PROBE_END();
     return;
   }
@@ -520,7 +655,11 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
   const uint32_t radix = 1u << bits0, kbits = bits0 - fused0;
   for (uint32_t d = threadIdx.x; d < radix; d += blockDim.x) h0[d] = 0;
   const uint32_t M = prm->n_slots;
-  const uint32_t tile = blockIdx.x, base = tile * (blockDim.x * items);
+  const uint32_t tile = xcd_tile(blockIdx.x, gen_blocks, ca.xcd_gen), base = tile * (blockDim.x * items);
+  if (tile >= gen_blocks) {
+    YDC_GEN_PROBE_END();
+    return;
+  }
   const uint32_t g_end = min(M, base + blockDim.x * items);  // (base >= M: nothing to generate)
   if (base < M) {
     if (tile_first) {  // (k_servant_scan left the owners of the tiles' first slots behind)
@@ -595,6 +734,8 @@ __global__ __launch_bounds__(256) void k_slot_gen(ServantTable sv, const uint32_
 // cls_by_g[vals[i]] with the element's key being its index (== global rank).
 // ---------------------------------------------------------------------------
 constexpr int kMaxRadixBits = 11;
+constexpr int kMaxFusedClsBits = 5;   // class bits k_radix_scatter_classed can rank on
+constexpr uint32_t kMaxFusedClasses = 8;  // ... and the class count up to which the planner asks it to
 
 // 32-bit keys travel with their values in 8-byte records (packed: `keys` points to uint2
 // {key, value}, `vals` is unused); 64-bit keys (fp64 format) keep two arrays.
@@ -615,6 +756,7 @@ struct SortIn {
   uint32_t gbits, out_mask;
   uint32_t packed;        // input is records
   uint32_t key_is_index;  // first class pass: the key is the element's index (its global rank)
+  uint32_t xcd_hist, xcd_scatter;  // XCD-contiguous tile order in the histogram / scatter launch
 };
 
 template <typename KeyT>
@@ -664,13 +806,14 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(SortIn<KeyT> in, De
                                                              uint32_t n_tiles, uint32_t* hist,
                                                              PrefixArgs pa) {
   extern __shared__ uint32_t h[];  // radix
-  if (blockIdx.x == n_tiles) {
+  if (blockIdx.x == xcd_grid(n_tiles)) {
     chunk_prefix_block(pa, prm);
     return;
   }
   const uint32_t radix = 1u << in.bits;
   const uint32_t M = prm->n_slots;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = xcd_tile(blockIdx.x, n_tiles, in.xcd_hist);
+  if (tile >= n_tiles) return;
   for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) h[d] = 0;
   __syncthreads();
   const uint32_t base = tile * (kSortThreads * in.items);
@@ -728,9 +871,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   uint32_t* cnt = sm;
   uint32_t* dstart = sm + kSortWaves * radix;
   const uint32_t M = prm->n_slots;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = xcd_tile(blockIdx.x, n_tiles, in.xcd_scatter);
   const uint32_t base = tile * (kSortThreads * in.items);
-  if (base >= M) return;
+  if (tile >= n_tiles || base >= M) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t wave_span = in.items * 64;  // consecutive elements a wave owns
   {
@@ -823,9 +966,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
   uint32_t* kcnt = dstart + radix;
   uint32_t* kstart = kcnt + kSortWaves * kradix;
   const uint32_t M = prm->n_slots;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = xcd_tile(blockIdx.x, n_tiles, in.xcd_scatter);
   const uint32_t base = tile * (kSortThreads * in.items);
-  if (base >= M) return;
+  if (tile >= n_tiles || base >= M) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t wave_span = in.items * 64;
   {
@@ -839,24 +982,33 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
       dstart[d] = acc + hist[d * n_tiles + tile];
       acc += row_total[d];
     }
-    __syncthreads();  // lds[] is reused by the second scan
+    // (row totals and this tile's column of the scanned table, once more in LDS — cnt[] is
+    // not in use yet —: the sums over the classes below read them 2 n_cls times per key digit)
+    uint32_t* rt_l = cnt;
+    uint32_t* h_l = cnt + radix;
+    for (uint32_t d = threadIdx.x; d < radix; d += kSortThreads) {
+      rt_l[d] = row_total[d];
+      h_l[d] = hist[d * n_tiles + tile];
+    }
+    __syncthreads();  // (and lds[] is reused by the second scan)
     // Key-only digit starts: all classes' elements with a smaller key digit + the elements
     // of earlier tiles with the same key digit.
     const uint32_t kper = (kradix + kSortThreads - 1) / kSortThreads;
-    const uint32_t k0 = threadIdx.x * kper, k1 = min(kradix, k0 + kper);
+    const uint32_t k0 = min(kradix, threadIdx.x * kper), k1 = min(kradix, k0 + kper);
     sum = 0;
     for (uint32_t d = k0; d < k1; ++d)
-      for (uint32_t c = 0; c < n_cls; ++c) sum += row_total[(c << kbits) | d];
+      for (uint32_t c = 0; c < n_cls; ++c) sum += rt_l[(c << kbits) | d];
     acc = block_exclusive_scan(sum, lds, &total);
     for (uint32_t d = k0; d < k1; ++d) {
       uint32_t all = 0, earlier = 0;
       for (uint32_t c = 0; c < n_cls; ++c) {
-        all += row_total[(c << kbits) | d];
-        earlier += hist[((c << kbits) | d) * n_tiles + tile];
+        all += rt_l[(c << kbits) | d];
+        earlier += h_l[(c << kbits) | d];
       }
       kstart[d] = acc + earlier;
       acc += all;
     }
+    __syncthreads();  // rt_l / h_l are cnt[]: read before it is cleared
     for (uint32_t d = threadIdx.x; d < kSortWaves * radix; d += kSortThreads) cnt[d] = 0;
     for (uint32_t d = threadIdx.x; d < kSortWaves * kradix; d += kSortThreads) kcnt[d] = 0;
   }
@@ -887,7 +1039,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
     }
     uint64_t peers = kpeers;  // same key digit; now the same class as well
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < kMaxFusedClsBits; ++b) {
       if ((uint32_t)b < in.fused_cls_bits) {
         const uint64_t m = __ballot((d >> (kbits + b)) & 1u);
         peers &= ((d >> (kbits + b)) & 1u) ? m : ~m;

@@ -139,6 +139,13 @@ struct MatchBuffers {
   // first slot whose global rank is >= 64 m (bin_sort.h). With <= 8 classes pass 0 turns a level
   // into class cursors with one lookup and one 64-entry window per class instead of a search.
   const uint32_t* level_tab;
+  // Non-NULL (radix path, the class partition was a pass of its own): that pass's scanned
+  // histogram table — entry [c * tile_tab_tiles + t] = slots of class c among the first
+  // t * tile_tab_elems slots of the global order, i.e. a level table at tile granularity that
+  // the sort leaves behind anyway (kernels.h: k_radix_scan). A lane's two level searches then run
+  // over the class's entries of ONE tile (a few dozen) instead of its whole list.
+  const uint32_t* tile_tab;
+  uint32_t tile_tab_tiles, tile_tab_elems;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
   uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
 };
@@ -783,15 +790,49 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       } else if (L.list_p && C <= 4) {
         // (filled in below by the whole wave)
       } else if (L.list_p) {
+        // Every step of a search is a memory round trip (~1 us in a busy launch) and the picks
+        // cannot start before the last one: the tile table narrows both searches to one sort
+        // tile's worth of the class list, and each step probes the three quartile points of
+        // what is left (independent loads, one round trip) — 1 + ~4 round trips where the plain
+        // bisection of a 2^17-entry list took 18.
         uint32_t lo0 = b, hi0 = e, lo1 = b, hi1 = e;
+        if (B.tile_tab) {
+          const uint32_t off = prm->rank_offset, nt = B.tile_tab_tiles;
+          const uint32_t t0 = min((n0 > off ? n0 - off : 0u) / B.tile_tab_elems, nt - 1);
+          const uint32_t t1 = min((n1 > off ? n1 - off : 0u) / B.tile_tab_elems, nt - 1);
+          const uint32_t* row = B.tile_tab + (size_t)lane * nt;
+          const uint32_t a0 = row[t0], z0 = t0 + 1 < nt ? row[t0 + 1] : e - b;
+          const uint32_t a1 = row[t1], z1 = t1 + 1 < nt ? row[t1 + 1] : e - b;
+          lo0 = b + a0;
+          hi0 = b + z0;
+          lo1 = b + a1;
+          hi1 = b + z1;
+        }
         while (lo0 < hi0 || lo1 < hi1) {
-          const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-          const uint32_t v0 = lo0 < hi0 ? list_rank(L, m0) : 0u, v1 = lo1 < hi1 ? list_rank(L, m1) : 0u;
+          // quartile probes of [lo, hi): q1 <= q2 <= q3 < hi (they coincide in short ranges)
+          const uint32_t s0 = (hi0 - lo0 + 3) >> 2, s1 = (hi1 - lo1 + 3) >> 2;
+          uint32_t q0[3], q1[3], v0[3], v1[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            q0[k] = lo0 < hi0 ? min(lo0 + (k + 1) * s0 - 1, hi0 - 1) : 0u;
+            q1[k] = lo1 < hi1 ? min(lo1 + (k + 1) * s1 - 1, hi1 - 1) : 0u;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            v0[k] = lo0 < hi0 ? list_rank(L, q0[k]) : 0u;
+            v1[k] = lo1 < hi1 ? list_rank(L, q1[k]) : 0u;
+          }
           if (lo0 < hi0) {
-            if (v0 < n0) lo0 = m0 + 1; else hi0 = m0;
+            if (v0[0] >= n0) hi0 = q0[0];
+            else if (v0[1] >= n0) { lo0 = q0[0] + 1; hi0 = q0[1]; }
+            else if (v0[2] >= n0) { lo0 = q0[1] + 1; hi0 = q0[2]; }
+            else lo0 = q0[2] + 1;
           }
           if (lo1 < hi1) {
-            if (v1 < n1) lo1 = m1 + 1; else hi1 = m1;
+            if (v1[0] >= n1) hi1 = q1[0];
+            else if (v1[1] >= n1) { lo1 = q1[0] + 1; hi1 = q1[1]; }
+            else if (v1[2] >= n1) { lo1 = q1[1] + 1; hi1 = q1[2]; }
+            else lo1 = q1[2] + 1;
           }
         }
         c0 = lo0;

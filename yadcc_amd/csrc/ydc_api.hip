@@ -121,6 +121,7 @@ struct ydc_context {
   // Resident registry.
   DevBuf<uint32_t> d_version, d_nproc, d_load, d_max_tasks, d_running, d_flags, d_class_of;
   DevBuf<uint32_t> d_spare[6];  // ydc_remove_servants compacts into these, then swaps
+  DevBuf<uint32_t> d_ip_hash, d_ip_filter;
   DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted, d_cls_comp, d_part_base;
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
   DevBuf<uint8_t> d_cls_single;
@@ -274,6 +275,9 @@ struct ydc_context {
   // 16 KB of LDS per matching wave = 10 waves per CU. Smaller rings (more waves per CU, shorter
   // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
   uint32_t opt_ring_total = 0;  // entries of a matching wave's rings; 0: chosen per batch (YDC_RING_TOTAL)
+  uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
+  bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
+  bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
   bool opt_split_gen = false;  // slot generation and request classification as two launches (YDC_SPLIT_GEN=1)
   bool opt_dense = true;  // 4-waves-per-SIMD matching kernel and twice the chunks where it pays (YDC_DENSE=0)
   bool opt_fused_class = true;
@@ -408,12 +412,25 @@ int rebuild_tables(ydc_context* c) {
                   c->h_alias_ip.data(), c->h_alias_servant.data());
   const uint32_t n_ip = (uint32_t)c->tables.ip_sorted.size();
   c->n_parts = c->tables.n_comp;
-  c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits, &c->n_parts);
   const uint32_t C = c->tables.n_classes();
+  // The class partition on the last key pass, which may be given room for it. Up to 8 classes:
+  // with 30 (cfg4: 9 + 9 + (5 + 5) bits instead of 8 + 8 + 7 and a class pass) the three passes
+  // took 188 us where the four take 155 — wider digits scatter worse, and the fused pass ranks
+  // twice and writes a third array (profiles/r04: measured and rejected).
+  uint32_t fuse_bits = 0;
+  if (C > 1 && C <= kMaxFusedClasses && c->opt_fused_class)
+    while ((1u << fuse_bits) < C) ++fuse_bits;
+  c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits, &c->n_parts, fuse_bits);
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
   HIP_TRY(c, c->d_ip_sorted.reserve(n_ip));
   HIP_TRY(c, c->d_ip_servant.reserve(n_ip));
+  HIP_TRY(c, c->d_ip_hash.reserve(c->tables.ip_hash.size()));
+  HIP_TRY(c, hipMemcpyAsync(c->d_ip_hash.p, c->tables.ip_hash.data(), c->tables.ip_hash.size() * 4,
+                            hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, c->d_ip_filter.reserve(c->tables.ip_filter.size()));
+  HIP_TRY(c, hipMemcpyAsync(c->d_ip_filter.p, c->tables.ip_filter.data(), c->tables.ip_filter.size() * 4,
+                            hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, c->d_cls_env.reserve((size_t)C * c->env_words));
   HIP_TRY(c, c->d_cls_ver.reserve(C));
   HIP_TRY(c, c->d_cls_begin.reserve(C + 1));
@@ -511,27 +528,30 @@ struct KernelTimer {
 
 // pa (nullable): the chunk prefix rides in the histogram launch as one more workgroup.
 template <typename KeyT>
-int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in, uint32_t n_tiles, void* out_keys,
+int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in_, uint32_t n_tiles, void* out_keys,
                      bool out_u32, uint32_t* out_vals, const PrefixArgs* pa = nullptr,
                      bool have_hist = false) {
+  SortIn<KeyT> in = in_;
+  in.xcd_hist = (c->opt_xcd >> 1) & 1;
+  in.xcd_scatter = (c->opt_xcd >> 2) & 1;
   const uint32_t radix = 1u << in.bits;
   if (!have_hist)  // (the first pass's tile histograms come out of k_slot_gen)
-    YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(n_tiles + (pa ? 1 : 0)), dim3(kSortThreads),
+    YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(xcd_grid(n_tiles) + (pa ? 1 : 0)), dim3(kSortThreads),
                radix * 4, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p, pa ? *pa : PrefixArgs{});
   YDC_LAUNCH(c, "k_radix_scan", k_radix_scan, dim3(radix), dim3(256), 0, c->stream, n_tiles,
              c->d_hist.p, c->d_row_total.p);
   const size_t lds = (size_t)(kSortWaves + 1) * radix * 4;
   if (in.fused_cls_bits) {
     const size_t lds2 = lds + (size_t)(kSortWaves + 1) * (radix >> in.fused_cls_bits) * 4;
-    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter_classed<KeyT>), dim3(n_tiles),
+    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter_classed<KeyT>), dim3(xcd_grid(n_tiles)),
                dim3(kSortThreads), lds2, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint32_t*)out_keys, out_vals, c->d_rank_to_g.p);
   } else if (out_u32) {
-    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint32_t>), dim3(n_tiles),
+    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint32_t>), dim3(xcd_grid(n_tiles)),
                dim3(kSortThreads), lds, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint32_t*)out_keys, out_vals);
   } else {
-    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint64_t>), dim3(n_tiles),
+    YDC_LAUNCH(c, "k_radix_scatter", (k_radix_scatter<KeyT, uint64_t>), dim3(xcd_grid(n_tiles)),
                dim3(kSortThreads), lds, c->stream, in, c->d_prm.p, n_tiles, c->d_hist.p,
                c->d_row_total.p, (uint64_t*)out_keys, out_vals);
   }
@@ -640,6 +660,9 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_RING_TOTAL")) c->opt_ring_total = std::max(256u, (uint32_t)atoi(s));
   if (const char* s = getenv("YDC_DENSE")) c->opt_dense = atoi(s) != 0;
   if (const char* s = getenv("YDC_SPLIT_GEN")) c->opt_split_gen = atoi(s) != 0;
+  if (const char* s = getenv("YDC_XCD_TILES")) c->opt_xcd = (uint32_t)atoi(s);
+  if (const char* s = getenv("YDC_TILE_TAB")) c->opt_tile_tab = atoi(s) != 0;
+  if (const char* s = getenv("YDC_CLASSIFY_PER_THREAD")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
@@ -670,7 +693,7 @@ int ydc_destroy(ydc_context* c) {
   stream_release(c);
   group_release(c);
   for (auto* b : {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
-                  &c->d_flags, &c->d_class_of, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
+                  &c->d_flags, &c->d_class_of, &c->d_ip_hash, &c->d_ip_filter, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
                   &c->d_cls_comp, &c->d_part_base,
                   &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist, &c->d_tile_first,
                   &c->d_row_total, &c->d_self_lo, &c->d_self_hi, &c->d_chunk_consuming,
@@ -1045,7 +1068,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     if (gb + cls_bits <= 32 && c->opt_packed_class) p.gbits = gb;  // the class rides above the slot index
     // A handful of classes and room left in the last key digit: one pass does both.
     const uint32_t last_bits = c->kf.key_bits - (p.key_passes - 1) * c->kf.bits_per_pass;
-    if (C <= 8 && p.key_passes >= 1 && last_bits + cls_bits <= (uint32_t)kMaxRadixBits &&
+    if (C <= kMaxFusedClasses && p.key_passes >= 1 && last_bits + cls_bits <= (uint32_t)kMaxRadixBits &&
         c->opt_fused_class) {
       p.fused_cls_bits = cls_bits;
       HIP_TRY(c, c->d_rank_to_g.reserve(slot_bound));
@@ -1170,6 +1193,13 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     p.mb.sampled = c->d_prm.p->n_sampled;
     p.mb.flag_mask = 63;
     p.mb.level_tab = p.binsort && c->opt_level_tab && c->n_parts <= 1 ? c->d_level_tab.p : nullptr;
+    // The class partition as a pass of its own leaves its scanned histogram table in d_hist:
+    // digit == class, one column per sort tile (enqueue_sort; k_radix_scan).
+    if (!p.binsort && p.cls_passes == 1 && p.slot_bound && c->opt_tile_tab) {
+      p.mb.tile_tab = c->d_hist.p;
+      p.mb.tile_tab_tiles = p.n_tiles;
+      p.mb.tile_tab_elems = kSortThreads * p.sort_items;
+    }
     // (a group of one rank is a single GPU with the exchanges of the protocol around it)
     p.fuse01 = c->opt_fuse_passes && c->group.n_ranks <= 1;
     if (p.fuse01) {
@@ -1256,6 +1286,11 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
                       p.binsort ? 1u : 0u, p.binsort ? 1u : 0u};
   }
   ca.n_ip = (uint32_t)c->tables.ip_sorted.size();
+  ca.ip_hash = (const uint2*)c->d_ip_hash.p;
+  ca.ip_hash_shift = c->tables.ip_hash_shift;
+  ca.xcd_gen = c->opt_xcd & 1;
+  ca.ip_filter = c->d_ip_filter.p;
+  ca.ip_filter_shift = c->tables.ip_filter_shift;
   ca.row_out = p.wide_lists && N && classify ? c->d_row_of.p : nullptr;
   ca.cls_comp = c->d_cls_comp.p;  // (k_slot_gen reads them for the part id above the key)
   ca.n_parts = c->n_parts;
@@ -1263,7 +1298,11 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   const uint32_t fused0 = p.key_passes == 1 ? p.fused_cls_bits : 0;
   const uint32_t bits0 = std::min(bpp0, c->kf.key_bits) + fused0;
   const uint32_t gen_blocks = gen && p.slot_bound ? p.n_tiles : 0;
-  const uint32_t cls_blocks = classify ? ceil_div(N, 256) : 0;
+  // Large batches of the radix path: four requests per thread (kernels.h: task_classify_block_multi;
+  // the lookup form with one mask word). YDC_CLASSIFY_PER_THREAD=1 keeps one.
+  ca.per_thread = classify && !p.binsort && N >= (1u << 18) && !c->tables.env_ver_mask.empty() && W == 1 &&
+                          !ca.row_out && c->opt_classify_multi ? 4u : 1u;
+  const uint32_t cls_blocks = classify ? ceil_div(N, 256 * ca.per_thread) : 0;
   if (gen_blocks + cls_blocks == 0) return;
   const size_t lds0 = ((size_t)4 << bits0);
   // Key window (sharded sort): local prefix, first local slot and registry-wide names.
@@ -1283,13 +1322,13 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   }
   const char* gen_name = gen_blocks && cls_blocks ? "k_slot_gen" : (gen_blocks ? "k_slot_gen(slots)" : "k_slot_gen(requests)");
   if (p.key32) {
-    YDC_LAUNCH(c, gen_name, k_slot_gen<uint32_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+    YDC_LAUNCH(c, gen_name, k_slot_gen<uint32_t>, dim3(xcd_grid(gen_blocks) + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint32_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
                r_first, gbase, p.packed ? 1u : 0u, p.win ? nullptr : c->d_tile_first.p);
   } else {
-    YDC_LAUNCH(c, gen_name, k_slot_gen<uint64_t>, dim3(gen_blocks + cls_blocks), dim3(256), lds0,
+    YDC_LAUNCH(c, gen_name, k_slot_gen<uint64_t>, dim3(xcd_grid(gen_blocks) + cls_blocks), dim3(256), lds0,
                c->stream, p.sv, base, c->d_prm.p, (uint32_t)c->kf.exact, c->kf.cap_bits,
                (uint64_t*)c->d_keys[0].p, c->d_vals[0].p, cls_by_g, c->d_owner.p,
                gen_blocks, p.sort_items, bits0, fused0, p.gbits, c->d_hist.p, ca, c->kf.comp_shift,
@@ -2655,6 +2694,10 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
       p.slot_bound = (uint32_t)bound;
       p.sort_items = p.slot_bound <= 300000 ? 2 : (p.slot_bound <= 700000 ? 4 : 8);
       p.n_tiles = std::max<uint32_t>(1, ceil_div(p.slot_bound, kSortThreads * p.sort_items));
+      if (p.mb.tile_tab) {  // (the window's own tiles: ranks are registry-wide, rank_offset apart)
+        p.mb.tile_tab_tiles = p.n_tiles;
+        p.mb.tile_tab_elems = kSortThreads * p.sort_items;
+      }
       HIP_TRY(c, g.d_cum.reserve(kWindowThresholds + 1));
       HIP_TRY(c, g.d_r_first.reserve(S));
       HIP_TRY(c, g.d_lbase.reserve((size_t)S + 1));
