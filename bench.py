@@ -529,7 +529,7 @@ def setup(args):
     return E
 
 
-def measure_config(E, args, config, scaling, steps, warmup, detail):
+def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
     """Times `steps` batches of `config` on the run's context(s). detail "full": the driver's
     line (end-to-end loops, CPU baseline, >= 100 latency samples); "compact": a sub-record of
     it (resident loop, synchronous latencies, per-kernel events, parity against the committed
@@ -547,7 +547,7 @@ def measure_config(E, args, config, scaling, steps, warmup, detail):
     # Strong: the config's own batch and pool. Either way rank r owns the r-th range of the
     # batch (arrival order).
     n_cfg, s_cfg, n_envs, unk = synth.CONFIGS[config]
-    n_envs = (args.digests if full else 0) or n_envs
+    n_envs = (args.digests if full else digests) or n_envs
     shared = args.shared_ip_frac if full else 0.0
     mult = world if scaling == "weak" else 1
     n_all = n_cfg * mult
@@ -766,7 +766,7 @@ def measure_config(E, args, config, scaling, steps, warmup, detail):
         "pipeline_depth": 2 if pipelined else 1,
         "ms_per_step_synchronous": sync_ms,
         "config": {"workload": "%s%s%s: %s%s, %d classes" % (
-                       config, " with %d digests" % n_envs if full and args.digests else "",
+                       config, " with %d digests" % n_envs if (full and args.digests) or digests else "",
                        "" if world == 1 else " (%s scaling)" % scaling, shape,
                        ", %.0f %% of the servants on shared hosts" % (100 * shared) if shared else "",
                        st["n_classes"]),
@@ -821,6 +821,10 @@ def measure_config(E, args, config, scaling, steps, warmup, detail):
         out["conservation"] = bool(np.array_equal(
             host_run.astype(np.int64) - sv["running_tasks"].astype(np.int64),
             np.bincount(host_idx[ok], minlength=n_serv)))
+    if digests and world == 1:
+        from oracle import oraclebind as O
+        want, _, wrun = O.dispatch(sv, tk_all, "sorted", want_util=False)
+        out["parity_vs_oracle"] = bool(np.array_equal(host_idx, want) and np.array_equal(host_run, wrun))
     if prof:
         dom = max(prof, key=lambda k: prof[k][1])
         launches, total_ms = prof[dom]
@@ -912,6 +916,11 @@ def main():
         for cfg in ("cfg3", "cfg4"):
             k = max(5, min(args.steps, 20))
             out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 3, "compact"))
+        # Sparse eligibility: cfg2's batch on a pool with 150 digests, every servant advertising its
+        # own handful (~one servant class per servant; the reference has no limit on them,
+        # task_dispatcher.h:93-94) — the walk in groups of 64 requests (wide_kernel.h).
+        rec = measure_config(E, args, "cfg2", "weak", 3, 2, "compact", digests=150)
+        out["configs"]["cfg2_150_digests"] = compact(rec)
     if extra and E.world == 1 and not E.use_dist and not args.resident_only:
         E.ctx.close()  # (the native tool opens its own context on the device)
         out["td_surface"] = td_surface(with_reference=not args.no_cpu_baseline)

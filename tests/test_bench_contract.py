@@ -89,7 +89,10 @@ def test_bench_cfg2_line():
     # the other single-GPU configurations of BASELINE.json, timed in the same run and pinned to
     # the committed fixtures of the verbatim reference
     c = j["configs"]
-    assert set(c) == {"cfg3", "cfg4", "cfg5"}
+    assert set(c) == {"cfg3", "cfg4", "cfg5", "cfg2_150_digests"}
+    d = c["cfg2_150_digests"]
+    assert "with 150 digests" in d["workload"] and d["parity_vs_oracle"] is True and d["conservation"] is True
+    assert d["ms_per_step"] < 40  # (84 ms with the lone walker of round 3)
     assert "1000000 pending requests x 8000 servants" in c["cfg3"]["workload"]
     assert "4000000 pending requests x 16000 servants" in c["cfg4"]["workload"]
     for k in ("cfg3", "cfg4"):

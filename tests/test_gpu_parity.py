@@ -396,16 +396,19 @@ def test_many_classes_paths(ctx):
     assert st["n_classes"] > 256
 
 
-@pytest.mark.parametrize("wide", [1, 2, 3, 0])
+@pytest.mark.parametrize("wide", [1, 4, 2, 3, 0])
 def test_more_than_256_classes(wide, monkeypatch):
     """Pools whose machines advertise individual compiler sets (the reference has no limit on
     (environment set, version) combinations, task_dispatcher.h:93-94, .cc:316-344): 150 digests,
     about one class per servant. wide=1: one wave per chunk with the class states in LDS
-    (k_sim_wide), a request's classes read from its (digest, version threshold) row, and — these
-    pools do not converge by rounds — the walk; wide=2: the walk with prefetch waves; wide=3: mask
+    (k_sim_wide), a request's classes read from its (digest, version threshold) row — registries
+    with such rows are walked 64 requests at a time from the first request on (k_walk_groups);
+    wide=4: rounds of speculation and then the lone walker instead; wide=2: the walk with prefetch waves; wide=3: mask
     scan instead of the rows; wide=0: the thread-per-chunk kernel. Plain, with traffic from the servants'
     own hosts on shared hosts (holes, `self` resolved at replay time), and oversubscribed."""
     monkeypatch.setenv("YDC_WIDE", "1" if wide else "0")
+    if wide in (2, 4):
+        monkeypatch.setenv("YDC_GROUP_WALK", "0")  # rounds, then one request at a time
     if wide == 2:
         monkeypatch.setenv("YDC_WALK_PREFETCH", "1")  # the walk with prefetch waves
     if wide == 3:
@@ -425,6 +428,44 @@ def test_more_than_256_classes(wide, monkeypatch):
                                    oversubscribed=True, self_frac=0.2)
         st = check(c, sv, tk)
         assert st["n_classes"] > 256 and st["timeouts"] > 100
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_group_walk_random_sparse_pools(seed):
+    """k_walk_groups (sparse eligibility: 40 .. 200 digests, about one class per servant) on random
+    shapes: ragged batch sizes, none / heavy traffic from the servants' own hosts, shared hosts,
+    oversubscription (Timeout tails), unknown digests, initial running_tasks, and a batch
+    committed in two halves — placement, utilisation and running_tasks against the literal
+    restatement of the reference."""
+    rng = np.random.default_rng(seed)
+    kw = dict(seed=seed, n_tasks=int(rng.choice([1, 63, 64, 65, 1000, 4097, 20000])),
+              n_servants=int(rng.choice([300, 700, 1500])), n_envs=int(rng.choice([40, 90, 150, 200])),
+              self_frac=float(rng.choice([0.0, 0.1, 0.6])), unknown_env_frac=float(rng.choice([0.0, 0.01])),
+              min_version_20_frac=float(rng.choice([0.0, 0.5, 1.0])))
+    if rng.random() < 0.3:
+        kw["oversubscribed"] = True
+    if rng.random() < 0.3:
+        kw["shared_ip_frac"] = 0.25
+    if rng.random() < 0.3:
+        kw["initial_running"] = True
+    sv, tk = cases.random_case(**kw)
+    c = binding.Context(device=0)
+    try:
+        want, wutil, wrun = O.dispatch(sv, tk, "scan" if len(tk["env_id"]) <= 5000 else "sorted")
+        c.upload_servants(pack.to_abi_columns(sv))
+        n = len(tk["env_id"])
+        if seed % 3 == 0 and n > 1:
+            cut = int(rng.integers(1, n))
+            a, ua, _ = c.dispatch({k: v[:cut] for k, v in tk.items()}, commit=True)
+            b, ub, grun = c.dispatch({k: v[cut:] for k, v in tk.items()}, commit=True)
+            got, gutil = np.concatenate([a, b]), np.concatenate([ua, ub])
+        else:
+            got, gutil, grun = c.dispatch(tk)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (kw, bad[:5], got[bad[:5]], want[bad[:5]], c.stats())
+        assert np.array_equal(grun, wrun) and np.array_equal(gutil, wutil)
     finally:
         c.close()
 

@@ -26,6 +26,7 @@ constexpr uint32_t kWideFields = 9;
 // entries + how far it is filled): 72 B + 8 B of mask words per class.
 constexpr uint32_t kMaxWalkPrefetchClasses = 1920;
 constexpr uint32_t kWalkRing = 4;
+constexpr size_t kGroupWalkMaxLds = 160 * 1024 - 512;  // k_walk_groups: one workgroup, a CU's LDS
 // Dynamic LDS of k_sim_wide for C classes: the nine state arrays + the class masks of a block of
 // 64 requests (64 x ceil(C / 64) 64-bit words).
 // Seven state arrays of C words, the two the scan reads (head rank, head slot) padded to a
@@ -74,6 +75,86 @@ struct WideState {
     return r;
   }
 };
+
+// The general step of one request on the LDS state — the shared state machine of dispatch_core.h:
+// a request from a servant's own host whose servant shows at the head of an eligible class, a
+// request one of whose classes has holes, a host that runs several servants. The whole wave works
+// on the ONE request t (lane l looks at the classes l, l + 64, ... of its mask words); holew's bits
+// follow the classes' holes.
+__device__ __forceinline__ void wide_general_step(const ClassLists& L, const WideState& S, uint64_t* holew,
+                                                  uint32_t W, const uint64_t* mask, uint32_t self_lo,
+                                                  uint32_t self_hi, const SharedIpTable& shared,
+                                                  uint32_t* __restrict__ slot_of, uint32_t t, uint32_t lane) {
+  uint64_t many = 0;
+  for (uint32_t w = 0; w < W; ++w) many |= mask[w];
+  if (many == 0) {
+    if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+    return;
+  }
+  if (self_hi == kSelfShared) {
+    auto state_of = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
+      cursor = S.cur[c];
+      lo = S.lo[c];
+      hown_lo = S.hlo[c];
+    };
+    resolve_shared_self(mask, self_lo, &shared, state_of, self_lo, self_hi);
+  }
+  uint32_t bp = kNone, bi = 0, bg = 0, bc = kNone;
+  for (uint32_t w = 0; w < W; ++w) {
+    if ((mask[w] >> lane) & 1u) {
+      const uint32_t c = w * 64 + lane;
+      uint32_t ci, cp, cg;
+      if (class_candidate(L, S.run(L, c), self_lo, self_hi, ci, cp, cg) && cp < bp) {
+        bp = cp;
+        bi = ci;
+        bg = cg;
+        bc = c;
+      }
+    }
+  }
+  const uint32_t mn = wave_min_u32(bp);
+  bool win = mn != kNone && bp == mn;
+  if (mn == kNone) {
+    // task_dispatcher.cc:392-396: the requestor's own servant, first eligible class that has it
+    uint32_t sc = kNone;
+    if (self_lo != kNone) {
+      for (uint32_t w = 0; w < W && sc == kNone; ++w) {
+        if ((mask[w] >> lane) & 1u) {
+          const uint32_t c = w * 64 + lane;
+          uint32_t ci, cg;
+          if (class_self_candidate(L, S.run(L, c), self_lo, self_hi, ci, cg)) {
+            sc = c;
+            bi = ci;
+            bg = cg;
+            bc = c;
+          }
+        }
+      }
+    }
+    const uint32_t first = wave_min_u32(sc);
+    if (first == kNone) {
+      if (lane == 0) slot_of[t] = kIdxTimeout;
+      return;
+    }
+    win = sc == first;
+  }
+  if (win) {
+    slot_of[t] = bg;
+    ClassRun r = S.run(L, bc);
+    const bool had = r.lo < r.cursor;
+    class_consume(L, r, bi, self_lo, self_hi);
+    S.cur[bc] = r.cursor;
+    S.lo[bc] = r.lo;
+    S.hlo[bc] = r.hown_lo;
+    S.hhi[bc] = r.hown_hi;
+    S.hp[bc] = r.head_p;
+    S.hg[bc] = r.head_g;
+    S.np[bc] = r.cursor + 1 < r.end ? list_rank(L, r.cursor + 1) : kNone;
+    S.ng[bc] = r.cursor + 1 < r.end ? list_slot(L, r.cursor + 1) : kNone;
+    const bool has = r.lo < r.cursor;
+    if (has != had) holew[bc >> 6] ^= 1ull << (bc & 63u);
+  }
+}
 
 // walk != 0 (launched with ONE workgroup): the speculation is not converging — pools of many
 // small classes with sparse eligibility have no "level" the guesses could start from, and a
@@ -436,75 +517,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
       // ---- general step (dispatch_core.h's state machine on the LDS state)
       flush();
       __builtin_amdgcn_wave_barrier();
-      many = 0;
-      for (uint32_t w = 0; w < W; ++w) many |= mask[w];
-      if (many == 0) {
-        if (lane == 0) slot_of[t] = kIdxEnvNotFound;
-        continue;
-      }
-      if (self_hi == kSelfShared) {
-        auto state_of = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
-          cursor = S.cur[c];
-          lo = S.lo[c];
-          hown_lo = S.hlo[c];
-        };
-        resolve_shared_self(mask, self_lo, &shared, state_of, self_lo, self_hi);
-      }
-      uint32_t bp = kNone, bi = 0, bg = 0, bc = kNone;
-      for (uint32_t w = 0; w < W; ++w) {
-        if ((mask[w] >> lane) & 1u) {
-          const uint32_t c = w * 64 + lane;
-          uint32_t ci, cp, cg;
-          if (class_candidate(L, S.run(L, c), self_lo, self_hi, ci, cp, cg) && cp < bp) {
-            bp = cp;
-            bi = ci;
-            bg = cg;
-            bc = c;
-          }
-        }
-      }
-      const uint32_t mn = wave_min_u32(bp);
-      bool win = mn != kNone && bp == mn;
-      if (mn == kNone) {
-        // task_dispatcher.cc:392-396: the requestor's own servant, first eligible class that has it
-        uint32_t sc = kNone;
-        if (self_lo != kNone) {
-          for (uint32_t w = 0; w < W && sc == kNone; ++w) {
-            if ((mask[w] >> lane) & 1u) {
-              const uint32_t c = w * 64 + lane;
-              uint32_t ci, cg;
-              if (class_self_candidate(L, S.run(L, c), self_lo, self_hi, ci, cg)) {
-                sc = c;
-                bi = ci;
-                bg = cg;
-                bc = c;
-              }
-            }
-          }
-        }
-        const uint32_t first = wave_min_u32(sc);
-        if (first == kNone) {
-          if (lane == 0) slot_of[t] = kIdxTimeout;
-          continue;
-        }
-        win = sc == first;
-      }
-      if (win) {
-        slot_of[t] = bg;
-        ClassRun r = S.run(L, bc);
-        const bool had = r.lo < r.cursor;
-        class_consume(L, r, bi, self_lo, self_hi);
-        S.cur[bc] = r.cursor;
-        S.lo[bc] = r.lo;
-        S.hlo[bc] = r.hown_lo;
-        S.hhi[bc] = r.hown_hi;
-        S.hp[bc] = r.head_p;
-        S.hg[bc] = r.head_g;
-        S.np[bc] = r.cursor + 1 < r.end ? list_rank(L, r.cursor + 1) : kNone;
-        S.ng[bc] = r.cursor + 1 < r.end ? list_slot(L, r.cursor + 1) : kNone;
-        const bool has = r.lo < r.cursor;
-        if (has != had) holew[bc >> 6] ^= 1ull << (bc & 63u);
-      }
+      wide_general_step(L, S, holew, W, mask, self_lo, self_hi, shared, slot_of, t, lane);
       __builtin_amdgcn_wave_barrier();
       YDC_WACC(pr_gen);
     }
@@ -544,6 +557,351 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
   }
 #endif
   if (prefetched && lane == 0) lds_store_u32(wdone, 1u);
+}
+
+
+// ---------------------------------------------------------------------------
+// k_walk_groups — the walk, sixty-four requests at a time (sparse eligibility: many small
+// classes, a request may use a few dozen of them — host_tables.h: elig_off / elig_cls).
+//
+// The lone walker above places one request per step with the whole wave looking at its classes:
+// ~0.6 us per request however few classes it has. Here LANE i holds request tb + i of a block
+// and scans its own row of eligible classes in LDS (all rows are staged once); then the block is
+// resolved in a few iterations, each of which commits every request whose pick is provably the
+// one the sequential process makes:
+//   * lane j's pick (its eligible class with the lowest-ranked head) is what sequence gives it
+//     unless an EARLIER unresolved request may still take that very slot. Earlier requests that
+//     commit in the same iteration take heads of other classes, which only raises those heads:
+//     j's minimum stays where it is.
+//   * so: every lane claims its winner class (LDS atomic min of the lane index); the lowest lane
+//     per class is a first picker, the others wait for the next iteration ("losers"). Every
+//     unresolved lane marks the classes of its row with its lane index (`taint`, atomic min);
+//     a first picker whose winner class carries a mark from an earlier lane waits too and marks
+//     its own row (repeated until no lane is added). What is left commits: distinct classes,
+//     none of them reachable by anything unresolved before it.
+//   * a request that needs the general step (its host's own servant at a head of one of its
+//     classes, holes in one of them, a host with several servants, nothing left but perhaps its
+//     own servant) is a barrier: the lanes before it resolve first, then the whole wave runs
+//     the state machine on it (wide_general_step), then the lanes behind it continue.
+//   * EnvironmentNotFound (empty row) and Timeout (every class of the row exhausted: classes only
+//     lose entries inside a batch) are final the moment they are seen.
+// Same protocol as the walker around it: starts at the first chunk whose start guess changed,
+// leaves end states and guesses consistent behind it. One wave.
+// ---------------------------------------------------------------------------
+// (rows are padded to multiples of eight classes in LDS — a row is read eight ids at a time)
+__host__ __device__ inline size_t group_walk_lds_bytes(uint32_t C, uint32_t n_rows, uint32_t n_list) {
+  return wide_lds_bytes(C) + (size_t)2 * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32;
+}
+
+__global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, uint32_t n_tasks,
+                                                    uint32_t chunk_size, uint32_t n_chunks,
+                                                    ClassState* __restrict__ guess,
+                                                    ClassState* __restrict__ endst, uint8_t* dirty,
+                                                    uint32_t* __restrict__ slot_of, SharedIpTable shared,
+                                                    uint32_t round, DeviceParams* prm, WideLists wl,
+                                                    uint32_t n_rows, uint32_t n_list, uint32_t whole_batch) {
+  extern __shared__ uint32_t wsm[];
+  const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
+  if (lane == 0) prm->n_changed[round & 63] = 0;
+  uint32_t k = n_chunks;
+  for (uint32_t base = 0; base < n_chunks && k == n_chunks; base += 64) {
+    const uint64_t m = __ballot(base + lane < n_chunks && dirty[base + lane] != 0);
+    if (m) k = base + (uint32_t)__builtin_ctzll(m);
+  }
+  if (k >= n_chunks) return;  // nothing left to walk
+  // LDS: the state arrays and bit rows of k_sim_wide, then claim[C] | taint[C] | row offsets | rows
+  const uint32_t W8 = (W + 7u) & ~7u, Cpad = W8 * 64;
+  const uint32_t state_words = (kWideFields - 2) * C + 2 * Cpad;
+  const uint32_t mask_at = (state_words + 3u) & ~1u;
+  WideState S{wsm,         wsm + C,     wsm + 2 * C,        wsm + 3 * C,        wsm + 4 * C,
+              wsm + 7 * C, wsm + 7 * C + Cpad, wsm + 5 * C, wsm + 6 * C,
+              (const uint64_t*)(wsm + mask_at) + (size_t)64 * W8 + W};
+  uint64_t* const holew = (uint64_t*)(wsm + mask_at) + (size_t)64 * W8;
+  uint32_t* const claim = wsm + wide_lds_bytes(C) / 4;
+  uint32_t* const taint = claim + C;
+  uint32_t* const row_off = taint + C;  // n_rows + 1: starts of the PADDED rows, in groups of eight ids
+  // (16-byte aligned: a row is read eight 16-bit class ids at a time)
+  uint16_t* const row_cls = (uint16_t*)(((uintptr_t)(row_off + n_rows + 1) + 15) & ~(uintptr_t)15);
+  // claim / taint entries are (0xFFFFFF - iteration) << 6 | lane: an atomic min prefers the
+  // current iteration's marks to any older one and the lowest lane among them — nothing is wiped.
+  for (uint32_t c = lane; c < C; c += 64) claim[c] = taint[c] = kNone;
+  {
+    // Padded row starts: a wave scan over ceil(len / 8), 64 rows per round.
+    uint32_t carry = 0;
+    for (uint32_t r0 = 0; r0 < n_rows; r0 += 64) {
+      const uint32_t r = r0 + lane;
+      const uint32_t g = r < n_rows ? (wl.off[r + 1] - wl.off[r] + 7) / 8 : 0u;
+      uint32_t incl = g;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if ((int)lane >= d) incl += up;
+      }
+      if (r < n_rows) row_off[r] = carry + incl - g;
+      carry += readlane_u32(incl, 63);
+    }
+    if (lane == 0) row_off[n_rows] = carry;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 8) {  // (a row is at most 64 classes: one lane per padded entry)
+    // padding repeats the row's first class: looked at twice, chosen no differently
+    uint32_t v[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {  // (eight rows' loads in flight)
+      const uint32_t r = min(r0 + u, n_rows - 1);
+      const uint32_t o = wl.off[r], len = wl.off[r + 1] - o;
+      v[u] = len ? wl.cls[o + (lane < len ? lane : 0)] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t r = r0 + u;
+      if (r < n_rows) {
+        const uint32_t padded = (row_off[r + 1] - row_off[r]) * 8;
+        if (lane < padded) row_cls[(size_t)row_off[r] * 8 + lane] = (uint16_t)v[u];
+      }
+    }
+  }
+  // ---- start state (clamped like class_run_init: speculative states may be anything)
+  const ClassState* start = guess + (size_t)k * C;
+  for (uint32_t c = lane; c < C; c += 64) {
+    const ClassState st = start[c];
+    const uint32_t b = L.cls_begin[c], e = L.cls_begin[c + 1];
+    uint32_t cur = st.cursor, lo = st.lo;
+    cur = cur < b ? b : (cur > e ? e : cur);
+    lo = lo < b ? b : (lo > cur ? cur : lo);
+    S.cur[c] = cur;
+    S.lo[c] = lo;
+    S.hlo[c] = st.hown_lo;
+    S.hhi[c] = st.hown_hi;
+    S.end[c] = e;
+    S.hp[c] = cur < e ? list_rank(L, cur) : kNone;
+    S.hg[c] = cur < e ? list_slot(L, cur) : kNone;
+    S.np[c] = cur + 1 < e ? list_rank(L, cur + 1) : kNone;
+    S.ng[c] = cur + 1 < e ? list_slot(L, cur + 1) : kNone;
+  }
+  for (uint32_t c = C + lane; c < Cpad; c += 64) {
+    S.hp[c] = kNone;
+    S.hg[c] = kNone;
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t hole_classes = 0;  // (wave-uniform) classes that have holes
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t c = w * 64 + lane;
+    const uint64_t hb = __ballot(c < C && S.lo[c] < S.cur[c]);
+    const uint64_t sb = __ballot(c < C && L.cls_single && L.cls_single[c] != 0);
+    hole_classes += (uint32_t)__popcll(hb);
+    if (lane == 0) {
+      holew[w] = hb;
+      holew[W + w] = sb;  // (== S.singlew[w])
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // One fetch of "the entry after next" in flight per lane (issued when the lane commits, stored
+  // right before the next commit or general step can need it: scans read heads only).
+  uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
+  bool pend_on = false;
+  auto flush = [&]() {
+    if (pend_on) {
+      S.np[pend_c] = pend_p;
+      S.ng[pend_c] = pend_g;
+      pend_on = false;
+    }
+  };
+  uint32_t epoch = 0xFFFFFFu;  // counts down, one per iteration (a batch has far fewer than 2^24)
+  // The block's request columns are fetched a block ahead.
+  uint32_t nx_slo = kNone, nx_shi = kNone, nx_row = kNone;
+  {
+    const uint32_t t = k * chunk_size + lane;
+    if (t < min(n_tasks, (k + 1) * chunk_size)) {
+      nx_slo = T.self_lo[t];
+      nx_shi = T.self_hi[t];
+      nx_row = wl.row_of[t];
+    }
+  }
+  for (;;) {  // chunk k and every chunk behind it
+    const uint32_t t0 = k * chunk_size, t1 = min(n_tasks, t0 + chunk_size);
+    for (uint32_t tb = t0; tb < t1; tb += 64) {
+      const uint32_t t = tb + lane;
+      const bool valid = t < t1;
+      const uint32_t slo = nx_slo, shi = nx_shi, r = nx_row;
+      {
+        // (the next block: of this chunk, or the first of the next one)
+        uint32_t tn = tb + 64 + lane, tn_end = t1;
+        if (tb + 64 >= t1) {
+          tn = (k + 1) * chunk_size + lane;
+          tn_end = min(n_tasks, (k + 2) * chunk_size);
+        }
+        const bool vn = tn < tn_end && tn < n_tasks;
+        nx_slo = vn ? T.self_lo[tn] : kNone;
+        nx_shi = vn ? T.self_hi[tn] : kNone;
+        nx_row = vn ? wl.row_of[tn] : kNone;
+      }
+      // The row: n groups of eight class ids, unpacked into registers for the block (a lone wave
+      // is bound by the instructions it issues — ~4.5 cycles each —, not by the LDS: every scan
+      // of every iteration walks these 8 n ids, so they are unpacked once, not per scan).
+      uint32_t n = 0;
+      uint32_t cid[64];
+      if (valid && r != kNone) {
+        const uint32_t o = row_off[r];
+        n = row_off[r + 1] - o;
+        const uint4* row = (const uint4*)row_cls + o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint4 q = (uint32_t)j < n ? row[j] : make_uint4(0, 0, 0, 0);
+          cid[8 * j + 0] = q.x & 0xFFFFu;
+          cid[8 * j + 1] = q.x >> 16;
+          cid[8 * j + 2] = q.y & 0xFFFFu;
+          cid[8 * j + 3] = q.y >> 16;
+          cid[8 * j + 4] = q.z & 0xFFFFu;
+          cid[8 * j + 5] = q.z >> 16;
+          cid[8 * j + 6] = q.w & 0xFFFFu;
+          cid[8 * j + 7] = q.w >> 16;
+        }
+      }
+      bool pending = valid;
+      if (valid && n == 0) {
+        slot_of[t] = kIdxEnvNotFound;  // task_dispatcher.cc:105-108
+        pending = false;
+      }
+      // Does a class of this lane's row have holes? Looked up once per block (and again after a
+      // general step: only those change holes) instead of with every scan.
+      auto row_has_holes = [&]() {
+        bool h = false;
+        if (hole_classes) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if ((uint32_t)j < n) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const uint32_t c = cid[8 * j + u];
+                h |= ((holew[c >> 6] >> (c & 63u)) & 1u) != 0;
+              }
+            }
+          }
+        }
+        return h;
+      };
+      bool my_holes = pending && row_has_holes();
+      for (;;) {
+        const uint64_t pend_mask = __ballot(pending);
+        if (!pend_mask) break;
+        --epoch;
+        const uint32_t tag = epoch << 6;
+        // ---- every unresolved lane: the lowest-ranked head among the classes of its row
+        uint32_t best = kNone, bc = 0;
+        bool gen = false;
+        if (pending) {
+          gen = shi == kSelfShared || my_holes;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if ((uint32_t)j < n) {
+              uint32_t hp[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) hp[u] = S.hp[cid[8 * j + u]];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                if (hp[u] < best) {
+                  best = hp[u];
+                  bc = cid[8 * j + u];
+                }
+              }
+            }
+          }
+          // From a servant's host: only its own servant at the head of the WINNING class matters —
+          // at the head of any other class of the row it would be stepped over to a higher-ranked
+          // entry, which cannot beat the winner (whose head is below that class's head already).
+          if (slo != kNone && best != kNone && S.hg[bc] - slo < shi - slo) gen = true;
+          if (best == kNone && slo != kNone) gen = true;  // nothing left but perhaps its own servant (:392-396)
+        }
+        const uint64_t gen_mask = __ballot(pending && gen);
+        const uint32_t first_gen = gen_mask ? (uint32_t)__builtin_ctzll(gen_mask) : 64u;
+        if (first_gen == (uint32_t)__builtin_ctzll(pend_mask)) {
+          // The request that needs the state machine is the next one in sequence: the whole wave.
+          const uint32_t tg = tb + first_gen;
+          const uint32_t g_lo = readlane_u32(slo, first_gen), g_hi = readlane_u32(shi, first_gen);
+          flush();
+          __builtin_amdgcn_wave_barrier();
+          wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane);
+          __builtin_amdgcn_wave_barrier();
+          hole_classes = 0;
+          for (uint32_t w = 0; w < W; ++w) hole_classes += (uint32_t)__popcll(holew[w]);
+          if (lane == first_gen) pending = false;
+          my_holes = pending && row_has_holes();
+          continue;
+        }
+        bool cand = pending && lane < first_gen;
+        if (cand && best == kNone) {
+          slot_of[t] = kIdxTimeout;  // :116-118 with timeout == now; classes only lose entries: final
+          pending = false;
+          cand = false;
+        }
+        if (cand) atomicMin(&claim[bc], tag | lane);
+        __builtin_amdgcn_wave_barrier();
+        const bool loser = cand && claim[bc] != (tag | lane);
+        bool blocked = false, mark = loser;
+        for (;;) {
+          if (mark) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if ((uint32_t)j < n) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) atomicMin(&taint[cid[8 * j + u]], tag | lane);
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // (a mark of this iteration from a lower lane: the tag matches and the value is smaller)
+          mark = cand && !loser && !blocked && taint[bc] < (tag | lane);
+          if (!__ballot(mark)) break;
+          blocked |= mark;
+        }
+        flush();  // (issued an iteration ago: the scan and the marking ran in its shadow)
+        __builtin_amdgcn_wave_barrier();
+        if (cand && !loser && !blocked) {
+          // ---- commit: the head of class bc is this request's slot; no holes on this path
+          slot_of[t] = S.hg[bc];
+          const uint32_t cur = S.cur[bc] + 1;
+          S.cur[bc] = cur;
+          S.lo[bc] = cur;
+          S.hp[bc] = S.np[bc];
+          S.hg[bc] = S.ng[bc];
+          if (cur + 1 < S.end[bc]) {
+            pend_c = bc;
+            pend_p = list_rank(L, cur + 1);
+            pend_g = list_slot(L, cur + 1);
+            pend_on = true;
+          } else {
+            S.np[bc] = kNone;
+            S.ng[bc] = kNone;
+          }
+          pending = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    const bool more = k + 1 < n_chunks;
+    if (!whole_batch || !more) {
+      // (walking the whole batch from its first request, nobody reads the states in between)
+      flush();
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = lane; c < C; c += 64) {
+        ClassState s;
+        s.cursor = S.cur[c];
+        s.lo = S.lo[c];
+        const bool holes = s.lo < s.cursor;
+        s.hown_lo = holes ? S.hlo[c] : kNone;
+        s.hown_hi = holes ? S.hhi[c] : kNone;
+        endst[(size_t)k * C + c] = s;
+        if (more) guess[(size_t)(k + 1) * C + c] = s;  // (what chunk k + 1 is replayed from, right now)
+      }
+    }
+    if (lane == 0) {
+      dirty[k] = 0;
+      atomicAdd(&prm->chunk_sims, 1u);
+    }
+    if (!more) break;
+    ++k;
+  }
 }
 
 }  // namespace ydc

@@ -276,6 +276,7 @@ struct ydc_context {
   // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
   uint32_t opt_ring_total = 0;  // entries of a matching wave's rings; 0: chosen per batch (YDC_RING_TOTAL)
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
+  bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
   bool opt_split_gen = false;  // slot generation and request classification as two launches (YDC_SPLIT_GEN=1)
@@ -662,6 +663,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = getenv("YDC_SPLIT_GEN")) c->opt_split_gen = atoi(s) != 0;
   if (const char* s = getenv("YDC_XCD_TILES")) c->opt_xcd = (uint32_t)atoi(s);
   if (const char* s = getenv("YDC_TILE_TAB")) c->opt_tile_tab = atoi(s) != 0;
+  if (const char* s = getenv("YDC_GROUP_WALK")) c->opt_group_walk = atoi(s) != 0;
   if (const char* s = getenv("YDC_CLASSIFY_PER_THREAD")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
@@ -1749,9 +1751,32 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
       if (wide)  // (above 64 KB of dynamic LDS the runtime wants to be told)
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_sim_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)std::max(wide_lds_bytes(kMaxWideClasses), wide_lds_bytes(kMaxWalkPrefetchClasses, true))));
+      // The walk in groups of 64 requests (k_walk_groups) where the registry has eligible-class
+      // lists and they fit the LDS beside the class states (YDC_GROUP_WALK=0: the lone walker).
+      const uint32_t n_rows = p.wide_lists ? (uint32_t)c->tables.elig_off.size() - 1 : 0;
+      const uint32_t n_list = p.wide_lists ? (uint32_t)c->tables.elig_cls.size() : 0;
+      const bool group_walk = wide && p.wide_lists && c->opt_group_walk && p.C <= 65535 &&
+                              group_walk_lds_bytes(p.C, n_rows, n_list) <= kGroupWalkMaxLds;
+      if (group_walk)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_walk_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kGroupWalkMaxLds));
       uint32_t last_changed = 0xFFFFFFFFu;
       bool walked = false;
-      for (;;) {
+      if (group_walk) {
+        // Sparse eligibility (eligible-class lists): no level to guess from, so no rounds of
+        // speculation at all — the batch is walked from its first request, 64 requests at a time
+        // (chunk 0's start state is the true one, k_guess_init; every chunk is still marked).
+        YDC_LAUNCH(c, "k_walk_groups", k_walk_groups, dim3(1), dim3(64),
+                   group_walk_lds_bytes(p.C, n_rows, n_list), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
+                   c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
+                   WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u);
+        ++rounds;
+        HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (c->h_prm->overflow)
+          return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
+      }
+      for (; !group_walk;) {
         for (uint32_t b = 0; b < c->opt_rounds_per_check; ++b) {
           ClassState* gold = c->d_guess[0].p;
           if (wide) {
