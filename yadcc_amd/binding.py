@@ -165,6 +165,34 @@ def _ptr(a):
     return a.data_ptr()  # anything torch-like
 
 
+# The library reads ONE developer variable, YDC_TUNE="key=value,...". The tests and measurement
+# scripts of this repository name their switches YDC_<KEY>=<value>: compose_tune() folds those
+# into YDC_TUNE right before a context is created (and takes out again what it folded in last
+# time, so that a switch a test has dropped is gone). Not an interface of the package.
+_TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GUESS", "PAIR", "RING_TOTAL",
+              "DENSE", "SPLIT_GEN", "XCD_TILES", "TILE_TAB", "GROUP_WALK", "CLASSIFY_PER_THREAD",
+              "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
+              "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
+              "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
+              "ROUNDS_PER_CHECK", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+_tune_injected = ""
+
+
+def compose_tune():
+    global _tune_injected
+    cur = os.environ.get("YDC_TUNE", "")
+    if _tune_injected and cur.endswith(_tune_injected):
+        cur = cur[:len(cur) - len(_tune_injected)].rstrip(",")
+    mine = ",".join("%s=%s" % (k.lower(), os.environ["YDC_" + k]) for k in _TUNE_KEYS
+                    if "YDC_" + k in os.environ)
+    _tune_injected = mine
+    both = ",".join(x for x in (cur, mine) if x)
+    if both:
+        os.environ["YDC_TUNE"] = both
+    else:
+        os.environ.pop("YDC_TUNE", None)
+
+
 def device_count():
     """GPUs visible to the library's HIP runtime (0 when the library is missing)."""
     try:
@@ -270,6 +298,7 @@ class Context:
 
     def __init__(self, device=0, max_servants=0, max_tasks=0, max_slots=0, stream=None):
         h = C.c_void_p()
+        compose_tune()
         rc = lib().ydc_create(device, max_servants, max_tasks, max_slots, stream, C.byref(h))
         if rc:
             raise YdcError("ydc_create: %s (%s)" % (lib().ydc_strerror(rc).decode(),

@@ -384,6 +384,28 @@ void* pinned_device_pointer(const void* p, size_t bytes) {
   return nullptr;
 }
 
+// Developer / test switchboard: ONE environment variable, YDC_TUNE="key=value,key=value", read
+// when a context is created. It forces code paths the planner would not choose on its own (the
+// parity tests cover the fallbacks with it: chunk and ring sizes, the radix pipeline on a
+// registry the bin sort would take, the lone walker, ...) and splits launches for measurements.
+// Not an interface: a scheduler never sets it, and nothing in it changes a placement.
+const char* tune_value(const char* key) {
+  static thread_local std::string value;
+  const char* all = getenv("YDC_TUNE");
+  if (!all) return nullptr;
+  const size_t klen = std::strlen(key);
+  for (const char* p = all; *p;) {
+    const char* end = std::strchr(p, ',');
+    const size_t len = end ? (size_t)(end - p) : std::strlen(p);
+    if (len > klen && p[klen] == '=' && std::strncmp(p, key, klen) == 0) {
+      value.assign(p + klen + 1, len - klen - 1);
+      return value.c_str();
+    }
+    p += len + (end ? 1 : 0);
+  }
+  return nullptr;
+}
+
 int fail(ydc_context* ctx, int code, const char* fmt, ...) {
   if (ctx) {
     char buf[512];
@@ -652,37 +674,37 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
       return YDC_ERR_HIP;
     }
   }
-  if (const char* s = getenv("YDC_DEBUG_SIM")) c->debug_sim = atoi(s) != 0;
-  if (const char* s = getenv("YDC_CHUNK_SIZE")) c->opt_chunk_size = (uint32_t)atoi(s);
-  if (const char* s = getenv("YDC_TARGET_CHUNKS")) c->opt_target_chunks = (uint32_t)atoi(s);
-  if (const char* s = getenv("YDC_FUSED_CLASS")) c->opt_fused_class = atoi(s) != 0;
-  if (const char* s = getenv("YDC_OWN_GUESS")) c->opt_own_guess = atoi(s) != 0;
-  if (const char* s = getenv("YDC_PAIR")) c->opt_pair = atoi(s) != 0;
-  if (const char* s = getenv("YDC_RING_TOTAL")) c->opt_ring_total = std::max(256u, (uint32_t)atoi(s));
-  if (const char* s = getenv("YDC_DENSE")) c->opt_dense = atoi(s) != 0;
-  if (const char* s = getenv("YDC_SPLIT_GEN")) c->opt_split_gen = atoi(s) != 0;
-  if (const char* s = getenv("YDC_XCD_TILES")) c->opt_xcd = (uint32_t)atoi(s);
-  if (const char* s = getenv("YDC_TILE_TAB")) c->opt_tile_tab = atoi(s) != 0;
-  if (const char* s = getenv("YDC_GROUP_WALK")) c->opt_group_walk = atoi(s) != 0;
-  if (const char* s = getenv("YDC_CLASSIFY_PER_THREAD")) c->opt_classify_multi = atoi(s) != 1;
-  if (const char* s = getenv("YDC_PACKED_CLASS")) c->opt_packed_class = atoi(s) != 0;
-  if (const char* s = getenv("YDC_SHARD_SORT")) c->opt_shard_sort = atoi(s) != 0;
-  if (const char* s = getenv("YDC_PACKED_SORT")) c->opt_packed_sort = atoi(s) != 0;
-  if (const char* s = getenv("YDC_BINSORT")) c->opt_binsort = atoi(s) != 0;
-  if (const char* s = getenv("YDC_FUSE_PASSES")) c->opt_fuse_passes = atoi(s) != 0;
-  if (const char* s = getenv("YDC_WARM_UP")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
-  if (const char* s = getenv("YDC_HAND_TRIES")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
-  if (const char* s = getenv("YDC_LEVEL_TAB")) c->opt_level_tab = atoi(s) != 0;
-  if (const char* s = getenv("YDC_WIDE")) c->opt_wide = atoi(s) != 0;
-  if (const char* s = getenv("YDC_WALK_PREFETCH")) c->opt_walk_prefetch = atoi(s) != 0;
-  if (const char* s = getenv("YDC_WIDE_LISTS")) c->opt_wide_lists = atoi(s) != 0;
-  if (const char* s = getenv("YDC_GROUP_BINSORT")) c->opt_group_binsort = atoi(s) != 0;
-  if (const char* s = getenv("YDC_ZERO_COPY")) c->opt_zero_copy = atoi(s) != 0;
-  if (const char* s = getenv("YDC_HOST_IN")) c->opt_host_in_map = std::string(s) != "copy";
-  if (const char* s = getenv("YDC_BINSORT_VERIFY")) c->debug_verify_binsort = atoi(s) != 0;
-  if (const char* s = getenv("YDC_BINSORT_MAX_SLOTS")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
-  if (const char* s = getenv("YDC_SHARD_MARGIN")) c->opt_shard_margin = atoll(s);
-  if (const char* s = getenv("YDC_ROUNDS_PER_CHECK"))
+  if (const char* s = tune_value("debug_sim")) c->debug_sim = atoi(s) != 0;
+  if (const char* s = tune_value("chunk_size")) c->opt_chunk_size = (uint32_t)atoi(s);
+  if (const char* s = tune_value("target_chunks")) c->opt_target_chunks = (uint32_t)atoi(s);
+  if (const char* s = tune_value("fused_class")) c->opt_fused_class = atoi(s) != 0;
+  if (const char* s = tune_value("own_guess")) c->opt_own_guess = atoi(s) != 0;
+  if (const char* s = tune_value("pair")) c->opt_pair = atoi(s) != 0;
+  if (const char* s = tune_value("ring_total")) c->opt_ring_total = std::max(256u, (uint32_t)atoi(s));
+  if (const char* s = tune_value("dense")) c->opt_dense = atoi(s) != 0;
+  if (const char* s = tune_value("split_gen")) c->opt_split_gen = atoi(s) != 0;
+  if (const char* s = tune_value("xcd_tiles")) c->opt_xcd = (uint32_t)atoi(s);
+  if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
+  if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
+  if (const char* s = tune_value("classify_per_thread")) c->opt_classify_multi = atoi(s) != 1;
+  if (const char* s = tune_value("packed_class")) c->opt_packed_class = atoi(s) != 0;
+  if (const char* s = tune_value("shard_sort")) c->opt_shard_sort = atoi(s) != 0;
+  if (const char* s = tune_value("packed_sort")) c->opt_packed_sort = atoi(s) != 0;
+  if (const char* s = tune_value("binsort")) c->opt_binsort = atoi(s) != 0;
+  if (const char* s = tune_value("fuse_passes")) c->opt_fuse_passes = atoi(s) != 0;
+  if (const char* s = tune_value("warm_up")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
+  if (const char* s = tune_value("hand_tries")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
+  if (const char* s = tune_value("level_tab")) c->opt_level_tab = atoi(s) != 0;
+  if (const char* s = tune_value("wide")) c->opt_wide = atoi(s) != 0;
+  if (const char* s = tune_value("walk_prefetch")) c->opt_walk_prefetch = atoi(s) != 0;
+  if (const char* s = tune_value("wide_lists")) c->opt_wide_lists = atoi(s) != 0;
+  if (const char* s = tune_value("group_binsort")) c->opt_group_binsort = atoi(s) != 0;
+  if (const char* s = tune_value("zero_copy")) c->opt_zero_copy = atoi(s) != 0;
+  if (const char* s = tune_value("host_in")) c->opt_host_in_map = std::string(s) != "copy";
+  if (const char* s = tune_value("binsort_verify")) c->debug_verify_binsort = atoi(s) != 0;
+  if (const char* s = tune_value("binsort_max_slots")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
+  if (const char* s = tune_value("shard_margin")) c->opt_shard_margin = atoll(s);
+  if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
   return YDC_OK;
@@ -1022,7 +1044,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
   // Sort tiles: 256 threads x `items` elements; fewer elements per thread while that still
   // leaves the chip short of workgroups (the passes are latency-bound at this size).
   p.sort_items = p.slot_bound <= 300000 ? 2 : (p.slot_bound <= 700000 ? 4 : 8);
-  if (const char* e = getenv("YDC_SORT_ITEMS")) p.sort_items = std::min(8, std::max(1, atoi(e)));
+  if (const char* e = tune_value("sort_items")) p.sort_items = std::min(8, std::max(1, atoi(e)));
   p.n_tiles = std::max<uint32_t>(1, ceil_div(p.slot_bound, kSortThreads * p.sort_items));
   p.any_shared = c->tables.any_shared_ip;
   p.use_generic = p.C > kMaxWaveClasses;
@@ -2415,8 +2437,8 @@ int ydc_group_ipc_export(ydc_context* c, int rank, int n_ranks, void* out_handle
   // Slots of 64 KB of payload (a configs[3] registry's slot deltas: 16k servants x 4 B) unless
   // tuned; two sets of n_ranks slots of 8-byte granules.
   uint32_t slot_words = 16384;
-  if (const char* e = getenv("YDC_IPC_SLOT_WORDS")) slot_words = (uint32_t)std::max(64, atoi(e));
-  if (const char* e = getenv("YDC_IPC_TIMEOUT_MS"))
+  if (const char* e = tune_value("ipc_slot_words")) slot_words = (uint32_t)std::max(64, atoi(e));
+  if (const char* e = tune_value("ipc_timeout_ms"))
     b.timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ull;  // 100 MHz wall clock
   b.slot_words = slot_words;
   b.bytes = (size_t)2 * n_ranks * slot_words * 8;
@@ -2432,7 +2454,7 @@ int ydc_group_ipc_export(ydc_context* c, int rank, int n_ranks, void* out_handle
   // Device flavour: fine-grained device memory where the runtime exports it (peer writes have to
   // be visible to a kernel that is running — across devices that takes fine-grained memory), plain
   // device memory otherwise (enough between processes that share one device).
-  const char* coarse = getenv("YDC_IPC_COARSE");
+  const char* coarse = tune_value("ipc_coarse");
   if (!(coarse && atoi(coarse))) {
     if (hipExtMallocWithFlags(&b.own_dev, b.bytes, hipDeviceMallocFinegrained) == hipSuccess) {
       if (hipIpcGetMemHandle(&b.handle, b.own_dev) == hipSuccess) {

@@ -98,6 +98,7 @@ class GpuTaskDispatcher:
     def __init__(self, device=0, min_memory=None, start_timer=False, fake_clock=True):
         self._L = self._load()
         h = C.c_void_p()
+        binding.compose_tune()
         rc = self._L.ydc_td_create(device, min_memory.encode() if min_memory else None,
                                   int(start_timer), int(fake_clock), C.byref(h))
         if rc:
