@@ -286,14 +286,109 @@ __device__ __forceinline__ void servant_scan_block(const ServantTable& sv, uint3
                       tile_first, prm, my_last, carry, last_with_slots, cls_cnt);
 }
 
+
+// The same scan as SEVERAL workgroups, one per slab of 1024 servants (cfg3: 8, cfg4: 16), none of
+// which waits for another: workgroup b adds up the slot counts of the servants BEFORE its slab
+// itself (closed forms: b rounds of independent column loads, no barrier between them — the
+// trick of k_front_bins' slot tiles) and scans its own slab once. The last workgroup has then
+// seen every servant: it also counts per class and does what follows the scan. The slab loop of
+// one workgroup paid a block scan and two barriers per slab with one round trip in flight
+// (cfg4: 24 us); a run of consecutive servants per thread (one scan, strided loads) took 56.
+__device__ __forceinline__ void servant_scan_multi(const ServantTable& sv, uint32_t n_classes,
+                                                   uint32_t max_slots, uint32_t* slot_base,
+                                                   uint32_t* cls_begin, uint32_t* chunk_consuming,
+                                                   uint32_t n_chunks, const PartTable& parts,
+                                                   uint32_t tile_size, uint32_t* tile_first,
+                                                   DeviceParams* prm) {
+  const bool last = blockIdx.x + 1 == gridDim.x;
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t carry, last_with_slots;
+  extern __shared__ uint32_t cls_cnt[];  // n_classes + 1
+  for (uint32_t c = threadIdx.x; c <= n_classes; c += blockDim.x) cls_cnt[c] = 0;
+  if (threadIdx.x == 0) {
+    carry = 0;
+    last_with_slots = 0;
+  }
+  // Per-batch reset of the request-side counters (saves a memset launch): a stripe per workgroup.
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_chunks * parts.n_parts;
+       k += gridDim.x * blockDim.x)
+    chunk_consuming[k] = 0;
+  __syncthreads();
+  const uint32_t slab0 = blockIdx.x * blockDim.x;
+  uint32_t before = 0, my_last = 0;
+  for (uint32_t s0 = threadIdx.x; s0 < slab0; s0 += 4 * blockDim.x) {
+    uint32_t cls[4], nproc[4], load[4], mt[4], run[4], fl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // (four rows per thread in flight; s < slab0 <= sv.n)
+      const uint32_t s = min(s0 + u * blockDim.x, slab0 - 1);
+      cls[u] = sv.class_of[s];
+      nproc[u] = sv.nproc[s];
+      load[u] = sv.load[s];
+      mt[u] = sv.max_tasks[s];
+      run[u] = sv.running[s];
+      fl[u] = sv.flags[s];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t s = s0 + u * blockDim.x;
+      if (s >= slab0 || cls[u] == kNone) continue;
+      const uint32_t k = servant_slot_count(nproc[u], load[u], mt[u], run[u], fl[u]);
+      before += k;
+      if (last && k) {
+        atomicAdd(&cls_cnt[cls[u]], k);
+        my_last = max(my_last, s);
+      }
+    }
+  }
+  // the slab's own servants
+  const uint32_t s = slab0 + threadIdx.x;
+  uint32_t cls = kNone, k = 0;
+  if (s < sv.n) {
+    cls = sv.class_of[s];
+    if (cls != kNone) k = servant_slot_count(sv.nproc[s], sv.load[s], sv.max_tasks[s], sv.running[s], sv.flags[s]);
+  }
+  {
+    uint32_t v = before;  // one LDS atomic per wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&carry, v);
+  }
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan(k, lds, &total);  // (barriers inside: carry is complete behind it)
+  const uint32_t tile_shift = 31 - (uint32_t)__clz((int)tile_size), tile_mask = tile_size - 1;
+  const uint32_t base = carry + ex;
+  if (s < sv.n) {
+    slot_base[s] = base;
+    if (k) {
+      if (last) atomicAdd(&cls_cnt[cls], k);
+      my_last = s;
+      // tile_first[t] = owner of the first slot of sort tile t: the tiles that start inside this
+      // servant's slots (k_slot_gen would otherwise find it with a dependent binary search).
+      if (tile_first)
+        for (uint32_t t = (base + tile_mask) >> tile_shift; ((uint64_t)t << tile_shift) < (uint64_t)base + k; ++t)
+          tile_first[t] = s;
+    }
+  }
+  if (!last) return;
+  __syncthreads();
+  if (threadIdx.x == 0) carry += total;
+  __syncthreads();
+  servant_scan_finish(sv, n_classes, max_slots, slot_base, cls_begin, parts, tile_shift, tile_mask,
+                      tile_first, prm, my_last, carry, last_with_slots, cls_cnt);
+}
+
 __global__ __launch_bounds__(1024) void k_servant_scan(ServantTable sv, uint32_t n_classes,
                                                        uint32_t max_slots, uint32_t* slot_base,
                                                        uint32_t* cls_begin, uint32_t* chunk_consuming,
                                                        uint32_t n_chunks, PartTable parts,
                                                        uint32_t tile_size, uint32_t* tile_first,
                                                        DeviceParams* prm) {
-  servant_scan_block(sv, n_classes, max_slots, slot_base, cls_begin, chunk_consuming, n_chunks, parts,
-                     tile_size, tile_first, prm);
+  if (gridDim.x > 1)
+    servant_scan_multi(sv, n_classes, max_slots, slot_base, cls_begin, chunk_consuming, n_chunks, parts,
+                       tile_size, tile_first, prm);
+  else
+    servant_scan_block(sv, n_classes, max_slots, slot_base, cls_begin, chunk_consuming, n_chunks, parts,
+                       tile_size, tile_first, prm);
 }
 
 // ---------------------------------------------------------------------------

@@ -276,6 +276,7 @@ struct ydc_context {
   // chunks) were measured and bring nothing: the waves saturate VALU issue at ~2 per SIMD.
   uint32_t opt_ring_total = 0;  // entries of a matching wave's rings; 0: chosen per batch (YDC_RING_TOTAL)
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
+  bool opt_scan_multi = true;  // (scan_multi=0: one workgroup loops over the slabs)
   bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
@@ -686,6 +687,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("xcd_tiles")) c->opt_xcd = (uint32_t)atoi(s);
   if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
   if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
+  if (const char* s = tune_value("scan_multi")) c->opt_scan_multi = atoi(s) != 0;
   if (const char* s = tune_value("classify_per_thread")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = tune_value("packed_class")) c->opt_packed_class = atoi(s) != 0;
   if (const char* s = tune_value("shard_sort")) c->opt_shard_sort = atoi(s) != 0;
@@ -1284,7 +1286,9 @@ void enqueue_scan(ydc_context* c, const BatchPlan& p, uint32_t* cls_begin) {
     mark(c, 1);
     return;
   }
-  YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(1), dim3(1024), (p.C + 1) * sizeof(uint32_t),
+  // (one workgroup per slab of 1024 servants from 4k servants on: kernels.h, servant_scan_multi)
+  const uint32_t scan_blocks = p.S > 4096 && c->opt_scan_multi ? ceil_div(p.S, 1024) : 1u;
+  YDC_LAUNCH(c, "k_servant_scan", k_servant_scan, dim3(scan_blocks), dim3(1024), (p.C + 1) * sizeof(uint32_t),
              c->stream, p.sv, p.C, p.slot_bound_glob, c->d_slot_base.p, cls_begin,
              c->d_chunk_consuming.p, p.K, PartTable{c->d_cls_comp.p, c->n_parts, c->d_part_base.p},
              kSortThreads * p.sort_items, p.win ? nullptr : c->d_tile_first.p, c->d_prm.p);
