@@ -852,6 +852,10 @@ struct SortIn {
   uint32_t packed;        // input is records
   uint32_t key_is_index;  // first class pass: the key is the element's index (its global rank)
   uint32_t xcd_hist, xcd_scatter;  // XCD-contiguous tile order in the histogram / scatter launch
+  // Measurement only (tests/tools/scatter_probe.hip; 0 in the library): 1 = the scatter's stores go
+  // to the element's own place (coalesced), 2 = no gather of the tile's histogram column, 4 = no
+  // stores at all.
+  uint32_t dbg;
 };
 
 template <typename KeyT>
@@ -956,6 +960,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t n_tiles, uint32_t* 
 // an element among equal digits is: digit start + earlier tiles (scanned hist) +
 // earlier waves + earlier rounds of this wave + lower lanes with the same digit
 // (wave ballot match) — no atomics, deterministic, stable.
+// (65 VGPRs = seven waves per SIMD; forced to 64 it spills 26 of them: cfg4's four passes 145 -> 185 us)
 template <typename KeyT, typename OutKeyT>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     SortIn<KeyT> in, const DeviceParams* prm, uint32_t n_tiles, const uint32_t* hist,
@@ -981,7 +986,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     uint32_t total;
     uint32_t acc = block_exclusive_scan(sum, lds, &total);
     for (uint32_t d = d0; d < d1; ++d) {
-      dstart[d] = acc + hist[d * n_tiles + tile];
+      dstart[d] = acc + ((in.dbg & 2) ? 0u : hist[d * n_tiles + tile]);
       acc += row_total[d];
     }
     for (uint32_t d = threadIdx.x; d < kSortWaves * radix; d += kSortThreads) cnt[d] = 0;
@@ -991,17 +996,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
   uint32_t val[kSortItems], dig[kSortItems], rank[kSortItems];
   const uint64_t lt_mask = (1ull << lane) - 1;
   uint32_t* wcnt = cnt + wave * radix;
+  // All loads first (clamped, unconditional): eight round trips in flight together instead of
+  // one behind the other, each in front of its ranking step (tests/tools/scatter_probe.hip: the
+  // pass without its stores took 25 us of 44 for 5M records — eight dependent memory latencies).
+  const uint32_t rank_off = prm->rank_offset;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = min(base + wave * wave_span + j * 64 + lane, M - 1);
+    sort_load(in, i, rank_off, true, key[j], val[j]);
+  }
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = base + wave * wave_span + j * 64 + lane;
     const bool valid = (uint32_t)j < in.items && i < M;
-    key[j] = 0;
-    val[j] = 0;
     uint32_t d = 0;
-    if (valid) {
-      sort_load(in, i, prm->rank_offset, true, key[j], val[j]);
-      d = sort_digit(in, i, key[j], val[j]);
-    }
+    if (valid) d = sort_digit(in, i, key[j], val[j]);
     dig[j] = d;
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -1034,6 +1043,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     const uint32_t i = base + wave * wave_span + j * 64 + lane;
     if ((uint32_t)j < in.items && i < M) {
       const uint32_t pos = dstart[dig[j]] + wcnt[dig[j]] + rank[j];
+      if (in.dbg & 4) { if (pos == 0xFFFFFFF0u) sort_store(out_keys, out_vals, in.packed, 0, (OutKeyT)key[j], val[j]); }
+      else if (in.dbg & 1) sort_store(out_keys, out_vals, in.packed, base + wave * wave_span + j * 64 + lane, (OutKeyT)key[j], val[j] & in.out_mask);
+      else
       sort_store(out_keys, out_vals, in.packed, pos, (OutKeyT)key[j], val[j] & in.out_mask);
     }
   }
@@ -1112,17 +1124,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_classed(
   const uint64_t lt_mask = (1ull << lane) - 1;
   uint32_t* wcnt = cnt + wave * radix;
   uint32_t* wkcnt = kcnt + wave * kradix;
+  KeyT keyv[kSortItems];
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {  // (all loads first, in flight together: see k_radix_scatter)
+    const uint32_t i = min(base + wave * wave_span + j * 64 + lane, M - 1);
+    sort_load(in, i, prm->rank_offset, true, keyv[j], val[j]);
+  }
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = base + wave * wave_span + j * 64 + lane;
     const bool valid = (uint32_t)j < in.items && i < M;
-    val[j] = 0;
     uint32_t d = 0;
-    if (valid) {
-      KeyT key;
-      sort_load(in, i, prm->rank_offset, true, key, val[j]);
-      d = sort_digit(in, i, key, val[j]);
-    }
+    if (valid) d = sort_digit(in, i, keyv[j], val[j]);
     dig[j] = d;
     uint64_t kpeers = __ballot(valid);
 #pragma unroll

@@ -558,6 +558,7 @@ int launch_sort_pass(ydc_context* c, const SortIn<KeyT>& in_, uint32_t n_tiles, 
   SortIn<KeyT> in = in_;
   in.xcd_hist = (c->opt_xcd >> 1) & 1;
   in.xcd_scatter = (c->opt_xcd >> 2) & 1;
+  in.dbg = 0;
   const uint32_t radix = 1u << in.bits;
   if (!have_hist)  // (the first pass's tile histograms come out of k_slot_gen)
     YDC_LAUNCH(c, "k_radix_hist", k_radix_hist<KeyT>, dim3(xcd_grid(n_tiles) + (pa ? 1 : 0)), dim3(kSortThreads),
