@@ -43,12 +43,13 @@ def main():
     F = np.stack(front)
     used = F[0, :, 0] > 0
     n_wg = int(used.sum())
-    n_bins = n_wg - n_req - int(np.ceil(len(sv["version"]) / 8))
+    # (slot tiles first, then the bin boundaries — a power of two, more of them than tiles —, then requests)
+    n_bins = 1 << int(np.floor(np.log2(n_wg - n_req - 1)))
     n_tiles = n_wg - n_bins - n_req
     print("%s: k_front_bins %d workgroups = %d bin boundaries + %d slot tiles + %d request blocks; us after the first workgroup's start"
           % (cfg, n_wg, n_bins, n_tiles, n_req))
     t0 = np.where(F[:, :, 0] > 0, F[:, :, 0], np.iinfo(np.int64).max).min(axis=1)[:, None]
-    for name, lo, hi in (("bin boundaries", 0, n_bins), ("slot tiles", n_bins, n_bins + n_tiles),
+    for name, lo, hi in (("slot tiles", 0, n_tiles), ("bin boundaries", n_tiles, n_bins + n_tiles),
                          ("request blocks", n_bins + n_tiles, n_wg)):
         st = (F[:, lo:hi, 0] - t0) / 100.0
         en = (F[:, lo:hi, 1] - t0) / 100.0

@@ -59,8 +59,14 @@ struct BinTable {
   // [n_tiles * B] the tile's slots of the bin: (offset inside the tile's staging region << 16) |
   // count (a tile holds at most 2048 slots).
   uint32_t* runs;
-  uint32_t group;   // G: servants per slot tile
+  uint32_t group;   // G: servants per slot tile at most (kBinMaxGroup)
   uint32_t n_tiles;
+  // Slot tile t = servants [tile_start[t], tile_start[t + 1]): cut by the host so that every
+  // tile holds about the same number of slots (by the servants' static bound min(max_tasks,
+  // nproc); at most `group` servants and 2048 slots) — the launch lasts as long as its fullest
+  // tile. tile_base[t] = slots of the servants before the tile (written by the tile itself).
+  const uint32_t* tile_start;
+  uint32_t* tile_base;
 };
 
 // Workgroup of boundary j (1 .. B): row j of BinTable::base. With a handful of classes the
@@ -168,7 +174,7 @@ __device__ __forceinline__ void front_bin_boundary(const ServantTable& sv, uint3
   }
 }
 
-// Workgroup of slot tile `tile`: servants [tile * G, tile * G + G).
+// Workgroup of slot tile `tile`: servants [tile_start[tile], tile_start[tile + 1]).
 // Values are (class << gbits) | slot (gbits == 0: one class, the slot alone).
 __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t tile, uint32_t cap_bits,
                                                 uint32_t comp_shift, uint32_t gbits,
@@ -182,7 +188,7 @@ __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t
   uint32_t* wcnt_all = fsm + B;       // [4 waves][B]
   uint32_t* col = fsm + 5 * B;        // [6][G] the tile's servants: class, nproc, load, max_tasks, running, flags
   uint32_t* lbase = col + 6 * G;      // [G + 1] local prefix of their slot counts
-  const uint32_t s0 = tile * G, ns = min(G, sv.n - s0);
+  const uint32_t s0 = bt.tile_start[tile], ns = bt.tile_start[tile + 1] - s0;
   // The tile's own servants (loads issued ahead of the long loop below).
   if (threadIdx.x < ns) {
     const uint32_t s = s0 + threadIdx.x;
@@ -232,6 +238,7 @@ __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t
   // (a registry that overflows the workspace fails the batch: generate nothing)
   const uint32_t total = (uint64_t)base + lbase[ns] <= max_slots ? lbase[ns] : 0u;
   if (threadIdx.x < ns) slot_base[s0 + threadIdx.x] = base + lbase[threadIdx.x];
+  if (threadIdx.x == 0) bt.tile_base[tile] = base;
   uint32_t bbits = 0;
   while ((1u << bbits) < B) ++bbits;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -316,7 +323,7 @@ __device__ __forceinline__ void front_slot_tile(const ServantTable& sv, uint32_t
   }
 }
 
-// Workgroups [0, B): bin boundaries 1 .. B; [B, B + n_tiles): slot tiles; the rest: requests.
+// Workgroups [0, n_tiles): slot tiles; [n_tiles, n_tiles + B): bin boundaries 1 .. B; the rest: requests.
 __global__ __launch_bounds__(256) void k_front_bins(ServantTable sv, uint32_t n_classes, uint32_t max_slots,
                                                     uint32_t* slot_base, uint32_t* cls_begin,
                                                     PartTable parts, DeviceParams* prm, uint32_t cap_bits,
@@ -332,12 +339,15 @@ __global__ __launch_bounds__(256) void k_front_bins(ServantTable sv, uint32_t n_
     }
   } probe_end{blk};
 #endif
-  if (blk < bt.n_bins) {
-    front_bin_boundary(sv, n_classes, parts, cap_bits, comp_shift, bt, blk + 1, max_slots, slot_base,
-                       cls_begin, prm);
+  // Longest first: a launch of ~1200 workgroups takes ~6 us to hand them all out (in index
+  // order), and a slot tile works for ~8 us, a bin boundary for ~6, a request block for ~3 —
+  // the tiles used to start behind the 512 boundaries and ended the launch at 14.5 us.
+  if (blk < bt.n_tiles) {
+    front_slot_tile(sv, blk, cap_bits, comp_shift, gbits, parts.cls_comp, parts.n_parts, bt, max_slots,
+                    slot_base, owner, stage);
   } else if (blk < bt.n_bins + bt.n_tiles) {
-    front_slot_tile(sv, blk - bt.n_bins, cap_bits, comp_shift, gbits, parts.cls_comp, parts.n_parts,
-                    bt, max_slots, slot_base, owner, stage);
+    front_bin_boundary(sv, n_classes, parts, cap_bits, comp_shift, bt, blk - bt.n_tiles + 1, max_slots,
+                       slot_base, cls_begin, prm);
   } else {
     task_classify_block(ca, blk - bt.n_bins - bt.n_tiles, prm);
   }
@@ -411,11 +421,11 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_sort(BinSortArgs a, Devi
   const uint32_t t0 = 2 * threadIdx.x;
   if (t0 < T) {
     r0 = a.bt.runs[(size_t)t0 * a.bt.n_bins + j];
-    b0 = a.slot_base[t0 * a.bt.group];
+    b0 = a.bt.tile_base[t0];
   }
   if (t0 + 1 < T) {
     r1 = a.bt.runs[(size_t)(t0 + 1) * a.bt.n_bins + j];
-    b1 = a.slot_base[(t0 + 1) * a.bt.group];
+    b1 = a.bt.tile_base[t0 + 1];
   }
   if (n == 0 || prm->n_slots == 0) return;
   if (n > kBinCap) {

@@ -45,6 +45,13 @@ struct HostTables {
   // host and never touch the table.
   std::vector<uint32_t> ip_filter;
   uint32_t ip_filter_shift = 25;
+  // Slot tiles of the bin sort's front (bin_sort.h): tile t = servants [bin_tile_start[t],
+  // bin_tile_start[t + 1]), cut so that the tiles' slot BOUNDS (min(max_tasks, nproc) of the
+  // servants that take tasks) are about equal: at most kTileSlots of them, at most kTileServants
+  // servants. What a servant really offers in a batch is its bound minus running_tasks and foreign
+  // load, so a tile never holds more than its bound.
+  static constexpr uint32_t kTileSlots = 640, kTileSlotsMax = 2048, kTileServants = 32;
+  std::vector<uint32_t> bin_tile_start;
   // Eligible-class masks by (digest bit, version threshold), for registries with few distinct
   // class versions (and a table of at most 2^20 words): ver_sorted = the distinct class versions ascending,
   // env_ver_mask[(env * (V + 1) + vi) * words + w] = classes advertising digest `env` (one of
@@ -214,6 +221,20 @@ struct HostTables {
       ip_sorted[i] = byip[i].first;
       ip_servant[i] = byip[i].second;
       if (i && byip[i].first == byip[i - 1].first) any_shared_ip = true;
+    }
+    bin_tile_start.assign(1, 0u);
+    {
+      uint32_t in_tile = 0, first = 0;
+      for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t ub = class_of[s] == kNone ? 0u : std::min(max_tasks[s], nproc[s]);
+        if (s > first && (in_tile + ub > kTileSlots || s - first >= kTileServants)) {
+          bin_tile_start.push_back(s);
+          first = s;
+          in_tile = 0;
+        }
+        in_tile += ub;
+      }
+      bin_tile_start.push_back(n);
     }
     uint32_t bits = 4;
     while ((1u << bits) < 2 * n_ip) ++bits;

@@ -122,6 +122,7 @@ struct ydc_context {
   DevBuf<uint32_t> d_version, d_nproc, d_load, d_max_tasks, d_running, d_flags, d_class_of;
   DevBuf<uint32_t> d_spare[6];  // ydc_remove_servants compacts into these, then swaps
   DevBuf<uint32_t> d_ip_hash, d_ip_filter;
+  DevBuf<uint32_t> d_bin_tile_start, d_bin_tile_base;  // slot tiles of the bin sort's front (host_tables.h)
   DevBuf<uint32_t> d_ip_sorted, d_ip_servant, d_cls_ver, d_ver_sorted, d_cls_comp, d_part_base;
   DevBuf<uint64_t> d_cls_env, d_env_ver_mask;
   DevBuf<uint8_t> d_cls_single;
@@ -452,6 +453,10 @@ int rebuild_tables(ydc_context* c) {
   HIP_TRY(c, c->d_ip_hash.reserve(c->tables.ip_hash.size()));
   HIP_TRY(c, hipMemcpyAsync(c->d_ip_hash.p, c->tables.ip_hash.data(), c->tables.ip_hash.size() * 4,
                             hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, c->d_bin_tile_start.reserve(c->tables.bin_tile_start.size()));
+  HIP_TRY(c, c->d_bin_tile_base.reserve(c->tables.bin_tile_start.size()));
+  HIP_TRY(c, hipMemcpyAsync(c->d_bin_tile_start.p, c->tables.bin_tile_start.data(),
+                            c->tables.bin_tile_start.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, c->d_ip_filter.reserve(c->tables.ip_filter.size()));
   HIP_TRY(c, hipMemcpyAsync(c->d_ip_filter.p, c->tables.ip_filter.data(), c->tables.ip_filter.size() * 4,
                             hipMemcpyHostToDevice, c->stream));
@@ -720,7 +725,7 @@ int ydc_destroy(ydc_context* c) {
   stream_release(c);
   group_release(c);
   for (auto* b : {&c->d_version, &c->d_nproc, &c->d_load, &c->d_max_tasks, &c->d_running,
-                  &c->d_flags, &c->d_class_of, &c->d_ip_hash, &c->d_ip_filter, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
+                  &c->d_flags, &c->d_class_of, &c->d_ip_hash, &c->d_ip_filter, &c->d_bin_tile_start, &c->d_bin_tile_base, &c->d_ip_sorted, &c->d_ip_servant, &c->d_cls_ver,
                   &c->d_cls_comp, &c->d_part_base,
                   &c->d_slot_base, &c->d_cls_begin, &c->d_vals[0], &c->d_vals[1], &c->d_hist, &c->d_tile_first,
                   &c->d_row_total, &c->d_self_lo, &c->d_self_hi, &c->d_chunk_consuming,
@@ -1128,8 +1133,10 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     // Slot tiles: G consecutive servants, at most 2048 slots (a servant offers < 2^cap_bits).
     // (Smaller tiles were measured: more workgroups that each add up the servants before them
     // cost more than the fullest tile's shorter loop saves.)
-    p.bin_group = std::min(kBinMaxGroup, std::max(1u, 2048u >> c->kf.cap_bits));
-    p.bin_tiles = ceil_div(p.S, p.bin_group);
+    // Slot tiles: runs of consecutive servants cut by the host to about equal slot bounds
+    // (host_tables.h: bin_tile_start; at most kBinMaxGroup servants and 2048 slots each).
+    p.bin_group = kBinMaxGroup;
+    p.bin_tiles = (uint32_t)c->tables.bin_tile_start.size() - 1;
     if (p.bin_shift + p.bin_slot_bits + p.bin_cls_bits > 32 || p.bin_tiles > kBinMaxTiles) p.binsort = false;
   }
   if (p.binsort) {
@@ -1341,7 +1348,8 @@ void enqueue_gen(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk, boo
   uint16_t* cls_by_g = C > 1 && !p.gbits ? c->d_cls_by_g.p : nullptr;
   if (p.binsort && gen) {
     // Bin boundaries | slot tiles | requests: one launch, no workgroup waits for another.
-    const BinTable bt{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles};
+    const BinTable bt{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles,
+                      c->d_bin_tile_start.p, c->d_bin_tile_base.p};
     const size_t lds_words = std::max<size_t>((size_t)5 * p.n_bins + 7 * p.bin_group + 1, C + 1);
     YDC_LAUNCH(c, "k_front_bins", k_front_bins, dim3(p.n_bins + p.bin_tiles + cls_blocks), dim3(256),
                lds_words * 4, c->stream, p.sv, C, p.slot_bound_glob, c->d_slot_base.p, c->d_cls_begin.p,
@@ -1385,7 +1393,8 @@ int enqueue_sort(ydc_context* c, const BatchPlan& p, bool prefix_pending) {
     // One workgroup per bin (+ one for the chunk prefix): order inside the bins, global ranks,
     // class lists.
     BinSortArgs ba{(const uint2*)c->d_keys[0].p,
-                   BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles},
+                   BinTable{p.n_bins, p.bin_shift, c->d_binbase.p, c->d_binruns.p, p.bin_group, p.bin_tiles,
+                            c->d_bin_tile_start.p, c->d_bin_tile_base.p},
                    p.C, p.gbits, p.bin_slot_bits, p.bin_cls_bits, c->d_slot_base.p, c->d_cls_begin.p,
                    (uint2*)c->d_keys[1].p, c->d_rank_to_g.p,
                    c->opt_level_tab && c->n_parts <= 1 ? c->d_level_tab.p : nullptr};
