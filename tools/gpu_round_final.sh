@@ -7,8 +7,10 @@ O=gpurun_out/final; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 (timeout 1200 python -m pytest tests -m gpu -q --timeout 420 --durations=10 -p no:cacheprovider 2>&1 | tail -25) > $O/pytest.log
 timeout 300 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
-timeout 300 python bench.py --no-pipeline --no-cpu-baseline > $O/bench_cfg2_sync.json 2> $O/bench_cfg2_sync.err
-timeout 300 python bench.py --shared-ip-frac 0.05 --steps 2000 --warmup 100 --no-cpu-baseline > $O/bench_cfg2_shared.json 2> $O/bench_cfg2_shared.err
+( time timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_line.json 2> $O/bench_driver_line.err
+( time timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 ) > $O/bench_gpus2_one_device.json 2> $O/bench_gpus2_one_device.err
+timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-extra-configs > $O/bench_cfg2_sync.json 2> $O/bench_cfg2_sync.err
+timeout 300 python bench.py --shared-ip-frac 0.05 --steps 2000 --warmup 100 --no-cpu-baseline --no-extra-configs > $O/bench_cfg2_shared.json 2> $O/bench_cfg2_shared.err
 timeout 300 python bench.py --config cfg3 --steps 500 --warmup 20 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 timeout 300 python bench.py --config cfg4 --steps 200 --warmup 10 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 timeout 300 python bench.py --config cfg5 --steps 1000 --warmup 50 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
@@ -23,8 +25,12 @@ done
 [ -x build/fastloop_probe ] && timeout 100 build/fastloop_probe > $O/fastloop_probe.txt 2>&1
 timeout 300 bash tools/profile.sh cfg2 > $O/profile_cfg2.log 2>&1
 timeout 400 bash tools/profile.sh cfg3 --config cfg3 > $O/profile_cfg3.log 2>&1
-YDC_PROFILE_PMC=0 timeout 300 bash tools/profile.sh cfg4 --config cfg4 > $O/profile_cfg4.log 2>&1
-(timeout 120 tools/td_native_bench 2>&1 | tail -12) > $O/td_native_bench.log
+timeout 400 bash tools/profile.sh cfg4 --config cfg4 > $O/profile_cfg4.log 2>&1
+{ timeout 120 tools/td_native_bench wait 2000 10000 50; timeout 120 tools/td_native_bench wait 2000 100000 20;
+  timeout 200 tools/td_native_bench heartbeat 16000 1000000 3; timeout 120 tools/td_native_bench heartbeat 2000 100000 5; } > $O/td_native_bench.log 2>&1
+[ -x tests/tools/scatter_probe ] && timeout 100 tests/tools/scatter_probe 5000000 8 8 > $O/scatter_probe.txt 2>&1
+YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 100 python tools/tail_probe.py cfg4 8 > $O/tail_cfg4.txt 2>&1
+YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 100 python tools/front_probe.py > $O/front_cfg2.txt 2>&1
 cat $O/pytest.log
 python - $O <<'PY'
 import json,sys,glob,os
