@@ -607,14 +607,18 @@ def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
     ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    # Per-batch latency (p50 / p99): synchronous calls, one batch in flight.
+    # Per-batch latency (p50 / p99) and the synchronous rate: one batch in flight, a few untimed
+    # calls first (the switch from the pipelined loop, a short run's clocks still settling), at
+    # least n_lat samples whatever --steps is.
     n_lat = 100 if full else 30
     lat = []
-    for _ in range((min(steps, 1000) if full else n_lat) if pipelined else 0):
-        s0 = time.perf_counter()
-        step()
-        lat.append(time.perf_counter() - s0)
     if pipelined:
+        for _ in range(5):
+            step()
+        for _ in range(max(n_lat, min(steps, 1000)) if full else n_lat):
+            s0 = time.perf_counter()
+            step()
+            lat.append(time.perf_counter() - s0)
         step()  # (d_out / d_run hold a synchronous batch's results for the checks below)
     sync_ms = 1e3 * sum(lat) / len(lat) if lat else None
     if not pipelined:
