@@ -81,15 +81,28 @@ struct WideState {
 // request one of whose classes has holes, a host that runs several servants. The whole wave works
 // on the ONE request t (lane l looks at the classes l, l + 64, ... of its mask words); holew's bits
 // follow the classes' holes.
+// row_c: kNone - 1 = "no row": the lanes read the request's classes off its mask words (lane l the
+// classes l, l + 64, ...); else this lane's class of the request's row of eligible classes (kNone:
+// none; rows are ascending and hold a class once) — one class per lane, no loop over the words.
+constexpr uint32_t kNoRow = 0xFFFFFFFEu;
 __device__ __forceinline__ void wide_general_step(const ClassLists& L, const WideState& S, uint64_t* holew,
                                                   uint32_t W, const uint64_t* mask, uint32_t self_lo,
                                                   uint32_t self_hi, const SharedIpTable& shared,
-                                                  uint32_t* __restrict__ slot_of, uint32_t t, uint32_t lane) {
-  uint64_t many = 0;
-  for (uint32_t w = 0; w < W; ++w) many |= mask[w];
-  if (many == 0) {
-    if (lane == 0) slot_of[t] = kIdxEnvNotFound;
-    return;
+                                                  uint32_t* __restrict__ slot_of, uint32_t t, uint32_t lane,
+                                                  uint32_t row_c = kNoRow) {
+  const bool by_row = row_c != kNoRow;
+  if (by_row) {
+    if (__ballot(row_c != kNone) == 0) {
+      if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+      return;
+    }
+  } else {
+    uint64_t many = 0;
+    for (uint32_t w = 0; w < W; ++w) many |= mask[w];
+    if (many == 0) {
+      if (lane == 0) slot_of[t] = kIdxEnvNotFound;
+      return;
+    }
   }
   if (self_hi == kSelfShared) {
     auto state_of = [&](uint32_t c, uint32_t& cursor, uint32_t& lo, uint32_t& hown_lo) {
@@ -100,15 +113,27 @@ __device__ __forceinline__ void wide_general_step(const ClassLists& L, const Wid
     resolve_shared_self(mask, self_lo, &shared, state_of, self_lo, self_hi);
   }
   uint32_t bp = kNone, bi = 0, bg = 0, bc = kNone;
-  for (uint32_t w = 0; w < W; ++w) {
-    if ((mask[w] >> lane) & 1u) {
-      const uint32_t c = w * 64 + lane;
+  if (by_row) {
+    if (row_c != kNone) {
       uint32_t ci, cp, cg;
-      if (class_candidate(L, S.run(L, c), self_lo, self_hi, ci, cp, cg) && cp < bp) {
+      if (class_candidate(L, S.run(L, row_c), self_lo, self_hi, ci, cp, cg)) {
         bp = cp;
         bi = ci;
         bg = cg;
-        bc = c;
+        bc = row_c;
+      }
+    }
+  } else {
+    for (uint32_t w = 0; w < W; ++w) {
+      if ((mask[w] >> lane) & 1u) {
+        const uint32_t c = w * 64 + lane;
+        uint32_t ci, cp, cg;
+        if (class_candidate(L, S.run(L, c), self_lo, self_hi, ci, cp, cg) && cp < bp) {
+          bp = cp;
+          bi = ci;
+          bg = cg;
+          bc = c;
+        }
       }
     }
   }
@@ -117,7 +142,15 @@ __device__ __forceinline__ void wide_general_step(const ClassLists& L, const Wid
   if (mn == kNone) {
     // task_dispatcher.cc:392-396: the requestor's own servant, first eligible class that has it
     uint32_t sc = kNone;
-    if (self_lo != kNone) {
+    if (self_lo != kNone && by_row) {
+      uint32_t ci, cg;
+      if (row_c != kNone && class_self_candidate(L, S.run(L, row_c), self_lo, self_hi, ci, cg)) {
+        sc = row_c;
+        bi = ci;
+        bg = cg;
+        bc = row_c;
+      }
+    } else if (self_lo != kNone) {
       for (uint32_t w = 0; w < W && sc == kNone; ++w) {
         if ((mask[w] >> lane) & 1u) {
           const uint32_t c = w * 64 + lane;
@@ -590,7 +623,8 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
 // ---------------------------------------------------------------------------
 // (rows are padded to multiples of eight classes in LDS — a row is read eight ids at a time)
 __host__ __device__ inline size_t group_walk_lds_bytes(uint32_t C, uint32_t n_rows, uint32_t n_list) {
-  return wide_lds_bytes(C) + (size_t)2 * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32;
+  return wide_lds_bytes(C) + (size_t)2 * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32 +
+         2 * (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
 __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, uint32_t n_tasks,
@@ -621,7 +655,9 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   uint32_t* const taint = claim + C;
   uint32_t* const row_off = taint + C;  // n_rows + 1: starts of the PADDED rows, in groups of eight ids
   // (16-byte aligned: a row is read eight 16-bit class ids at a time)
-  uint16_t* const row_cls = (uint16_t*)(((uintptr_t)(row_off + n_rows + 1) + 15) & ~(uintptr_t)15);
+  uint8_t* const row_len = (uint8_t*)(row_off + n_rows + 1);           // [n_rows] true lengths (<= 64)
+  uint8_t* const row_holes = row_len + ((n_rows + 15) & ~15u);          // [n_rows] 1: a class of the row has holes
+  uint16_t* const row_cls = (uint16_t*)(((uintptr_t)(row_holes + ((n_rows + 15) & ~15u)) + 15) & ~(uintptr_t)15);
   // claim / taint entries are (0xFFFFFF - iteration) << 6 | lane: an atomic min prefers the
   // current iteration's marks to any older one and the lowest lane among them — nothing is wiped.
   for (uint32_t c = lane; c < C; c += 64) claim[c] = taint[c] = kNone;
@@ -637,7 +673,10 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
         if ((int)lane >= d) incl += up;
       }
-      if (r < n_rows) row_off[r] = carry + incl - g;
+      if (r < n_rows) {
+        row_off[r] = carry + incl - g;
+        row_len[r] = (uint8_t)(wl.off[r + 1] - wl.off[r]);
+      }
       carry += readlane_u32(incl, 63);
     }
     if (lane == 0) row_off[n_rows] = carry;
@@ -696,6 +735,20 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     }
   }
   __builtin_amdgcn_wave_barrier();
+  // "A class of the row has holes" per row: what a request needs to know before it may take the
+  // fast path. Recomputed when a general step changes some class's holes (only those do).
+  auto mark_rows_with_holes = [&]() {
+    for (uint32_t r = lane; r < n_rows; r += 64) {
+      bool h = false;
+      if (hole_classes) {
+        const uint16_t* ids = row_cls + (size_t)row_off[r] * 8;
+        for (uint32_t j = 0; j < row_len[r]; ++j) h |= ((holew[ids[j] >> 6] >> (ids[j] & 63u)) & 1u) != 0;
+      }
+      row_holes[r] = h ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  mark_rows_with_holes();
   // One fetch of "the entry after next" in flight per lane (issued when the lane commits, stored
   // right before the next commit or general step can need it: scans read heads only).
   uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
@@ -763,25 +816,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         slot_of[t] = kIdxEnvNotFound;  // task_dispatcher.cc:105-108
         pending = false;
       }
-      // Does a class of this lane's row have holes? Looked up once per block (and again after a
-      // general step: only those change holes) instead of with every scan.
-      auto row_has_holes = [&]() {
-        bool h = false;
-        if (hole_classes) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if ((uint32_t)j < n) {
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const uint32_t c = cid[8 * j + u];
-                h |= ((holew[c >> 6] >> (c & 63u)) & 1u) != 0;
-              }
-            }
-          }
-        }
-        return h;
-      };
-      bool my_holes = pending && row_has_holes();
+      bool my_holes = pending && row_holes[r] != 0;
       for (;;) {
         const uint64_t pend_mask = __ballot(pending);
         if (!pend_mask) break;
@@ -821,12 +856,20 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           const uint32_t g_lo = readlane_u32(slo, first_gen), g_hi = readlane_u32(shi, first_gen);
           flush();
           __builtin_amdgcn_wave_barrier();
-          wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane);
+          // (the request's classes: lane l takes entry l of its row)
+          const uint32_t g_row = readlane_u32(r, first_gen);
+          const uint32_t g_len = row_len[g_row];
+          const uint32_t g_c = lane < g_len ? (uint32_t)row_cls[(size_t)row_off[g_row] * 8 + lane] : kNone;
+          wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane, g_c);
           __builtin_amdgcn_wave_barrier();
-          hole_classes = 0;
-          for (uint32_t w = 0; w < W; ++w) hole_classes += (uint32_t)__popcll(holew[w]);
+          uint32_t holes_now = 0;
+          for (uint32_t w = 0; w < W; ++w) holes_now += (uint32_t)__popcll(holew[w]);
+          if (holes_now != hole_classes) {  // (a step changes one class's holes at most)
+            hole_classes = holes_now;
+            mark_rows_with_holes();
+          }
           if (lane == first_gen) pending = false;
-          my_holes = pending && row_has_holes();
+          my_holes = pending && row_holes[r] != 0;
           continue;
         }
         bool cand = pending && lane < first_gen;
