@@ -167,3 +167,27 @@ def reference_prefix(cfg, sv, tk):
         h.update(np.ascontiguousarray(tk[k][:n]).tobytes())
     assert h.hexdigest() == str(z["input_sha256"]), "generator drift: regenerate tests/golden"
     return z["ref_servant_idx"]
+
+
+def check_prefix_digests(cfg, sv, tk, servant_idx):
+    """Compares the first placements of a full-size run with the verbatim reference's block digests
+    (tests/golden/ref_<cfg>_prefix_digests.npz, generator tests/golden/make_prefix_digests.py:
+    cfg3's first 400k requests — the dedicated-tier boundary and its chain included —, cfg4's
+    first 200k). Returns the number of requests covered."""
+    import hashlib
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "ref_%s_prefix_digests.npz" % cfg))
+    n, block = int(z["prefix"]), int(z["block"])
+    h = hashlib.sha256()
+    for k in sorted(sv):
+        h.update(np.ascontiguousarray(sv[k]).tobytes())
+    for k in sorted(tk):
+        h.update(np.ascontiguousarray(tk[k][:n]).tobytes())
+    assert h.hexdigest() == str(z["input_sha256"]), "generator drift: regenerate tests/golden"
+    for b in range(n // block):
+        part = servant_idx[b * block:(b + 1) * block]
+        assert synth.placement_hash(part) == int(z["digest"][b]), "requests %d..%d differ from the reference" % (
+            b * block, (b + 1) * block)
+        assert int((part < 0xFFFFFFFE).sum()) == int(z["granted"][b])
+    return n

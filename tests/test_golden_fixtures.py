@@ -44,6 +44,18 @@ def test_full_size_pools_prefix_matches_reference(cfg):
     assert np.array_equal(idx, ref)
 
 
+@pytest.mark.parametrize("cfg,n", [("cfg3", 400_000), ("cfg4", 200_000)])
+def test_full_size_pools_long_prefix_digests(cfg, n):
+    """... and on the long prefixes pinned block by block (tests/golden/ref_<cfg>_prefix_digests.npz:
+    cfg3's first 400k requests — past the dedicated-tier boundary —, cfg4's first 200k)."""
+    from tests import cases
+    from yadcc_amd import synth
+    sv, tk = synth.make_config(cfg)
+    head = {k: v[:n] for k, v in tk.items()}
+    idx, _, _ = O.dispatch(sv, head, "sorted")
+    assert cases.check_prefix_digests(cfg, sv, tk, idx) == n
+
+
 def test_stream_fixture_first_ticks_match_the_oracle():
     """tests/golden/ref_cfg5_stream_200_ticks.npz (the verbatim reference replaying configs[4]'s
     event stream): the oracle restatement, fed the same stream, reproduces the reference's

@@ -286,6 +286,9 @@ def test_cfg3_full_size(ctx):
     ref = cases.reference_prefix("cfg3", sv, tk)
     got, _, _ = ctx.dispatch(tk, want_util=False, want_running=False)
     assert np.array_equal(got[:len(ref)], ref)
+    # ... and, block by block, on its first 400k requests: the dedicated-tier boundary (request ~337k)
+    # and the chain of ~2000 requests the matching passes follow behind it.
+    assert cases.check_prefix_digests("cfg3", sv, tk, got) == 400_000
 
 
 def test_cfg4_full_size_one_gpu(ctx):
@@ -296,6 +299,7 @@ def test_cfg4_full_size_one_gpu(ctx):
     ref = cases.reference_prefix("cfg4", sv, tk)
     got, _, _ = ctx.dispatch(tk, want_util=False, want_running=False)
     assert np.array_equal(got[:len(ref)], ref)
+    assert cases.check_prefix_digests("cfg4", sv, tk, got) == 200_000
 
 
 def test_cfg3_disjoint_envs(ctx):
