@@ -103,7 +103,7 @@ class FlatStringMap {
     // in front of its home slot.
     std::size_t hole = i;
     for (std::size_t j = (i + 1) & mask; hashes_[j] != 0; j = (j + 1) & mask) {
-      const std::size_t home = hashes_[j] & mask;
+      const std::size_t home = Home(hashes_[j]) & mask;
       // (cyclic) `home` outside (hole, j]: the entry may move into the hole
       const bool movable = hole <= j ? (home <= hole || home > j) : (home <= hole && home > j);
       if (movable) {
@@ -135,12 +135,15 @@ class FlatStringMap {
     std::string key;
     V value{};
   };
+  // Bit 0 of a stored hash is forced to 1 (HashBytes): the home slot comes from the bits above it,
+  // or every key would start on an odd slot.
+  static std::size_t Home(std::uint64_t h) { return (std::size_t)(h >> 1); }
 
   // The slot of `key`, or the empty slot its probe sequence ends at. The hashes are an array of
   // their own: a probe that does not match touches eight of them per cache line and no key.
   std::size_t locate(std::string_view key, std::uint64_t h) const {
     const std::size_t mask = hashes_.size() - 1;
-    for (std::size_t i = h & mask;; i = (i + 1) & mask) {
+    for (std::size_t i = Home(h) & mask;; i = (i + 1) & mask) {
       if (hashes_[i] == 0) return i;
       if (hashes_[i] == h && entries_[i].key.size() == key.size() &&
           std::memcmp(entries_[i].key.data(), key.data(), key.size()) == 0)
@@ -165,7 +168,7 @@ class FlatStringMap {
     const std::size_t mask = hashes_.size() - 1;
     for (std::size_t k = 0; k != old_hashes.size(); ++k) {
       if (!old_hashes[k]) continue;
-      std::size_t i = old_hashes[k] & mask;
+      std::size_t i = Home(old_hashes[k]) & mask;
       while (hashes_[i]) i = (i + 1) & mask;
       hashes_[i] = old_hashes[k];
       filter_[(old_hashes[k] >> 24) & filter_mask_] |= 1ull << ((old_hashes[k] >> 18) & 63);
