@@ -400,19 +400,22 @@ def test_many_classes_paths(ctx):
     assert st["n_classes"] > 256
 
 
-@pytest.mark.parametrize("wide", [1, 4, 2, 3, 0])
+@pytest.mark.parametrize("wide", [1, 5, 4, 2, 3, 0])
 def test_more_than_256_classes(wide, monkeypatch):
     """Pools whose machines advertise individual compiler sets (the reference has no limit on
     (environment set, version) combinations, task_dispatcher.h:93-94, .cc:316-344): 150 digests,
     about one class per servant. wide=1: one wave per chunk with the class states in LDS
     (k_sim_wide), a request's classes read from its (digest, version threshold) row — registries
-    with such rows are walked 64 requests at a time from the first request on (k_walk_groups);
+    with such rows are walked 64 requests at a time from the first request on (k_walk_groups: head
+    rank and class id in one word; wide=5: in two arrays, as registries with more slots need them);
     wide=4: rounds of speculation and then the lone walker instead; wide=2: the walk with prefetch waves; wide=3: mask
     scan instead of the rows; wide=0: the thread-per-chunk kernel. Plain, with traffic from the servants'
     own hosts on shared hosts (holes, `self` resolved at replay time), and oversubscribed."""
     monkeypatch.setenv("YDC_WIDE", "1" if wide else "0")
     if wide in (2, 4):
         monkeypatch.setenv("YDC_GROUP_WALK", "0")  # rounds, then one request at a time
+    if wide == 5:
+        monkeypatch.setenv("YDC_WALK_PACKED", "0")
     if wide == 2:
         monkeypatch.setenv("YDC_WALK_PREFETCH", "1")  # the walk with prefetch waves
     if wide == 3:
@@ -437,7 +440,7 @@ def test_more_than_256_classes(wide, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(300, 312))
-def test_group_walk_random_sparse_pools(seed):
+def test_group_walk_random_sparse_pools(seed, monkeypatch):
     """k_walk_groups (sparse eligibility: 40 .. 200 digests, about one class per servant) on random
     shapes: ragged batch sizes, none / heavy traffic from the servants' own hosts, shared hosts,
     oversubscription (Timeout tails), unknown digests, initial running_tasks, and a batch
@@ -454,6 +457,8 @@ def test_group_walk_random_sparse_pools(seed):
         kw["shared_ip_frac"] = 0.25
     if rng.random() < 0.3:
         kw["initial_running"] = True
+    if seed % 4 == 1:
+        monkeypatch.setenv("YDC_WALK_PACKED", "0")  # (head ranks and class ids in two arrays)
     sv, tk = cases.random_case(**kw)
     c = binding.Context(device=0)
     try:

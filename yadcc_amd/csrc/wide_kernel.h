@@ -85,11 +85,18 @@ struct WideState {
 // classes l, l + 64, ...); else this lane's class of the request's row of eligible classes (kNone:
 // none; rows are ascending and hold a class once) — one class per lane, no loop over the words.
 constexpr uint32_t kNoRow = 0xFFFFFFFEu;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (an LDS word named by its byte address)
+// Head rank above the class id (k_walk_groups, ranks below 2^(32 - cbits) - 1): the lowest-ranked
+// head of a row of classes and the class it belongs to are one unsigned minimum.
+__device__ __forceinline__ uint32_t pack_head(uint32_t rank, uint32_t c, uint32_t cbits) {
+  return rank == kNone ? kNone : (rank << cbits) | c;
+}
 __device__ __forceinline__ void wide_general_step(const ClassLists& L, const WideState& S, uint64_t* holew,
                                                   uint32_t W, const uint64_t* mask, uint32_t self_lo,
                                                   uint32_t self_hi, const SharedIpTable& shared,
                                                   uint32_t* __restrict__ slot_of, uint32_t t, uint32_t lane,
-                                                  uint32_t row_c = kNoRow) {
+                                                  uint32_t row_c = kNoRow, uint32_t* hpk = nullptr,
+                                                  uint32_t cbits = 0, uint32_t hpk_stride = 1) {
   const bool by_row = row_c != kNoRow;
   if (by_row) {
     if (__ballot(row_c != kNone) == 0) {
@@ -181,6 +188,7 @@ __device__ __forceinline__ void wide_general_step(const ClassLists& L, const Wid
     S.hlo[bc] = r.hown_lo;
     S.hhi[bc] = r.hown_hi;
     S.hp[bc] = r.head_p;
+    if (hpk) hpk[bc * hpk_stride] = pack_head(r.head_p, bc, cbits);  // (k_walk_groups: head rank and class in one word)
     S.hg[bc] = r.head_g;
     S.np[bc] = r.cursor + 1 < r.end ? list_rank(L, r.cursor + 1) : kNone;
     S.ng[bc] = r.cursor + 1 < r.end ? list_slot(L, r.cursor + 1) : kNone;
@@ -622,19 +630,26 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
 // leaves end states and guesses consistent behind it. One wave.
 // ---------------------------------------------------------------------------
 // (rows are padded to multiples of eight classes in LDS — a row is read eight ids at a time)
-__host__ __device__ inline size_t group_walk_lds_bytes(uint32_t C, uint32_t n_rows, uint32_t n_list) {
-  return wide_lds_bytes(C) + (size_t)2 * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32 +
+__host__ __device__ inline size_t group_walk_lds_bytes(uint32_t C, uint32_t n_rows, uint32_t n_list,
+                                                       bool packed = false) {
+  return wide_lds_bytes(C) + (size_t)(packed ? 3 : 2) * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32 +
          2 * (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
+// PACKED (ranks and class ids share a word: head_bits(C) + rank bits <= 32, the planner checks):
+// hpk[c] = head rank << cbits | c beside S.hp — the scan of a row is one load and half a
+// v_min3_u32 per class instead of a load, a compare and two selects (a lone wave is bound by the
+// instructions it issues).
+template <bool PACKED>
 __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                     uint32_t chunk_size, uint32_t n_chunks,
                                                     ClassState* __restrict__ guess,
                                                     ClassState* __restrict__ endst, uint8_t* dirty,
                                                     uint32_t* __restrict__ slot_of, SharedIpTable shared,
                                                     uint32_t round, DeviceParams* prm, WideLists wl,
-                                                    uint32_t n_rows, uint32_t n_list, uint32_t whole_batch) {
-  extern __shared__ uint32_t wsm[];
+                                                    uint32_t n_rows, uint32_t n_list, uint32_t whole_batch,
+                                                    uint32_t cbits) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
   const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
   if (lane == 0) prm->n_changed[round & 63] = 0;
   uint32_t k = n_chunks;
@@ -643,7 +658,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     if (m) k = base + (uint32_t)__builtin_ctzll(m);
   }
   if (k >= n_chunks) return;  // nothing left to walk
-  // LDS: the state arrays and bit rows of k_sim_wide, then claim[C] | taint[C] | row offsets | rows
+  // LDS: the state arrays and bit rows of k_sim_wide, then claim[C] | taint[C] (or pairs) | row offsets | rows
   const uint32_t W8 = (W + 7u) & ~7u, Cpad = W8 * 64;
   const uint32_t state_words = (kWideFields - 2) * C + 2 * Cpad;
   const uint32_t mask_at = (state_words + 3u) & ~1u;
@@ -652,15 +667,23 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
               (const uint64_t*)(wsm + mask_at) + (size_t)64 * W8 + W};
   uint64_t* const holew = (uint64_t*)(wsm + mask_at) + (size_t)64 * W8;
   uint32_t* const claim = wsm + wide_lds_bytes(C) / 4;
-  uint32_t* const taint = claim + C;
-  uint32_t* const row_off = taint + C;  // n_rows + 1: starts of the PADDED rows, in groups of eight ids
+  // PACKED: {packed head, taint} pairs — one LDS address per class of a row serves the scan (the
+  // head) and the marking (offset 4); else taint[C] alone
+  constexpr uint32_t kTs = PACKED ? 2 : 1;  // words per class in that array
+  uint32_t* const hpk = claim + C;
+  uint32_t* const taint = hpk + (PACKED ? 1 : 0);
+  const uint32_t cmask = (1u << cbits) - 1;
+  uint32_t* const row_off = hpk + kTs * C;  // n_rows + 1: starts of the PADDED rows, in groups of eight ids
   // (16-byte aligned: a row is read eight 16-bit class ids at a time)
   uint8_t* const row_len = (uint8_t*)(row_off + n_rows + 1);           // [n_rows] true lengths (<= 64)
   uint8_t* const row_holes = row_len + ((n_rows + 15) & ~15u);          // [n_rows] 1: a class of the row has holes
-  uint16_t* const row_cls = (uint16_t*)(((uintptr_t)(row_holes + ((n_rows + 15) & ~15u)) + 15) & ~(uintptr_t)15);
+  // (an offset from the LDS base, not a rounded-up pointer value: through an integer the pointer
+  // loses its address space and every row read becomes a FLAT load)
+  const uint32_t rows_at = ((uint32_t)((row_holes + ((n_rows + 15) & ~15u)) - (uint8_t*)wsm) + 15u) & ~15u;
+  uint16_t* const row_cls = (uint16_t*)((uint8_t*)wsm + rows_at);
   // claim / taint entries are (0xFFFFFF - iteration) << 6 | lane: an atomic min prefers the
   // current iteration's marks to any older one and the lowest lane among them — nothing is wiped.
-  for (uint32_t c = lane; c < C; c += 64) claim[c] = taint[c] = kNone;
+  for (uint32_t c = lane; c < C; c += 64) claim[c] = taint[c * kTs] = kNone;
   {
     // Padded row starts: a wave scan over ceil(len / 8), 64 rows per round.
     uint32_t carry = 0;
@@ -714,6 +737,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     S.hhi[c] = st.hown_hi;
     S.end[c] = e;
     S.hp[c] = cur < e ? list_rank(L, cur) : kNone;
+    if (PACKED) hpk[c * kTs] = pack_head(S.hp[c], c, cbits);
     S.hg[c] = cur < e ? list_slot(L, cur) : kNone;
     S.np[c] = cur + 1 < e ? list_rank(L, cur + 1) : kNone;
     S.ng[c] = cur + 1 < e ? list_slot(L, cur + 1) : kNone;
@@ -750,17 +774,40 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   };
   mark_rows_with_holes();
   // One fetch of "the entry after next" in flight per lane (issued when the lane commits, stored
-  // right before the next commit or general step can need it: scans read heads only).
-  uint32_t pend_c = 0, pend_p = kNone, pend_g = kNone;
+  // right before the next commit or general step can need it: scans read heads only). The two
+  // loads land in a0 / a1 — accumulation registers, which nothing else in this kernel uses — and
+  // go from there to the LDS (`flush`), both in inline assembly: a loaded VALUE the compiler knows
+  // of is copied to the register of the variable it merges into right behind the load, i.e. waited
+  // for on the spot — a round trip to the L2 per iteration, a quarter of the walk.
+  uint32_t pend_c = 0, pend_i = 0;
   bool pend_on = false;
   auto flush = [&]() {
     if (pend_on) {
-      S.np[pend_c] = pend_p;
-      S.ng[pend_c] = pend_g;
+      const uint32_t a_np = (uint32_t)(uintptr_t)(S.np + pend_c), a_ng = (uint32_t)(uintptr_t)(S.ng + pend_c);
+      if (L.list_p) {
+        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a0\n\tds_write_b32 %1, a1"
+                     :: "v"(a_np), "v"(a_ng) : "a0", "a1", "memory");
+      } else {  // (no class partition: a list entry's rank is its index)
+        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a1" :: "v"(a_ng) : "a0", "a1", "memory");
+        S.np[pend_c] = pend_i;
+      }
       pend_on = false;
     }
   };
   uint32_t epoch = 0xFFFFFFu;  // counts down, one per iteration (a batch has far fewer than 2^24)
+#ifdef YDC_PHASE_PROBE
+  // Measurement build (tools/walk_probe.py groups): 100 MHz ticks per part of an iteration, counts.
+  unsigned long long gp_block = 0, gp_scan = 0, gp_gen = 0, gp_claim = 0, gp_taint = 0, gp_commit = 0, gp_t = 0,
+                     gp_iters = 0, gp_gens = 0, gp_rounds = 0, gp_commits = 0, gp_losers = 0, gp_blocked = 0,
+                     gp_pending = 0, gp_total0 = wall_clock64();
+#define YDC_GTICK() (gp_t = wall_clock64())
+#define YDC_GACC(x) do { const unsigned long long now__ = wall_clock64(); (x) += now__ - gp_t; gp_t = now__; } while (0)
+#define YDC_GCNT(x, v) ((x) += (v))
+#else
+#define YDC_GTICK() ((void)0)
+#define YDC_GACC(x) ((void)0)
+#define YDC_GCNT(x, v) ((void)0)
+#endif
   // The block's request columns are fetched a block ahead.
   uint32_t nx_slo = kNone, nx_shi = kNone, nx_row = kNone;
   {
@@ -777,6 +824,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
       const uint32_t t = tb + lane;
       const bool valid = t < t1;
       const uint32_t slo = nx_slo, shi = nx_shi, r = nx_row;
+      YDC_GTICK();
       {
         // (the next block: of this chunk, or the first of the next one)
         uint32_t tn = tb + 64 + lane, tn_end = t1;
@@ -811,33 +859,64 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           cid[8 * j + 7] = q.w >> 16;
         }
       }
+      if (PACKED) {
+        // ... and turned into the LDS addresses of the classes' {head, taint} pairs: the scans and
+        // the marking rounds use them as they are (the empty asm keeps the compiler from
+        // holding id * 8 instead and adding the base in front of every access).
+        const uint32_t pairs_at = (uint32_t)(uintptr_t)hpk;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          cid[i] = pairs_at + cid[i] * 8u;
+          asm volatile("" : "+v"(cid[i]));
+        }
+      }
       bool pending = valid;
       if (valid && n == 0) {
         slot_of[t] = kIdxEnvNotFound;  // task_dispatcher.cc:105-108
         pending = false;
       }
       bool my_holes = pending && row_holes[r] != 0;
+      YDC_GACC(gp_block);
       for (;;) {
         const uint64_t pend_mask = __ballot(pending);
         if (!pend_mask) break;
         --epoch;
+        YDC_GCNT(gp_iters, 1);
+        YDC_GCNT(gp_pending, __popcll(pend_mask));
         const uint32_t tag = epoch << 6;
         // ---- every unresolved lane: the lowest-ranked head among the classes of its row
         uint32_t best = kNone, bc = 0;
         bool gen = false;
         if (pending) {
           gen = shi == kSelfShared || my_holes;
+          if (PACKED) {
+            uint32_t bk = kNone;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if ((uint32_t)j < n) {
-              uint32_t hp[8];
+            for (int j = 0; j < 8; ++j) {
+              if ((uint32_t)j < n) {
+                uint32_t h[8];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) hp[u] = S.hp[cid[8 * j + u]];
+                for (int u = 0; u < 8; ++u) h[u] = *(const lds_u32_t*)(uintptr_t)cid[8 * j + u];
+                bk = min(min(min(bk, h[0]), min(h[1], h[2])), min(min(h[3], h[4]), min(h[5], min(h[6], h[7]))));
+              }
+            }
+            if (bk != kNone) {
+              best = bk >> cbits;
+              bc = bk & cmask;
+            }
+          } else {
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                if (hp[u] < best) {
-                  best = hp[u];
-                  bc = cid[8 * j + u];
+            for (int j = 0; j < 8; ++j) {
+              if ((uint32_t)j < n) {
+                uint32_t hp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hp[u] = S.hp[cid[8 * j + u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  if (hp[u] < best) {
+                    best = hp[u];
+                    bc = cid[8 * j + u];
+                  }
                 }
               }
             }
@@ -850,6 +929,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         }
         const uint64_t gen_mask = __ballot(pending && gen);
         const uint32_t first_gen = gen_mask ? (uint32_t)__builtin_ctzll(gen_mask) : 64u;
+        YDC_GACC(gp_scan);
         if (first_gen == (uint32_t)__builtin_ctzll(pend_mask)) {
           // The request that needs the state machine is the next one in sequence: the whole wave.
           const uint32_t tg = tb + first_gen;
@@ -860,7 +940,8 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           const uint32_t g_row = readlane_u32(r, first_gen);
           const uint32_t g_len = row_len[g_row];
           const uint32_t g_c = lane < g_len ? (uint32_t)row_cls[(size_t)row_off[g_row] * 8 + lane] : kNone;
-          wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane, g_c);
+          wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane, g_c,
+                            PACKED ? hpk : nullptr, cbits, kTs);
           __builtin_amdgcn_wave_barrier();
           uint32_t holes_now = 0;
           for (uint32_t w = 0; w < W; ++w) holes_now += (uint32_t)__popcll(holew[w]);
@@ -870,6 +951,8 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           }
           if (lane == first_gen) pending = false;
           my_holes = pending && row_holes[r] != 0;
+          YDC_GACC(gp_gen);
+          YDC_GCNT(gp_gens, 1);
           continue;
         }
         bool cand = pending && lane < first_gen;
@@ -882,22 +965,34 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         __builtin_amdgcn_wave_barrier();
         const bool loser = cand && claim[bc] != (tag | lane);
         bool blocked = false, mark = loser;
+        YDC_GACC(gp_claim);
+        YDC_GCNT(gp_losers, __popcll(__ballot(loser)));
         for (;;) {
+          YDC_GCNT(gp_rounds, 1);
           if (mark) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if ((uint32_t)j < n) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) atomicMin(&taint[cid[8 * j + u]], tag | lane);
+                for (int u = 0; u < 8; ++u) {
+                  if (PACKED)
+                    __hip_atomic_fetch_min((lds_u32_t*)(uintptr_t)(cid[8 * j + u] + 4u), tag | lane, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                  else
+                    atomicMin(&taint[cid[8 * j + u]], tag | lane);
+                }
               }
             }
           }
           __builtin_amdgcn_wave_barrier();
           // (a mark of this iteration from a lower lane: the tag matches and the value is smaller)
-          mark = cand && !loser && !blocked && taint[bc] < (tag | lane);
+          mark = cand && !loser && !blocked && taint[bc * kTs] < (tag | lane);
           if (!__ballot(mark)) break;
           blocked |= mark;
         }
+        YDC_GACC(gp_taint);
+        YDC_GCNT(gp_blocked, __popcll(__ballot(blocked)));
+        YDC_GCNT(gp_commits, __popcll(__ballot(cand && !loser && !blocked)));
         flush();  // (issued an iteration ago: the scan and the marking ran in its shadow)
         __builtin_amdgcn_wave_barrier();
         if (cand && !loser && !blocked) {
@@ -906,13 +1001,18 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           const uint32_t cur = S.cur[bc] + 1;
           S.cur[bc] = cur;
           S.lo[bc] = cur;
-          S.hp[bc] = S.np[bc];
+          const uint32_t nhp = S.np[bc];
+          S.hp[bc] = nhp;
+          if (PACKED) hpk[bc * kTs] = pack_head(nhp, bc, cbits);
           S.hg[bc] = S.ng[bc];
           if (cur + 1 < S.end[bc]) {
             pend_c = bc;
-            pend_p = list_rank(L, cur + 1);
-            pend_g = list_slot(L, cur + 1);
+            pend_i = cur + 1;
             pend_on = true;
+            const uint32_t* ag = L.list_g + (size_t)(cur + 1) * L.stride;
+            const uint32_t* ap = L.list_p ? L.list_p + (size_t)(cur + 1) * L.stride : ag;
+            asm volatile("global_load_dword a0, %0, off\n\tglobal_load_dword a1, %1, off"
+                         :: "v"(ap), "v"(ag) : "a0", "a1", "memory");
           } else {
             S.np[bc] = kNone;
             S.ng[bc] = kNone;
@@ -920,6 +1020,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           pending = false;
         }
         __builtin_amdgcn_wave_barrier();
+        YDC_GACC(gp_commit);
       }
     }
     const bool more = k + 1 < n_chunks;
@@ -945,6 +1046,16 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     if (!more) break;
     ++k;
   }
+#ifdef YDC_PHASE_PROBE
+  if (lane == 0) {
+    const unsigned long long v[16] = {gp_block, gp_scan, gp_gen, gp_claim, gp_taint, gp_commit, wall_clock64() - gp_total0,
+                                      gp_iters, gp_gens, gp_rounds, gp_commits, gp_losers, gp_blocked, gp_pending, 0, 0};
+    for (int i = 0; i < 16; ++i) ydc_phase_probe[16 + i] = v[i];
+  }
+#endif
+#undef YDC_GTICK
+#undef YDC_GACC
+#undef YDC_GCNT
 }
 
 }  // namespace ydc

@@ -279,6 +279,7 @@ struct ydc_context {
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
   bool opt_scan_multi = true;  // (scan_multi=0: one workgroup loops over the slabs)
   bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
+  bool opt_walk_packed = true; // ... with head rank and class id in one word where they fit (walk_packed=0: two arrays)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
   bool opt_split_gen = false;  // slot generation and request classification as two launches (YDC_SPLIT_GEN=1)
@@ -693,6 +694,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("xcd_tiles")) c->opt_xcd = (uint32_t)atoi(s);
   if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
   if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
+  if (const char* s = tune_value("walk_packed")) c->opt_walk_packed = atoi(s) != 0;
   if (const char* s = tune_value("scan_multi")) c->opt_scan_multi = atoi(s) != 0;
   if (const char* s = tune_value("classify_per_thread")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = tune_value("packed_class")) c->opt_packed_class = atoi(s) != 0;
@@ -1793,19 +1795,32 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
       const uint32_t n_list = p.wide_lists ? (uint32_t)c->tables.elig_cls.size() : 0;
       const bool group_walk = wide && p.wide_lists && c->opt_group_walk && p.C <= 65535 &&
                               group_walk_lds_bytes(p.C, n_rows, n_list) <= kGroupWalkMaxLds;
+      // Head rank and class id in one word where both fit (and the extra array fits the LDS):
+      // ranks are list positions of the whole registry here, below slot_bound.
+      uint32_t walk_cbits = 1;
+      while ((1u << walk_cbits) < p.C) ++walk_cbits;
+      const bool walk_packed = group_walk && c->opt_walk_packed && c->group.n_ranks <= 1 &&
+                               (uint64_t)p.slot_bound + 1 < ((uint64_t)1 << (32 - walk_cbits)) &&
+                               group_walk_lds_bytes(p.C, n_rows, n_list, true) <= kGroupWalkMaxLds;
       if (group_walk)
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_walk_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kGroupWalkMaxLds));
+        HIP_TRY(c, hipFuncSetAttribute(walk_packed ? (const void*)k_walk_groups<true> : (const void*)k_walk_groups<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGroupWalkMaxLds));
       uint32_t last_changed = 0xFFFFFFFFu;
       bool walked = false;
       if (group_walk) {
         // Sparse eligibility (eligible-class lists): no level to guess from, so no rounds of
         // speculation at all — the batch is walked from its first request, 64 requests at a time
         // (chunk 0's start state is the true one, k_guess_init; every chunk is still marked).
-        YDC_LAUNCH(c, "k_walk_groups", k_walk_groups, dim3(1), dim3(64),
-                   group_walk_lds_bytes(p.C, n_rows, n_list), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
-                   c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
-                   WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u);
+        if (walk_packed)
+          YDC_LAUNCH(c, "k_walk_groups", k_walk_groups<true>, dim3(1), dim3(64),
+                     group_walk_lds_bytes(p.C, n_rows, n_list, true), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
+                     c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
+                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits);
+        else
+          YDC_LAUNCH(c, "k_walk_groups", k_walk_groups<false>, dim3(1), dim3(64),
+                     group_walk_lds_bytes(p.C, n_rows, n_list), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
+                     c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
+                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits);
         ++rounds;
         HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
