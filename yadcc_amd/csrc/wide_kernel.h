@@ -775,7 +775,8 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   mark_rows_with_holes();
   // One fetch of "the entry after next" in flight per lane (issued when the lane commits, stored
   // right before the next commit or general step can need it: scans read heads only). The two
-  // loads land in a0 / a1 — accumulation registers, which nothing else in this kernel uses — and
+  // loads land in a254 / a255 — the last accumulation registers: one wave per SIMD has 512 registers
+  // to itself, the compiler takes ~240 of them and would spill into a0, a1, ... if it had to — and
   // go from there to the LDS (`flush`), both in inline assembly: a loaded VALUE the compiler knows
   // of is copied to the register of the variable it merges into right behind the load, i.e. waited
   // for on the spot — a round trip to the L2 per iteration, a quarter of the walk.
@@ -785,10 +786,10 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     if (pend_on) {
       const uint32_t a_np = (uint32_t)(uintptr_t)(S.np + pend_c), a_ng = (uint32_t)(uintptr_t)(S.ng + pend_c);
       if (L.list_p) {
-        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a0\n\tds_write_b32 %1, a1"
-                     :: "v"(a_np), "v"(a_ng) : "a0", "a1", "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a254\n\tds_write_b32 %1, a255"
+                     :: "v"(a_np), "v"(a_ng) : "a254", "a255", "memory");
       } else {  // (no class partition: a list entry's rank is its index)
-        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a1" :: "v"(a_ng) : "a0", "a1", "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a255" :: "v"(a_ng) : "a254", "a255", "memory");
         S.np[pend_c] = pend_i;
       }
       pend_on = false;
@@ -1011,8 +1012,8 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
             pend_on = true;
             const uint32_t* ag = L.list_g + (size_t)(cur + 1) * L.stride;
             const uint32_t* ap = L.list_p ? L.list_p + (size_t)(cur + 1) * L.stride : ag;
-            asm volatile("global_load_dword a0, %0, off\n\tglobal_load_dword a1, %1, off"
-                         :: "v"(ap), "v"(ag) : "a0", "a1", "memory");
+            asm volatile("global_load_dword a254, %0, off\n\tglobal_load_dword a255, %1, off"
+                         :: "v"(ap), "v"(ag) : "a254", "a255", "memory");
           } else {
             S.np[bc] = kNone;
             S.ng[bc] = kNone;
