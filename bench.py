@@ -450,7 +450,10 @@ def setup(args):
                 with socket.socket() as so:
                     so.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(so.getsockname()[1])
-        dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+        import datetime
+        # (a rank that died leaves the others in a collective: give up after 15 minutes, not gloo's 30)
+        dist.init_process_group("gloo", rank=E.rank, world_size=E.world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("YDC_BENCH_GLOO_TIMEOUT", "900"))))
         phase("gloo group up (%d ranks)" % E.world)
 
     from yadcc_amd import binding
