@@ -23,6 +23,7 @@ done
 [ -s $F/scatter_probe.txt ] && cp $F/scatter_probe.txt profiles/${R}_scatter_probe.txt
 [ -s $F/tail_cfg4.txt ] && cp $F/tail_cfg4.txt profiles/${R}_cfg4_match_tail.txt
 [ -s $F/front_cfg2.txt ] && cp $F/front_cfg2.txt profiles/${R}_cfg2_front_phases.txt
+[ -s $F/walk_groups.txt ] && cp $F/walk_groups.txt profiles/${R}_walk_groups_probe.txt
 [ -s $F/issue_probe.txt ] && cp $F/issue_probe.txt profiles/${R}_issue_probe.txt
 [ -s $F/fastloop_probe.txt ] && cp $F/fastloop_probe.txt profiles/${R}_fastloop_probe.txt
 python tools/rocprof_summary.py hbmtable "cfg2 (100k requests x 2k servants)=profiles/${R}_cfg2_pmc_hbm.json" \

@@ -31,6 +31,7 @@ timeout 400 bash tools/profile.sh cfg4 --config cfg4 > $O/profile_cfg4.log 2>&1
 [ -x tests/tools/scatter_probe ] && timeout 100 tests/tools/scatter_probe 5000000 8 8 > $O/scatter_probe.txt 2>&1
 YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 100 python tools/tail_probe.py cfg4 8 > $O/tail_cfg4.txt 2>&1
 YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 100 python tools/front_probe.py > $O/front_cfg2.txt 2>&1
+YDC_LIB=$PWD/yadcc_amd/libydc_probe.so timeout 100 python tools/walk_probe.py groups > $O/walk_groups.txt 2>&1
 cat $O/pytest.log
 python - $O <<'PY'
 import json,sys,glob,os
