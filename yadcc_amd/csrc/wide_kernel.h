@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void k_sim_wide(ClassLists L, TaskTable T, uin
 // (rows are padded to multiples of eight classes in LDS — a row is read eight ids at a time)
 __host__ __device__ inline size_t group_walk_lds_bytes(uint32_t C, uint32_t n_rows, uint32_t n_list,
                                                        bool packed = false) {
-  return wide_lds_bytes(C) + (size_t)(packed ? 3 : 2) * C * 4 + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32 +
+  return wide_lds_bytes(C) + (size_t)(packed ? 3 : 2) * C * 4 + (packed ? 8 : 0) + ((size_t)n_rows + 4) * 4 + ((size_t)n_list + 8 * (size_t)n_rows) * 2 + 32 +
          2 * (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
@@ -669,8 +669,11 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   uint32_t* const claim = wsm + wide_lds_bytes(C) / 4;
   // PACKED: {packed head, taint} pairs — one LDS address per class of a row serves the scan (the
   // head) and the marking (offset 4); else taint[C] alone
+  // (PACKED: the first pair is nobody's — head kNone —: rows hold class id + 1, and the groups of
+  // eight beyond a row's end read as zeros)
   constexpr uint32_t kTs = PACKED ? 2 : 1;  // words per class in that array
-  uint32_t* const hpk = claim + C;
+  uint32_t* const pairs = claim + C;
+  uint32_t* const hpk = pairs + (PACKED ? 2 : 0);
   uint32_t* const taint = hpk + (PACKED ? 1 : 0);
   const uint32_t cmask = (1u << cbits) - 1;
   uint32_t* const row_off = hpk + kTs * C;  // n_rows + 1: starts of the PADDED rows, in groups of eight ids
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   // claim / taint entries are (0xFFFFFF - iteration) << 6 | lane: an atomic min prefers the
   // current iteration's marks to any older one and the lowest lane among them — nothing is wiped.
   for (uint32_t c = lane; c < C; c += 64) claim[c] = taint[c * kTs] = kNone;
+  if (PACKED && lane == 0) pairs[0] = pairs[1] = kNone;
   {
     // Padded row starts: a wave scan over ceil(len / 8), 64 rows per round.
     uint32_t carry = 0;
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     for (uint32_t u = 0; u < 8; ++u) {  // (eight rows' loads in flight)
       const uint32_t r = min(r0 + u, n_rows - 1);
       const uint32_t o = wl.off[r], len = wl.off[r + 1] - o;
-      v[u] = len ? wl.cls[o + (lane < len ? lane : 0)] : 0u;
+      v[u] = len ? wl.cls[o + (lane < len ? lane : 0)] + 1u : 0u;  // (class id + 1: 0 is no class)
     }
 #pragma unroll
     for (uint32_t u = 0; u < 8; ++u) {
@@ -766,7 +770,10 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
       bool h = false;
       if (hole_classes) {
         const uint16_t* ids = row_cls + (size_t)row_off[r] * 8;
-        for (uint32_t j = 0; j < row_len[r]; ++j) h |= ((holew[ids[j] >> 6] >> (ids[j] & 63u)) & 1u) != 0;
+        for (uint32_t j = 0; j < row_len[r]; ++j) {
+          const uint32_t c = ids[j] - 1u;
+          h |= ((holew[c >> 6] >> (c & 63u)) & 1u) != 0;
+        }
       }
       row_holes[r] = h ? 1 : 0;
     }
@@ -782,14 +789,18 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   // for on the spot — a round trip to the L2 per iteration, a quarter of the walk.
   uint32_t pend_c = 0, pend_i = 0;
   bool pend_on = false;
-  auto flush = [&]() {
+  // young: this iteration's first pickers have issued their fetches already (two loads, younger than
+  // any this flush is for — the counter is in order): wait for all but those.
+  auto flush = [&](bool young) {
     if (pend_on) {
       const uint32_t a_np = (uint32_t)(uintptr_t)(S.np + pend_c), a_ng = (uint32_t)(uintptr_t)(S.ng + pend_c);
+      if (young) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (L.list_p) {
-        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a254\n\tds_write_b32 %1, a255"
+        asm volatile("ds_write_b32 %0, a254\n\tds_write_b32 %1, a255"
                      :: "v"(a_np), "v"(a_ng) : "a254", "a255", "memory");
       } else {  // (no class partition: a list entry's rank is its index)
-        asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b32 %0, a255" :: "v"(a_ng) : "a254", "a255", "memory");
+        asm volatile("ds_write_b32 %0, a255" :: "v"(a_ng) : "a254", "a255", "memory");
         S.np[pend_c] = pend_i;
       }
       pend_on = false;
@@ -864,12 +875,15 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         // ... and turned into the LDS addresses of the classes' {head, taint} pairs: the scans and
         // the marking rounds use them as they are (the empty asm keeps the compiler from
         // holding id * 8 instead and adding the base in front of every access).
-        const uint32_t pairs_at = (uint32_t)(uintptr_t)hpk;
+        const uint32_t pairs_at = (uint32_t)(uintptr_t)pairs;
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
           cid[i] = pairs_at + cid[i] * 8u;
           asm volatile("" : "+v"(cid[i]));
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) cid[i] -= 1u;  // (the rows hold class id + 1)
       }
       bool pending = valid;
       if (valid && n == 0) {
@@ -877,6 +891,10 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         pending = false;
       }
       bool my_holes = pending && row_holes[r] != 0;
+      // (what the last block's last commits fetched: a lane fetches again at its first claim of
+      // this block, into the same registers)
+      flush(false);
+      __builtin_amdgcn_wave_barrier();
       YDC_GACC(gp_block);
       for (;;) {
         const uint64_t pend_mask = __ballot(pending);
@@ -891,14 +909,17 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         if (pending) {
           gen = shi == kSelfShared || my_holes;
           if (PACKED) {
+            // (two groups per wait: a scan is as many LDS round trips as it has waits)
             uint32_t bk = kNone;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; j += 2) {
               if ((uint32_t)j < n) {
-                uint32_t h[8];
+                uint32_t h[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) h[u] = *(const lds_u32_t*)(uintptr_t)cid[8 * j + u];
-                bk = min(min(min(bk, h[0]), min(h[1], h[2])), min(min(h[3], h[4]), min(h[5], min(h[6], h[7]))));
+                for (int u = 0; u < 16; ++u) h[u] = *(const lds_u32_t*)(uintptr_t)cid[8 * j + u];
+                const uint32_t a = min(min(min(bk, h[0]), min(h[1], h[2])), min(min(h[3], h[4]), min(h[5], min(h[6], h[7]))));
+                const uint32_t b = min(min(min(h[8], h[9]), min(h[10], h[11])), min(min(h[12], h[13]), min(h[14], h[15])));
+                bk = min(a, b);
               }
             }
             if (bk != kNone) {
@@ -935,12 +956,12 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
           // The request that needs the state machine is the next one in sequence: the whole wave.
           const uint32_t tg = tb + first_gen;
           const uint32_t g_lo = readlane_u32(slo, first_gen), g_hi = readlane_u32(shi, first_gen);
-          flush();
+          flush(false);
           __builtin_amdgcn_wave_barrier();
           // (the request's classes: lane l takes entry l of its row)
           const uint32_t g_row = readlane_u32(r, first_gen);
           const uint32_t g_len = row_len[g_row];
-          const uint32_t g_c = lane < g_len ? (uint32_t)row_cls[(size_t)row_off[g_row] * 8 + lane] : kNone;
+          const uint32_t g_c = lane < g_len ? (uint32_t)row_cls[(size_t)row_off[g_row] * 8 + lane] - 1u : kNone;
           wide_general_step(L, S, holew, W, T.mask + (size_t)tg * W, g_lo, g_hi, shared, slot_of, tg, lane, g_c,
                             PACKED ? hpk : nullptr, cbits, kTs);
           __builtin_amdgcn_wave_barrier();
@@ -964,8 +985,27 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         }
         if (cand) atomicMin(&claim[bc], tag | lane);
         __builtin_amdgcn_wave_barrier();
-        const bool loser = cand && claim[bc] != (tag | lane);
+        // (the claim word, and with it — one LDS round trip — what a first picker's fetch needs)
+        uint32_t claimed = kNone, cur0 = 0, end0 = 0;
+        if (cand) {
+          claimed = claim[bc];
+          cur0 = S.cur[bc];
+          end0 = S.end[bc];
+        }
+        const bool loser = cand && claimed != (tag | lane);
         bool blocked = false, mark = loser;
+        // A first picker fetches the entry that becomes its class's `next` if it commits, now: the
+        // marking rounds, the commit and the next iteration's scan and rounds pass before `flush`
+        // wants it (issued at the commit it arrived a third of a microsecond late). A first picker
+        // that ends up waiting has fetched for nothing.
+        const bool fetching = cand && !loser && cur0 + 2 < end0;
+        const bool young = __ballot(fetching) != 0;
+        if (fetching) {
+          const uint32_t* ag = L.list_g + (size_t)(cur0 + 2) * L.stride;
+          const uint32_t* ap = L.list_p ? L.list_p + (size_t)(cur0 + 2) * L.stride : ag;
+          asm volatile("global_load_dword a254, %0, off\n\tglobal_load_dword a255, %1, off"
+                       :: "v"(ap), "v"(ag) : "a254", "a255", "memory");
+        }
         YDC_GACC(gp_claim);
         YDC_GCNT(gp_losers, __popcll(__ballot(loser)));
         for (;;) {
@@ -994,26 +1034,22 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         YDC_GACC(gp_taint);
         YDC_GCNT(gp_blocked, __popcll(__ballot(blocked)));
         YDC_GCNT(gp_commits, __popcll(__ballot(cand && !loser && !blocked)));
-        flush();  // (issued an iteration ago: the scan and the marking ran in its shadow)
+        flush(young);  // (what the lanes that committed an iteration ago fetched)
         __builtin_amdgcn_wave_barrier();
         if (cand && !loser && !blocked) {
           // ---- commit: the head of class bc is this request's slot; no holes on this path
           slot_of[t] = S.hg[bc];
-          const uint32_t cur = S.cur[bc] + 1;
+          const uint32_t cur = cur0 + 1;
           S.cur[bc] = cur;
           S.lo[bc] = cur;
           const uint32_t nhp = S.np[bc];
           S.hp[bc] = nhp;
           if (PACKED) hpk[bc * kTs] = pack_head(nhp, bc, cbits);
           S.hg[bc] = S.ng[bc];
-          if (cur + 1 < S.end[bc]) {
+          if (fetching) {  // (cur + 1 < end: entry cur + 1 is on its way, see the claim)
             pend_c = bc;
             pend_i = cur + 1;
             pend_on = true;
-            const uint32_t* ag = L.list_g + (size_t)(cur + 1) * L.stride;
-            const uint32_t* ap = L.list_p ? L.list_p + (size_t)(cur + 1) * L.stride : ag;
-            asm volatile("global_load_dword a254, %0, off\n\tglobal_load_dword a255, %1, off"
-                         :: "v"(ap), "v"(ag) : "a254", "a255", "memory");
           } else {
             S.np[bc] = kNone;
             S.ng[bc] = kNone;
@@ -1027,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
     const bool more = k + 1 < n_chunks;
     if (!whole_batch || !more) {
       // (walking the whole batch from its first request, nobody reads the states in between)
-      flush();
+      flush(false);
       __builtin_amdgcn_wave_barrier();
       for (uint32_t c = lane; c < C; c += 64) {
         ClassState s;
