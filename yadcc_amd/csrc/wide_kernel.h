@@ -837,18 +837,6 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
       const bool valid = t < t1;
       const uint32_t slo = nx_slo, shi = nx_shi, r = nx_row;
       YDC_GTICK();
-      {
-        // (the next block: of this chunk, or the first of the next one)
-        uint32_t tn = tb + 64 + lane, tn_end = t1;
-        if (tb + 64 >= t1) {
-          tn = (k + 1) * chunk_size + lane;
-          tn_end = min(n_tasks, (k + 2) * chunk_size);
-        }
-        const bool vn = tn < tn_end && tn < n_tasks;
-        nx_slo = vn ? T.self_lo[tn] : kNone;
-        nx_shi = vn ? T.self_hi[tn] : kNone;
-        nx_row = vn ? wl.row_of[tn] : kNone;
-      }
       // The row: n groups of eight class ids, unpacked into registers for the block (a lone wave
       // is bound by the instructions it issues — ~4.5 cycles each —, not by the LDS: every scan
       // of every iteration walks these 8 n ids, so they are unpacked once, not per scan).
@@ -895,6 +883,19 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
       // this block, into the same registers)
       flush(false);
       __builtin_amdgcn_wave_barrier();
+      // (behind the flush, which waits for every load in flight)
+      {
+        // (the next block: of this chunk, or the first of the next one)
+        uint32_t tn = tb + 64 + lane, tn_end = t1;
+        if (tb + 64 >= t1) {
+          tn = (k + 1) * chunk_size + lane;
+          tn_end = min(n_tasks, (k + 2) * chunk_size);
+        }
+        const bool vn = tn < tn_end && tn < n_tasks;
+        nx_slo = vn ? T.self_lo[tn] : kNone;
+        nx_shi = vn ? T.self_hi[tn] : kNone;
+        nx_row = vn ? wl.row_of[tn] : kNone;
+      }
       YDC_GACC(gp_block);
       for (;;) {
         const uint64_t pend_mask = __ballot(pending);
