@@ -106,8 +106,6 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (an LDS word named by its byte address)
-
 // Minimum over the 64 lanes (every lane gets it). Six v_min_u32_dpp.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   v = min(v, dpp_u32<0x111>(0xFFFFFFFFu, v));       // row_shr:1
@@ -1833,7 +1831,6 @@ __global__ __launch_bounds__(256) void k_apply_tick(const uint32_t* idx, const S
 
 #include "bin_sort.h"
 #include "match_kernel.h"
-#include "zone_guess.h"
 #include "wide_kernel.h"
 
 #endif  // YADCC_AMD_KERNELS_H_

@@ -148,11 +148,6 @@ struct MatchBuffers {
   uint32_t tile_tab_tiles, tile_tab_elems;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
   uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
-  // Non-NULL (zone_guess.h): chunks [zone_hdr[0], zone_hdr[1]) — the stretch where the dedicated
-  // tier runs out — start pass 0 from zone_guess[(chunk - zone_hdr[0]) * C + class] instead of
-  // their level guess.
-  const uint32_t* zone_hdr;
-  const ClassState* zone_guess;
 };
 
 constexpr uint32_t kWarmUp = 16;
@@ -983,11 +978,6 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
           else st.cursor = st.lo = next_guess.cursor = next_guess.lo = lo[q];
         }
       }
-    }
-    if (B.zone_hdr) {
-      // (k_zone_guess walked the stretch around the tier's end: its cursors, not the level's)
-      const uint32_t z0 = B.zone_hdr[0], z1 = B.zone_hdr[1];
-      if (kc >= z0 && kc < z1 && lane < C) st = B.zone_guess[(size_t)(kc - z0) * C + lane];
     }
     w.set_state(0, st, lane, C);
     if (rings_from_windows && lane < C) w.k[0].filled = win_filled;

@@ -88,8 +88,6 @@ struct BatchPlan {
   bool fuse01 = false;  // the launch of matching pass 0 is pass 1 as well (no launch for pass 1)
   bool wide_lists = false;  // > 256 classes with short eligible-class rows: k_sim_wide's list form
   bool binsort = false;
-  bool zone = false;            // k_zone_guess in front of the passes (zone_guess.h)
-  const uint2* zone_sorted = nullptr;  // the key-sorted records it finds the tier's end in
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   uint32_t bin_group = 0, bin_tiles = 0;  // servants per slot tile, slot tiles (k_front_bins)
   ServantTable sv{};
@@ -135,8 +133,6 @@ struct ydc_context {
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
-  DevBuf<uint32_t> d_zone_hdr;   // [2] chunk range k_zone_guess left guesses for
-  DevBuf<ClassState> d_zone_guess;
   DevBuf<uint32_t> d_binbase, d_binruns;  // bin sort: starts of the bins per class, run table of the slot tiles
   DevBuf<uint32_t> d_level_tab;           // bin sort: class-list positions at every 64th global rank
   DevBuf<uint32_t> d_elig_off, d_elig_cls, d_row_of;  // > 256 classes: eligible-class lists, the requests' rows
@@ -283,8 +279,6 @@ struct ydc_context {
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
   bool opt_scan_multi = true;  // (scan_multi=0: one workgroup loops over the slabs)
   bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
-  bool opt_zone_guess = true;  // start guesses around the dedicated tier's end from a walk of that stretch (zone_guess=0: level guesses)
-  uint32_t opt_zone_lead = 1536, opt_zone_trail = 1024, opt_zone_max_chunks = 2560;
   bool opt_walk_packed = true; // ... with head rank and class id in one word where they fit (walk_packed=0: two arrays)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
@@ -701,10 +695,6 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
   if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
   if (const char* s = tune_value("walk_packed")) c->opt_walk_packed = atoi(s) != 0;
-  if (const char* s = tune_value("zone_guess")) c->opt_zone_guess = atoi(s) != 0;
-  if (const char* s = tune_value("zone_lead")) c->opt_zone_lead = (uint32_t)atoi(s);
-  if (const char* s = tune_value("zone_trail")) c->opt_zone_trail = (uint32_t)atoi(s);
-  if (const char* s = tune_value("zone_max_chunks")) c->opt_zone_max_chunks = (uint32_t)atoi(s);
   if (const char* s = tune_value("scan_multi")) c->opt_scan_multi = atoi(s) != 0;
   if (const char* s = tune_value("classify_per_thread")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = tune_value("packed_class")) c->opt_packed_class = atoi(s) != 0;
@@ -751,8 +741,6 @@ int ydc_destroy(ydc_context* c) {
   c->d_cls_by_g.release();
   c->d_owner.release();
   c->d_rank_to_g.release();
-  c->d_zone_hdr.release();
-  c->d_zone_guess.release();
   c->d_guess[0].release();
   c->d_endst.release();
   c->d_checkpoint.release();
@@ -1265,20 +1253,6 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
       // replay with 16 / 32 / 64, and the launch lasts as long as its slowest wave).
       p.mb.warm_len = c->opt_warm_up ? c->opt_warm_up : std::min(64u, std::max(kWarmUp, p.cs / 8));
     }
-    // The stretch where the dedicated tier runs out, walked by one wave in front of the passes
-    // (zone_guess.h). Where the passes are one round of latency-bound waves — a chain behind
-    // the first launch then costs its full serial time (cfg3: 224 of 384 us) —; a batch of more
-    // chunks hides its second replays behind the other waves' work.
-    p.zone = c->opt_zone_guess && p.W == 1 && p.mb.before && p.fuse01 && p.mb.tail && c->n_parts <= 1 &&
-             !p.binsort && p.packed && c->kf.exact && p.key_passes >= 1 && C > 8 && C <= 64 && p.mb.tile_tab &&
-             K >= 64 && K <= c->opt_zone_max_chunks && !for_window && slot_bound;
-    if (p.zone) {
-      HIP_TRY(c, c->d_zone_hdr.reserve(2));
-      HIP_TRY(c, c->d_zone_guess.reserve((size_t)kZoneMaxChunks * C));
-      p.mb.zone_hdr = c->d_zone_hdr.p;
-      p.mb.zone_guess = c->d_zone_guess.p;
-      p.zone_sorted = (const uint2*)c->d_keys[key_sorted].p;
-    }
     // Ring of R = 2^rshift entries per class; a wave's rings hold 2048 entries in all
     // (16 KB of LDS: ranks + generation indexes), see match_kernel.h.
     p.ring_total = c->opt_ring_total;
@@ -1503,27 +1477,6 @@ int enqueue_front_b(ydc_context* c, const BatchPlan& p, const uint32_t* d_base) 
     // No eligible servant at all: every request fails with EnvironmentNotFound
     // (task_dispatcher.cc:105-108).
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_slot_of.p, (int)kIdxEnvNotFound, N, st));
-  }
-  if (p.zone && N && !d_base) {
-    ZoneArgs za{};
-    za.L = p.L;
-    za.mask = c->d_mask.p;
-    za.n_tasks = N;
-    za.chunk_size = p.cs;
-    za.n_chunks = K;
-    za.before = c->d_before.p;
-    za.tail = p.mb.tail;
-    za.warm_len = p.mb.warm_len;
-    za.tile_tab = p.mb.tile_tab;
-    za.tile_tab_tiles = p.mb.tile_tab_tiles;
-    za.tile_tab_elems = p.mb.tile_tab_elems;
-    za.sorted = p.zone_sorted;
-    za.tier_shift = c->kf.key_bits - 1;
-    za.lead = c->opt_zone_lead;
-    za.trail = c->opt_zone_trail;
-    za.hdr = c->d_zone_hdr.p;
-    za.guess = c->d_zone_guess.p;
-    YDC_LAUNCH(c, "k_zone_guess", k_zone_guess, dim3(1), dim3(64), (size_t)C * kZoneWindow * 4, st, za, prm);
   }
   if (N && C && p.any_shared && p.slot_bound) {
     // Hosts that run several servants: the replays resolve `self` from the class state, which
