@@ -107,6 +107,7 @@ typedef struct ydc_stats {
    * sorted only its key window) and how many of them had to be repeated with the full sort
    * because a window turned out too small. */
   uint32_t shard_sort_batches, shard_sort_misses;
+  uint32_t small_batch;    /* 1: the one-launch path placed the batch (ydc_dispatch_tick) */
   float stage_ms[16];      /* per-stage GPU time when profiling is on (ydc_set_profiling) */
 } ydc_stats;
 
@@ -174,6 +175,30 @@ int ydc_get_running(ydc_context* ctx, uint32_t* out_running, uint32_t n);
  * out_running (nullable) [n_servants]: running_tasks after the batch. */
 int ydc_dispatch(ydc_context* ctx, const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t flags,
                  uint32_t* out_servant_idx, double* out_utilization, uint32_t* out_running);
+/* (ydc_dispatch and ydc_dispatch_device send batches of up to 64 requests through the
+ * one-launch path of ydc_dispatch_tick as well.) */
+
+/* One scheduler turn for the reference's real call shape — a WaitForStartingTask RPC asks for
+ * `waiters + 1` grants (daemon/local/task_grant_keeper.cc:145-146; the handler's loop,
+ * scheduler_service_impl.cc:234-264): a handful of requests, plus whatever reached the registry
+ * since the last turn. Applies, in this order, n_upd heartbeats (KeepServantAlive,
+ * task_dispatcher.cc:195-201; idx[i] == current count appends a servant, as ydc_update_servants),
+ * n_rel released grants (FreeTask's --running_tasks, :181) and places n_tasks requests
+ * (n x WaitForStartingNewTask with timeout == now, :93-140). Same answers as
+ * ydc_update_servants_wide + ydc_release_slots + ydc_dispatch — which is what it does when the
+ * batch is large (more than 64 requests), a heartbeat changes structure (a new servant, other
+ * environments / version / host / capacity bound) or the registry is beyond 16384 servants /
+ * 2048 classes. Otherwise ONE launch: a single workgroup reads the registry once, applies the
+ * deltas, and makes the picks one after another (the reference's own arg-min,
+ * :362-451, as a workgroup-wide min-reduction per pick); requests, deltas and results travel as
+ * kernel arguments and stores to page-locked memory — no sort, no copy command, one wait.
+ * upd_env_masks (nullable): env_words words per heartbeat row, as ydc_update_servants_wide.
+ * Host buffers in and out, synchronous. out_utilization is nullable. */
+int ydc_dispatch_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                      const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
+                      const uint32_t* release_servant_idx, uint32_t n_rel,
+                      const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t flags,
+                      uint32_t* out_servant_idx, double* out_utilization);
 
 /* Page-locked host memory for ydc_dispatch: request columns and result arrays that lie in a
  * range registered here (or allocated here, or pinned by the caller's own hipHostMalloc /
@@ -388,6 +413,7 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
 typedef struct ydc_td_stats {
   uint64_t requests, batches, device_ns, host_ns;
   uint64_t heartbeats, heartbeats_unchanged, bookkeeper_rebuilds;
+  uint64_t lease_pages; /* pages of the lease table in use (4096 grant ids each): bounded by the live leases */
 } ydc_td_stats;
 int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out);
 /* OnExpirationTimer, task_dispatcher.cc:498-536 (for hosts that drive the 1 s tick themselves). */

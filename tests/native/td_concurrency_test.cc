@@ -179,7 +179,40 @@ static void Storm() {
   CHECK(!ever.empty());
 }
 
+// Round-4 review: (a) a request whose digest is an empty view WITHOUT storage (data() == nullptr)
+// must not match the unused entries of UnsafePlace's per-batch digest cache — it asks for a digest
+// nobody advertises: EnvironmentNotFound (reference task_dispatcher.cc:105-108), like a non-null
+// empty one; (b) the lease table stays bounded when a page empties while ids are still being
+// handed out from it (serial grant / free over many page crossings).
+static void NullDigestAndLeasePages() {
+  GpuTaskDispatcher::Options opt;
+  opt.start_expiration_timer = false;
+  GpuTaskDispatcher td(opt);
+  CHECK(td.device_status() == 0);
+  td.KeepServantAlive(Servant("10.0.0.1:1", 4, "d"), 60s);
+  {
+    RequestView rq[2];
+    rq[0].requestor_ip = "9.9.9.9";
+    rq[0].compiler_digest = std::string_view{};  // null data, zero length
+    rq[1].requestor_ip = "9.9.9.9";
+    rq[1].compiler_digest = std::string_view{"", 0};
+    std::int32_t status[2] = {-99, -99};
+    std::uint64_t ids[2];
+    char locs[2 * 32];
+    td.WaitForStartingNewTasksInto(2, rq, 60s, status, ids, locs, 32);
+    CHECK(status[0] == 1 && status[1] == 1);  // EnvironmentNotFound, twice
+  }
+  TaskPersonality t{"9.9.9.9", 0, "d"};
+  for (int i = 0; i < 12 * 4096 + 17; ++i) {
+    auto g = td.WaitForStartingNewTask(t, 60s, td.Now(), false);
+    CHECK(g.ok);
+    td.FreeTask(g->task_id);
+  }
+  CHECK(td.host_stats().lease_pages <= 2);
+}
+
 int main() {
+  NullDigestAndLeasePages();
   WakeOrder();
   CompletedByOthers();
   Storm();

@@ -181,4 +181,16 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
   return YDC_OK;
 }
 
+int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                      const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
+                      const uint32_t* release_servant_idx, uint32_t n_rel, const ydc_task_soa* tasks,
+                      uint32_t n_tasks, uint32_t flags, uint32_t* out_servant_idx, double* out_utilization) {
+  if (n_upd)
+    if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, upd_env_masks, env_words, n_upd)) return rc;
+  if (n_rel)
+    if (int rc = ydc_release_slots(c, release_servant_idx, n_rel)) return rc;
+  if (!n_tasks) return YDC_OK;
+  return ydc_dispatch(c, tasks, n_tasks, flags, out_servant_idx, out_utilization, nullptr);
+}
+
 }  // extern "C"

@@ -13,8 +13,16 @@
 //       `leases` live grants spread over the pool, then rounds x (KeepServantAlive +
 //       NotifyServantRunningTasks of every servant, each reporting the grants it holds), then
 //       GetRunningTasks polls (task_dispatcher.cc:190-277, running_task_bookkeeper.cc:36-43).
+//   td_native_bench latency <servants> <samples>
+//       the reference's real call shape (one WaitForStartingTask RPC asks for waiters + 1 grants,
+//       daemon/local/task_grant_keeper.cc:145-146; the loop at scheduler_service_impl.cc:234-264):
+//       p50 / p99 per CALL for one request through ydc_td_wait_for_starting_new_task and for
+//       batches of 2 / 16 / 256 through ydc_td_wait_for_starting_new_tasks, registry warm, the
+//       grants freed between two calls (so the release reaches the device inside the next call),
+//       a servant's heartbeat with a new load figure before every fourth call.
 // Links libydc.so (GPU) or tests/native/libtd_stub.so (CPU model of the device API: host-side
 // profiling without a GPU). Prints one JSON object.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -256,6 +264,88 @@ static int HeartbeatMode(int n_servants, std::size_t leases, int rounds) {
   return 0;
 }
 
+static void Percentiles(std::vector<double>& us, double* p50, double* p99, double* mean) {
+  std::sort(us.begin(), us.end());
+  double sum = 0;
+  for (double v : us) sum += v;
+  *p50 = us[us.size() / 2];
+  *p99 = us[std::min(us.size() - 1, us.size() * 99 / 100)];
+  *mean = sum / us.size();
+}
+
+static int LatencyMode(int n_servants, int samples) {
+  ydc_td* td = Create();
+  std::mt19937_64 rng(3);
+  std::vector<ydc_td_servant> sv;
+  std::vector<std::string> locations;
+  std::vector<std::vector<const char*>> envs;
+  Register(td, n_servants, rng, 1, &sv, &locations, &envs);
+  std::printf("{\"mode\": \"latency\", \"servants\": %d, \"samples\": %d, \"per_call_us\": {", n_servants, samples);
+  const std::size_t batches[] = {1, 1, 2, 16, 64, 256};  // (the first 1: single-request entry point)
+  bool first = true;
+  for (int bi = 0; bi < 6; ++bi) {
+    const std::size_t batch = batches[bi];
+    const bool single_entry = bi == 0;
+    std::vector<const char*> ip_ptrs(batch), digest_ptrs(batch);
+    std::vector<std::uint32_t> minv(batch, 20);
+    std::vector<std::int32_t> status(batch);
+    std::vector<std::uint64_t> ids(batch), granted_ids;
+    constexpr std::size_t kStride = 32;
+    std::vector<char> locs(batch * kStride);
+    std::vector<double> us, us_hb;
+    std::size_t granted = 0;
+    for (int r = -20; r < samples; ++r) {
+      // One RPC: one requestor, one digest (scheduler_service_impl.cc:228-264).
+      const std::string ip = "172.16." + std::to_string((r >> 8) & 255) + "." + std::to_string(r & 255);
+      for (std::size_t i = 0; i < batch; ++i) {
+        ip_ptrs[i] = ip.c_str();
+        digest_ptrs[i] = g_env_ptrs[(unsigned)r % 4];
+      }
+      const bool heartbeat = (r & 3) == 3;
+      if (heartbeat) {
+        const int s = (int)(rng() % n_servants);
+        sv[s].current_load = (sv[s].current_load + 1) % (sv[s].num_processors / 2);
+        ydc_td_keep_servant_alive(td, &sv[s], 3600ll * 1000000000ll);
+      }
+      auto t0 = Clk::now();
+      int rc;
+      if (single_entry) {
+        rc = ydc_td_wait_for_starting_new_task(td, ip_ptrs[0], 20, digest_ptrs[0], 15ll * 1000000000ll, 0, 0,
+                                               &ids[0], locs.data(), kStride);
+        status[0] = rc;
+      } else {
+        rc = ydc_td_wait_for_starting_new_tasks(td, batch, ip_ptrs.data(), minv.data(), digest_ptrs.data(),
+                                                15ll * 1000000000ll, nullptr, status.data(), ids.data(),
+                                                locs.data(), kStride);
+      }
+      auto t1 = Clk::now();
+      if (rc < 0) {
+        std::fprintf(stderr, "device error %d\n", rc);
+        return 1;
+      }
+      granted_ids.clear();
+      for (std::size_t i = 0; i < batch; ++i)
+        if (status[i] == YDC_TD_GRANTED) granted_ids.push_back(ids[i]);
+      ydc_td_free_tasks(td, granted_ids.data(), granted_ids.size());
+      if (r >= 0) {
+        (heartbeat ? us_hb : us).push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        granted += granted_ids.size();
+      }
+    }
+    double p50, p99, mean, h50 = 0, h99 = 0, hmean = 0;
+    Percentiles(us, &p50, &p99, &mean);
+    if (!us_hb.empty()) Percentiles(us_hb, &h50, &h99, &hmean);
+    std::printf("%s\"%s%zu\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"behind_a_heartbeat_p50\": %.2f, "
+                "\"behind_a_heartbeat_p99\": %.2f, \"granted_per_call\": %.2f}",
+                first ? "" : ", ", single_entry ? "single_" : "batch_", batch, p50, p99, mean, h50, h99,
+                (double)granted / samples);
+    first = false;
+  }
+  std::printf("}}\n");
+  ydc_td_destroy(td);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   for (int i = 0; i < 4; ++i) {
     char b[80];
@@ -270,6 +360,8 @@ int main(int argc, char** argv) {
   if (mode == "heartbeat")
     return HeartbeatMode(argc > 2 ? std::atoi(argv[2]) : 16000, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 1000000,
                          argc > 4 ? std::atoi(argv[4]) : 3);
-  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat ...\n");
+  if (mode == "latency")
+    return LatencyMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 1000);
+  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat|latency ...\n");
   return 2;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (YDC_LIB: a measurement build of the same library, e.g. libydc_probe.so — tools/phase_probe.py)
 LIB_PATH = os.environ.get("YDC_LIB") or os.path.join(_HERE, "libydc.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 IPC_HANDLE_BYTES = 256
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_LOCAL, TRANSPORT_IPC_DEVICE, TRANSPORT_IPC_HOST = range(5)
 TRANSPORT_NAMES = ("none", "rccl", "local", "ipc", "ipc-host")
@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
     "ydc_upload_servants", "ydc_update_servants", "ydc_update_servants_wide",
     "ydc_set_host_aliases", "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
-    "ydc_get_running", "ydc_dispatch", "ydc_dispatch_device", "ydc_dispatch_device_async",
+    "ydc_get_running", "ydc_dispatch", "ydc_dispatch_tick", "ydc_dispatch_device", "ydc_dispatch_device_async",
     "ydc_dispatch_wait", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
@@ -72,7 +72,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "n_tasks", "n_servants", "n_classes", "n_slots", "key_bits", "radix_passes", "n_chunks",
         "rounds", "chunk_sims", "granted", "timeouts", "env_not_found", "shard_sort_batches",
-        "shard_sort_misses")] + [
+        "shard_sort_misses", "small_batch")] + [
             ("stage_ms", C.c_float * 16)]
 
     def as_dict(self):
@@ -116,6 +116,9 @@ def lib():
         L.ydc_get_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_dispatch.argtypes = [C.c_void_p, C.POINTER(TaskSoA), C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ydc_dispatch_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                        C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(TaskSoA),
+                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.ydc_dispatch_device.argtypes = L.ydc_dispatch.argtypes
         L.ydc_dispatch_device_async.argtypes = L.ydc_dispatch.argtypes
         L.ydc_dispatch_wait.argtypes = [C.c_void_p]
@@ -174,19 +177,21 @@ _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GU
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
-              "ROUNDS_PER_CHECK", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+              "ROUNDS_PER_CHECK", "SMALL_BATCH", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
 _tune_injected = ""
 
 
 def compose_tune():
+    """The folded YDC_<KEY> switches go FIRST: the library takes the first match of a key, so a
+    test's switch wins over the same key in an inherited YDC_TUNE."""
     global _tune_injected
     cur = os.environ.get("YDC_TUNE", "")
-    if _tune_injected and cur.endswith(_tune_injected):
-        cur = cur[:len(cur) - len(_tune_injected)].rstrip(",")
+    if _tune_injected and cur.startswith(_tune_injected):
+        cur = cur[len(_tune_injected):].lstrip(",")
     mine = ",".join("%s=%s" % (k.lower(), os.environ["YDC_" + k]) for k in _TUNE_KEYS
                     if "YDC_" + k in os.environ)
     _tune_injected = mine
-    both = ",".join(x for x in (cur, mine) if x)
+    both = ",".join(x for x in (mine, cur) if x)
     if both:
         os.environ["YDC_TUNE"] = both
     else:
@@ -403,6 +408,34 @@ class Context:
         self._check(lib().ydc_dispatch(self._h, C.byref(soa), n, DISPATCH_COMMIT if commit else 0,
                                        _ptr(out), _ptr(util), _ptr(run)), "ydc_dispatch")
         return out, util, run
+
+    def dispatch_tick(self, tasks, upd_idx=(), upd_rows=None, release_idx=(), env_masks=None,
+                      commit=True, want_util=False):
+        """One scheduler turn (ydc_dispatch_tick): heartbeat rows (structured array of ROW_DTYPE),
+        released grants (servant index each), then the requests. Returns (servant_idx, util|None)."""
+        ui = np.ascontiguousarray(upd_idx, dtype=np.uint32)
+        if len(ui):
+            self.n_servants = max(self.n_servants, int(ui.max()) + 1)
+        ur = np.ascontiguousarray(upd_rows if upd_rows is not None else np.zeros(0, ROW_DTYPE),
+                                  dtype=ROW_DTYPE)
+        assert len(ur) == len(ui)
+        rel = np.ascontiguousarray(release_idx, dtype=np.uint32)
+        keep = [np.ascontiguousarray(tasks[k], dtype=np.uint32)
+                for k in ("env_id", "min_version", "requestor_ip")]
+        n = len(keep[0])
+        soa = TaskSoA(*[a.ctypes.data for a in keep])
+        out = np.empty(n, np.uint32)
+        util = np.empty(n, np.float64) if want_util else None
+        em = None
+        if env_masks is not None:
+            em = np.ascontiguousarray(env_masks, dtype=np.uint64).reshape(len(ui), -1)
+        self._check(lib().ydc_dispatch_tick(self._h, ui.ctypes.data, ur.ctypes.data,
+                                            em.ctypes.data if em is not None else None,
+                                            em.shape[1] if em is not None else 1, len(ui),
+                                            rel.ctypes.data, len(rel), C.byref(soa), n,
+                                            DISPATCH_COMMIT if commit else 0, out.ctypes.data,
+                                            _ptr(util)), "ydc_dispatch_tick")
+        return out, util
 
     def dispatch_device(self, d_env, d_minv, d_ip, d_out_idx=None, d_out_util=None,
                         d_out_running=None, commit=False):

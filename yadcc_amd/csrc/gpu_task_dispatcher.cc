@@ -209,6 +209,19 @@ GpuTaskDispatcher::Task* GpuTaskDispatcher::TaskTable::create(std::uint64_t id) 
   t->live = true;
   ++p->live;
   ++live_;
+  next_id_ = id + 1;
+  // The page before this one may have emptied while ids were still being handed out from it.
+  if ((id & ((1u << kPageBits) - 1)) == 0 && page > first_page_) {
+    auto& before = pages_[page - first_page_ - 1];
+    if (before && before->live == 0) {
+      if (spare_.size() < 64) spare_.push_back(std::move(before));
+      before.reset();
+      while (pages_.size() > 1 && !pages_.front()) {
+        pages_.pop_front();
+        ++first_page_;
+      }
+    }
+  }
   return t;
 }
 
@@ -219,8 +232,10 @@ void GpuTaskDispatcher::TaskTable::erase(std::uint64_t id) {
   --live_;
   auto& p = pages_[(id >> kPageBits) - first_page_];
   if (--p->live == 0) {
-    // (the page ids are still being handed out from stays: it is the back)
-    if (&p != &pages_.back()) {
+    // An emptied page goes, unless ids are still being handed out from it — decided by id, not
+    // by its place in the deque: a full page that empties while it is still the back would
+    // otherwise stay for good once the next page is appended behind it.
+    if ((next_id_ >> kPageBits) != (id >> kPageBits)) {
       if (spare_.size() < 64) spare_.push_back(std::move(p));
       p.reset();
     }
@@ -290,6 +305,7 @@ GpuTaskDispatcher::HostStats GpuTaskDispatcher::host_stats() const {
   std::scoped_lock _(allocation_lock_);
   HostStats s = host_stats_;
   s.bookkeeper_rebuilds = running_task_bookkeeper_.rebuilds();
+  s.lease_pages = tasks_.pages();
   return s;
 }
 
@@ -663,16 +679,41 @@ void GpuTaskDispatcher::OnExpirationTimer() {
 // ---------------------------------------------------------------------------
 // Placement
 // ---------------------------------------------------------------------------
+std::uint32_t GpuTaskDispatcher::DeviceFlags(const Servant& s) const {
+  const auto& p = s.personality;
+  std::uint32_t f = 0;
+  if (p.priority == kServantPriorityDedicated) f |= YDC_SERVANT_DEDICATED;          // :405
+  if (p.total_memory_in_bytes != 0 && p.memory_available_in_bytes < min_memory_for_new_task_)
+    f |= YDC_SERVANT_LOW_MEMORY;                                                     // :286-287
+  return f;
+}
+
+// The rows of dirty_rows_ (sorted: appended rows in index order) as the device API wants them,
+// into sync_rows_ / sync_env_ (*env_words words per row).
+void GpuTaskDispatcher::UnsafePackDirtyRows(std::uint32_t* env_words) {
+  static_assert(sizeof(SyncRow) == sizeof(ydc_servant_row), "row layout");
+  std::sort(dirty_rows_.begin(), dirty_rows_.end());
+  const std::uint32_t ew = EnvWords();
+  sync_rows_.resize(dirty_rows_.size());
+  sync_env_.assign(dirty_rows_.size() * ew, 0);
+  for (std::size_t k = 0; k != dirty_rows_.size(); ++k) {
+    const Servant& s = *servants_[dirty_rows_[k]];
+    SyncRow& r = sync_rows_[k];
+    r.version = (std::uint32_t)s.personality.version;
+    r.num_processors = Clamp32(s.personality.num_processors);
+    r.current_load = Clamp32(s.personality.current_load);
+    r.max_tasks = Clamp32(s.personality.max_tasks);
+    r.flags = DeviceFlags(s);
+    r.ip_id = s.ip_id;
+    for (auto b : s.env_bits) sync_env_[k * ew + b / 64] |= 1ull << (b % 64);
+    r.env_mask = sync_env_[k * ew];
+  }
+  *env_words = ew;
+}
+
 int GpuTaskDispatcher::UnsafeSyncDevice() {
   if (!ctx_) return device_status_ ? device_status_ : YDC_ERR_NO_DEVICE;
-  auto flags_of = [this](const Servant& s) {
-    const auto& p = s.personality;
-    std::uint32_t f = 0;
-    if (p.priority == kServantPriorityDedicated) f |= YDC_SERVANT_DEDICATED;          // :405
-    if (p.total_memory_in_bytes != 0 && p.memory_available_in_bytes < min_memory_for_new_task_)
-      f |= YDC_SERVANT_LOW_MEMORY;                                                     // :286-287
-    return f;
-  };
+  auto flags_of = [this](const Servant& s) { return DeviceFlags(s); };
   if (need_full_upload_) {
     const std::size_t n = servants_.size();
     std::vector<std::uint32_t> version(n), nproc(n), load(n), max_tasks(n), running(n), flags(n), ip(n);
@@ -701,23 +742,10 @@ int GpuTaskDispatcher::UnsafeSyncDevice() {
     return UnsafeSyncAliases();
   }
   if (!dirty_rows_.empty()) {
-    std::sort(dirty_rows_.begin(), dirty_rows_.end());  // appended rows in index order
-    std::vector<ydc_servant_row> rows(dirty_rows_.size());
-    const std::uint32_t ew = EnvWords();
-    std::vector<std::uint64_t> env(rows.size() * ew, 0);
-    for (std::size_t k = 0; k != dirty_rows_.size(); ++k) {
-      const Servant& s = *servants_[dirty_rows_[k]];
-      rows[k].version = (std::uint32_t)s.personality.version;
-      rows[k].num_processors = Clamp32(s.personality.num_processors);
-      rows[k].current_load = Clamp32(s.personality.current_load);
-      rows[k].max_tasks = Clamp32(s.personality.max_tasks);
-      rows[k].flags = flags_of(s);
-      rows[k].ip_id = s.ip_id;
-      for (auto b : s.env_bits) env[k * ew + b / 64] |= 1ull << (b % 64);
-      rows[k].env_mask = env[k * ew];
-    }
-    int rc = ydc_update_servants_wide(ctx_, dirty_rows_.data(), rows.data(), env.data(), ew,
-                                      (std::uint32_t)rows.size());
+    std::uint32_t ew = 1;
+    UnsafePackDirtyRows(&ew);
+    int rc = ydc_update_servants_wide(ctx_, dirty_rows_.data(), (const ydc_servant_row*)sync_rows_.data(),
+                                      sync_env_.data(), ew, (std::uint32_t)dirty_rows_.size());
     if (rc != YDC_OK) return rc;
     for (auto i : dirty_rows_) row_is_dirty_[i] = 0;
     dirty_rows_.clear();
@@ -793,8 +821,12 @@ int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
     }
     rip[i] = last_ip_id;
   }
+  // What reached the registry since the last batch — heartbeat rows, released grants — travels
+  // WITH the batch (ydc_dispatch_tick: one launch for a handful of requests, deltas included);
+  // a table that has to be uploaded whole, or new address aliases, go first and by themselves.
   const std::uint64_t t0 = NowNs();
-  int rc = UnsafeSyncDevice();
+  int rc = !ctx_ ? (device_status_ ? device_status_ : YDC_ERR_NO_DEVICE)
+                 : (need_full_upload_ || aliases_dirty_ ? UnsafeSyncDevice() : YDC_OK);
   std::uint64_t device_ns = NowNs() - t0;
   if (rc == YDC_OK) {
     // Digests: the same view as the request before (one RPC's requests), else one of the last
@@ -805,15 +837,15 @@ int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
       std::size_t n = 0;
       std::uint32_t env = 0, name = 0;
     } seen[4];
-    unsigned next_seen = 0;
+    unsigned next_seen = 0;  // entries of seen[] in use: min(next_seen, 4) — an unused entry matches nothing
     for (std::uint32_t i = 0; i != n; ++i) {
       const RequestView& r = batch[i];
       const char* dp = r.compiler_digest.data();
       const std::size_t dn = r.compiler_digest.size();
       if (!(have_digest && dp == last_digest.data() && dn == last_digest.size())) {
         const Seen* hit = nullptr;
-        for (const Seen& s : seen)
-          if (s.p == dp && s.n == dn) hit = &s;
+        for (unsigned k = 0, used = next_seen < 4 ? next_seen : 4; k != used; ++k)
+          if (seen[k].p == dp && seen[k].n == dn) hit = &seen[k];
         if (hit) {
           last_env = hit->env;
           last_name = hit->name;
@@ -832,7 +864,16 @@ int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
     }
     ydc_task_soa soa{env, minv, rip};
     const std::uint64_t t1 = NowNs();
-    rc = ydc_dispatch(ctx_, &soa, n, YDC_DISPATCH_COMMIT, out, nullptr, nullptr);
+    std::uint32_t ew = 1;
+    if (!dirty_rows_.empty()) UnsafePackDirtyRows(&ew);
+    rc = ydc_dispatch_tick(ctx_, dirty_rows_.data(), (const ydc_servant_row*)sync_rows_.data(), sync_env_.data(), ew,
+                           (std::uint32_t)dirty_rows_.size(), pending_release_.data(),
+                           (std::uint32_t)pending_release_.size(), &soa, n, YDC_DISPATCH_COMMIT, out, nullptr);
+    if (rc == YDC_OK) {
+      for (auto i : dirty_rows_) row_is_dirty_[i] = 0;
+      dirty_rows_.clear();
+      pending_release_.clear();
+    }
     device_ns += NowNs() - t1;
   }
   host_stats_.device_ns += device_ns;

@@ -217,6 +217,7 @@ class GpuTaskDispatcher {
   struct HostStats {
     std::uint64_t requests = 0, batches = 0, device_ns = 0, host_ns = 0;
     std::uint64_t heartbeats = 0, heartbeats_unchanged = 0, bookkeeper_rebuilds = 0;
+    std::uint64_t lease_pages = 0;
   };
   HostStats host_stats() const;
 
@@ -276,6 +277,7 @@ class GpuTaskDispatcher {
     Task* create(std::uint64_t id);  // id = the next one in sequence
     void erase(std::uint64_t id);
     std::size_t size() const { return live_; }
+    std::size_t pages() const { return pages_.size(); }  // (tests: stays bounded)
     template <class F>
     void for_each(F&& f) {
       for (std::size_t p = 0; p != pages_.size(); ++p) {
@@ -293,6 +295,7 @@ class GpuTaskDispatcher {
     std::deque<std::unique_ptr<Page>> pages_;
     std::vector<std::unique_ptr<Page>> spare_;  // emptied pages, reused before the allocator is asked
     std::uint64_t first_page_ = 0;
+    std::uint64_t next_id_ = 0;  // the id create() hands out next
     std::size_t live_ = 0;
   };
   // Strings that task records refer to by number (permanent: bounded by the distinct digests
@@ -332,6 +335,8 @@ class GpuTaskDispatcher {
   void UnsafeSweepZombiesOf(Servant* servant, const RunningTaskView* reported, std::size_t n);
   int UnsafeSyncDevice();
   int UnsafeSyncAliases();
+  std::uint32_t DeviceFlags(const Servant& s) const;
+  void UnsafePackDirtyRows(std::uint32_t* env_words);
   // A batch in arrival order: contiguous views, or the requests of parked / queued callers.
   struct RequestSpan {
     const RequestView* views = nullptr;
@@ -387,6 +392,12 @@ class GpuTaskDispatcher {
   std::vector<std::uint32_t> dirty_rows_;
   std::vector<std::uint8_t> row_is_dirty_;
   std::vector<std::uint32_t> pending_release_;
+  struct SyncRow {  // layout of ydc_servant_row (include/yadcc_dispatch.h)
+    std::uint32_t version, num_processors, current_load, max_tasks, flags, ip_id;
+    std::uint64_t env_mask;
+  };
+  std::vector<SyncRow> sync_rows_;       // dirty_rows_ packed for the device API
+  std::vector<std::uint64_t> sync_env_;  // ... their environment masks
 
   // Request columns and the result array of a device batch, reused from batch to batch and
   // page-locked where the runtime lets us (ydc_host_alloc): ydc_dispatch then reads and writes

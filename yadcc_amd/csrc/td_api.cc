@@ -231,6 +231,7 @@ int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out) {
   out->heartbeats = s.heartbeats;
   out->heartbeats_unchanged = s.heartbeats_unchanged;
   out->bookkeeper_rebuilds = s.bookkeeper_rebuilds;
+  out->lease_pages = s.lease_pages;
   return YDC_OK;
 }
 

@@ -23,6 +23,7 @@
 #include "dispatch_core.h"
 #include "host_tables.h"
 #include "kernels.h"
+#include "tick_kernel.h"
 
 using namespace ydc;
 
@@ -271,6 +272,17 @@ struct ydc_context {
   DevBuf<uint32_t> d_out_idx, d_upd_idx;
   DevBuf<ydc_servant_row> d_upd_rows;
 
+  // Small-batch path (tick_kernel.h): one launch per call, requests / deltas / results as kernel
+  // arguments and plain stores to page-locked memory.
+  DevBuf<uint32_t> d_ip;            // resident copy of the ip_id column (rebuild_tables)
+  TickDone* h_tick_done = nullptr;  // page-locked, coherent: the kernel's stamp + counters
+  TickDone* d_tick_done = nullptr;  // ... its device address
+  uint8_t *h_tick_io = nullptr, *d_tick_io = nullptr;  // page-locked arena: columns / deltas in, results out
+  size_t tick_io_cap = 0;
+  uint32_t tick_seq = 0;
+  uint32_t opt_small_batch = 64;  // batches up to this many requests take it (small_batch=0: none does)
+  uint64_t tick_batches = 0;
+
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
   // 16 KB of LDS per matching wave = 10 waves per CU. Smaller rings (more waves per CU, shorter
@@ -449,6 +461,7 @@ int rebuild_tables(ydc_context* c) {
   c->kf = choose_key_format(c->tables.cap_bits, kMaxRadixBits, &c->n_parts, fuse_bits);
   if (C > 65535) return fail(c, YDC_ERR_TOO_MANY_CLASSES, "%u servant classes", C);
   HIP_TRY(c, c->d_class_of.reserve(n));
+  HIP_TRY(c, c->d_ip.reserve(n));
   HIP_TRY(c, c->d_ip_sorted.reserve(n_ip));
   HIP_TRY(c, c->d_ip_servant.reserve(n_ip));
   HIP_TRY(c, c->d_ip_hash.reserve(c->tables.ip_hash.size()));
@@ -477,6 +490,7 @@ int rebuild_tables(ydc_context* c) {
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->d_class_of.p, c->tables.class_of.data(), n * 4,
                               hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ip.p, c->h_ip.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_ip_sorted.p, c->tables.ip_sorted.data(), (size_t)n_ip * 4,
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_ip_servant.p, c->tables.ip_servant.data(), (size_t)n_ip * 4,
@@ -641,7 +655,7 @@ int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
 }
-uint32_t ydc_abi_version(void) { return 4; }
+uint32_t ydc_abi_version(void) { return 5; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
                void* stream, ydc_context** out) {
@@ -714,6 +728,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("binsort_verify")) c->debug_verify_binsort = atoi(s) != 0;
   if (const char* s = tune_value("binsort_max_slots")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = tune_value("shard_margin")) c->opt_shard_margin = atoll(s);
+  if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
   if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -760,6 +775,9 @@ int ydc_destroy(ydc_context* c) {
   if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_tick_done) (void)hipHostFree(c->h_tick_done);
+  if (c->h_tick_io) (void)hipHostFree(c->h_tick_io);
+  c->d_ip.release();
   c->d_in.release();
   c->d_res.release();
   for (auto& e : c->ev)
@@ -1892,6 +1910,218 @@ int fall_back_to_radix(ydc_context* c, uint32_t N, BatchPlan* p) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// The small-batch path (tick_kernel.h): a handful of requests, the heartbeat rows that change no
+// structure and the released grants that came in since the last call — one launch, no copy
+// command; the host spins on the stamp the kernel stores last.
+// ---------------------------------------------------------------------------
+namespace {
+
+// Registries and batches the one-workgroup kernel takes (tables must be current).
+bool tick_takes(const ydc_context* c, uint32_t n_tasks) {
+  return c->opt_small_batch && n_tasks <= c->opt_small_batch && c->n_servants <= kTickMaxServants &&
+         c->tables.n_classes() <= kTickMaxClasses && c->h_alias_ip.empty() && c->group.n_ranks == 0 &&
+         !c->stream_mode.active && c->pend_count == 0 && !c->debug_sim && !c->debug_verify_binsort;
+}
+
+// A heartbeat row that changes what the derived tables are built from (classes, the ip table,
+// the slot bound): same test as ydc_update_servants_wide.
+bool row_is_structural(const ydc_context* c, uint32_t s, const ydc_servant_row& r, const uint64_t* env_masks,
+                       uint32_t env_words, uint32_t i) {
+  if (s >= c->n_servants) return true;  // a new servant
+  const uint32_t EW = c->env_words;
+  if (env_masks && env_words > EW) return true;
+  if (!env_masks && EW > 1) return true;  // (refused by ydc_update_servants_wide: let it say so)
+  const uint64_t* env = &c->h_env[(size_t)s * EW];
+  for (uint32_t w = 0; w < EW; ++w) {
+    const uint64_t m = env_masks ? (w < env_words ? env_masks[(size_t)i * env_words + w] : 0) : (w == 0 ? r.env_mask : 0);
+    if (env[w] != m) return true;
+  }
+  return c->h_version[s] != r.version || c->h_ip[s] != r.ip_id || (c->h_max_tasks[s] == 0) != (r.max_tasks == 0) ||
+         std::min(c->h_max_tasks[s], c->h_nproc[s]) != std::min(r.max_tasks, r.num_processors);
+}
+
+struct TickCall {
+  const ydc_task_soa* tasks = nullptr;  // host columns, or device addresses (tasks_on_device)
+  bool tasks_on_device = false;
+  uint32_t n_tasks = 0;
+  const uint32_t* upd_idx = nullptr;  // host; rows known to change no structure
+  const ydc_servant_row* upd_rows = nullptr;
+  uint32_t n_upd = 0;
+  const uint32_t* rel = nullptr;  // host
+  uint32_t n_rel = 0;
+  uint32_t flags = 0;
+  uint32_t* out_idx = nullptr;  // host, or device addresses (out_on_device)
+  double* out_util = nullptr;
+  uint32_t* out_running = nullptr;
+  bool out_on_device = false;
+};
+
+template <int K, bool COLD>
+void tick_launch(ydc_context* c, const TickArgs& a, size_t lds) {
+  YDC_LAUNCH(c, "k_tick", (k_tick<K, COLD>), dim3(1), dim3(kTickThreads), lds, c->stream, a);
+}
+
+int tick_run(ydc_context* c, const TickCall& io) {
+  const uint32_t S = c->n_servants, C = c->tables.n_classes(), N = io.n_tasks;
+  const uint32_t W = std::max<uint32_t>(1, ceil_div(C, 64));
+  if (!c->h_tick_done) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_tick_done, sizeof(TickDone), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(c->h_tick_done, 0, sizeof(TickDone));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_tick_done, c->h_tick_done, 0));
+  }
+  auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  // Arena: [request columns] [heartbeat indexes | rows] [released] | [idx] [utilisation]
+  const bool tasks_ptr = !io.tasks_on_device && N > kTickInlineTasks;
+  const bool upd_ptr = io.n_upd > kTickInlineUpd, rel_ptr = io.n_rel > kTickInlineRel;
+  const size_t o_env = 0, o_upd = o_env + (tasks_ptr ? 3 * pad((size_t)N * 4) : 0);
+  const size_t o_rows = o_upd + (upd_ptr ? pad((size_t)io.n_upd * 4) : 0);
+  const size_t o_rel = o_rows + (upd_ptr ? pad((size_t)io.n_upd * sizeof(TickRow)) : 0);
+  const size_t o_idx = o_rel + (rel_ptr ? pad((size_t)io.n_rel * 4) : 0);
+  const size_t o_util = o_idx + (io.out_on_device ? 0 : pad((size_t)N * 4));
+  const size_t need = o_util + (!io.out_on_device && io.out_util ? pad((size_t)N * 8) : 0);
+  if (need > c->tick_io_cap) {
+    if (c->h_tick_io) (void)hipHostFree(c->h_tick_io);
+    c->h_tick_io = c->d_tick_io = nullptr;
+    c->tick_io_cap = 0;
+    const size_t want = std::max<size_t>(need + need / 2, 8192);
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_tick_io, want, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_tick_io, c->h_tick_io, 0));
+    c->tick_io_cap = want;
+  }
+  const bool commit = (io.flags & YDC_DISPATCH_COMMIT) != 0;
+  TickArgs a;
+  a.nproc = c->d_nproc.p;
+  a.load = c->d_load.p;
+  a.max_tasks = c->d_max_tasks.p;
+  a.flags = c->d_flags.p;
+  a.class_of = c->d_class_of.p;
+  a.ip = c->d_ip.p;
+  a.running = c->d_running.p;
+  a.cls_env = c->d_cls_env.p;
+  a.cls_ver = c->d_cls_ver.p;
+  a.S = S;
+  a.C = C;
+  a.EW = c->env_words;
+  a.W = W;
+  // running_tasks: the picks work on the resident column (COMMIT) or on a copy of it.
+  uint32_t* dev_run_out = io.out_running ? (io.out_on_device ? io.out_running : c->d_running_out.p) : nullptr;
+  a.rw = commit ? c->d_running.p : (dev_run_out ? dev_run_out : c->d_running_out.p);
+  a.run_out = dev_run_out && dev_run_out != a.rw ? dev_run_out : nullptr;
+  a.n_tasks = N;
+  a.t_env = a.t_minv = a.t_rip = nullptr;
+  if (io.tasks_on_device) {
+    a.t_env = io.tasks->env_id;
+    a.t_minv = io.tasks->min_version;
+    a.t_rip = io.tasks->requestor_ip;
+  } else if (tasks_ptr) {
+    const size_t col = pad((size_t)N * 4);
+    std::memcpy(c->h_tick_io + o_env, io.tasks->env_id, (size_t)N * 4);
+    std::memcpy(c->h_tick_io + o_env + col, io.tasks->min_version, (size_t)N * 4);
+    std::memcpy(c->h_tick_io + o_env + 2 * col, io.tasks->requestor_ip, (size_t)N * 4);
+    a.t_env = (const uint32_t*)(c->d_tick_io + o_env);
+    a.t_minv = (const uint32_t*)(c->d_tick_io + o_env + col);
+    a.t_rip = (const uint32_t*)(c->d_tick_io + o_env + 2 * col);
+  } else {
+    for (uint32_t i = 0; i < N; ++i) {
+      a.in_env[i] = io.tasks->env_id[i];
+      a.in_minv[i] = io.tasks->min_version[i];
+      a.in_rip[i] = io.tasks->requestor_ip[i];
+    }
+  }
+  a.n_upd = io.n_upd;
+  a.upd_idx = nullptr;
+  a.upd_rows = nullptr;
+  {
+    uint32_t* idx = upd_ptr ? (uint32_t*)(c->h_tick_io + o_upd) : a.in_upd_idx;
+    TickRow* rows = upd_ptr ? (TickRow*)(c->h_tick_io + o_rows) : a.in_upd;
+    for (uint32_t i = 0; i < io.n_upd; ++i) {
+      idx[i] = io.upd_idx[i];
+      rows[i] = TickRow{io.upd_rows[i].num_processors, io.upd_rows[i].current_load, io.upd_rows[i].max_tasks,
+                        io.upd_rows[i].flags};
+    }
+    if (upd_ptr) {
+      a.upd_idx = (const uint32_t*)(c->d_tick_io + o_upd);
+      a.upd_rows = (const TickRow*)(c->d_tick_io + o_rows);
+    }
+  }
+  a.n_rel = io.n_rel;
+  a.rel = nullptr;
+  if (rel_ptr) {
+    std::memcpy(c->h_tick_io + o_rel, io.rel, (size_t)io.n_rel * 4);
+    a.rel = (const uint32_t*)(c->d_tick_io + o_rel);
+  } else if (io.n_rel) {
+    std::memcpy(a.in_rel, io.rel, (size_t)io.n_rel * 4);
+  }
+  a.out_idx = io.out_on_device ? io.out_idx : (uint32_t*)(c->d_tick_io + o_idx);
+  a.out_util = io.out_util ? (io.out_on_device ? io.out_util : (double*)(c->d_tick_io + o_util)) : nullptr;
+  a.done = c->d_tick_done;
+  if (++c->tick_seq == 0) c->tick_seq = 1;
+  a.seq = c->tick_seq;
+
+  if (c->profiling) {
+    c->ksamples_used = 0;
+    for (int s = 0; s <= 6; ++s) mark(c, s);
+  }
+  const size_t lds = (size_t)kTickBlock * W * 8;
+  const uint32_t per_thread = std::max(1u, ceil_div(S, kTickThreads));
+  if (per_thread <= 1) tick_launch<1, true>(c, a, lds);
+  else if (per_thread <= 2) tick_launch<2, true>(c, a, lds);
+  else if (per_thread <= 4) tick_launch<4, true>(c, a, lds);
+  else if (per_thread <= 8) tick_launch<8, false>(c, a, lds);
+  else tick_launch<16, false>(c, a, lds);
+  HIP_TRY(c, hipGetLastError());
+  mark(c, 7);
+
+  // The kernel's last store is the stamp; spin on it (a launch-to-stamp round trip is a third
+  // shorter than launch + hipStreamSynchronize). Never forever: the stream is asked now and then.
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      if (__atomic_load_n(&c->h_tick_done->seq, __ATOMIC_ACQUIRE) == a.seq) break;
+      if ((spins & 0xFFFF) == 0xFFFF) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(c, YDC_ERR_HIP, "the small-batch kernel failed: %s", hipGetErrorString(q));
+        if (q == hipSuccess && __atomic_load_n(&c->h_tick_done->seq, __ATOMIC_ACQUIRE) != a.seq)
+          return fail(c, YDC_ERR_HIP, "the small-batch kernel finished without its stamp");
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+          return fail(c, YDC_ERR_HIP, "no stamp from the small-batch kernel after 30 s");
+      }
+    }
+  }
+  if (io.out_on_device || (io.out_running && !io.out_on_device) || c->profiling)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (device outputs: complete when the call returns)
+  if (!io.out_on_device) {
+    if (N) std::memcpy(io.out_idx, c->h_tick_io + o_idx, (size_t)N * 4);
+    if (N && io.out_util) std::memcpy(io.out_util, c->h_tick_io + o_util, (size_t)N * 8);
+    if (io.out_running && S)
+      HIP_TRY(c, hipMemcpy(io.out_running, dev_run_out, (size_t)S * 4, hipMemcpyDeviceToHost));
+  }
+  ++c->tick_batches;
+  ydc_stats& st = c->stats;
+  std::memset(&st, 0, sizeof(st));
+  st.n_tasks = N;
+  st.n_servants = S;
+  st.n_classes = C;
+  st.key_bits = c->kf.key_bits;
+  st.n_chunks = 1;
+  st.rounds = 1;
+  st.chunk_sims = 1;
+  st.small_batch = 1;
+  st.granted = c->h_tick_done->granted;
+  st.timeouts = c->h_tick_done->timeouts;
+  st.env_not_found = c->h_tick_done->env_not_found;
+  if (c->profiling) {
+    for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&st.stage_ms[i], c->ev[i], c->ev[i + 1]);
+    (void)hipEventElapsedTime(&st.stage_ms[YDC_STAGE_TOTAL], c->ev[0], c->ev[7]);
+    collect_kernel_profile(c);
+  }
+  return YDC_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t flags,
@@ -1902,6 +2132,23 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   if (c->pend_count && !c->pend[c->pend_head].rerun && c->pend[c->pend_head].active)
     return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (N && N <= c->opt_small_batch && d_out_idx && !c->host_in.active && !c->post_copy.bytes) {
+    // A handful of requests: one launch of the one-workgroup kernel (tick_kernel.h).
+    if (c->tables_dirty)
+      if (int rc = rebuild_tables(c)) return rc;
+    if (tick_takes(c, N)) {
+      TickCall io;
+      io.tasks = tk;
+      io.tasks_on_device = true;
+      io.n_tasks = N;
+      io.flags = flags;
+      io.out_idx = d_out_idx;
+      io.out_util = d_out_util;
+      io.out_running = d_out_running;
+      io.out_on_device = true;
+      return tick_run(c, io);
+    }
+  }
   BatchPlan p;
   if (int rc = plan_batch(c, N, &p)) return rc;
   uint32_t rounds = 0;
@@ -2043,6 +2290,25 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
   if (!c || (N && (!tk || !out_idx))) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (N && N <= c->opt_small_batch) {
+    // A handful of requests: one launch of the one-workgroup kernel, the requests as kernel
+    // arguments, the results stored to page-locked memory (tick_kernel.h).
+    if (c->max_tasks && N > c->max_tasks)
+      return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
+    if (c->pend_count) return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
+    if (c->tables_dirty)
+      if (int rc = rebuild_tables(c)) return rc;
+    if (tick_takes(c, N)) {
+      TickCall io;
+      io.tasks = tk;
+      io.n_tasks = N;
+      io.flags = flags;
+      io.out_idx = out_idx;
+      io.out_util = out_util;
+      io.out_running = out_running;
+      return tick_run(c, io);
+    }
+  }
   const uint32_t S = c->n_servants;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   // Page-locked caller buffers (ydc_host_register / ydc_host_alloc) are used as they are: the
@@ -2122,6 +2388,60 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
   if (out_running && S) std::memcpy(out_running, c->h_res + o_run, (size_t)S * 4);
   if (out_util && N) std::memcpy(out_util, c->h_res + o_util, (size_t)N * 8);
   return YDC_OK;
+}
+
+int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,
+                      const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
+                      const uint32_t* release_servant_idx, uint32_t n_rel, const ydc_task_soa* tasks,
+                      uint32_t n_tasks, uint32_t flags, uint32_t* out_servant_idx, double* out_utilization) {
+  if (!c || (n_upd && (!upd_idx || !upd_rows)) || (n_rel && !release_servant_idx) ||
+      (n_tasks && (!tasks || !out_servant_idx)))
+    return YDC_ERR_INVALID_ARGUMENT;
+  if (c->pend_count) return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
+  if (c->max_tasks && n_tasks > c->max_tasks)
+    return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", n_tasks, c->max_tasks);
+  HIP_TRY(c, hipSetDevice(c->device));
+  // Heartbeats that change structure (a new servant, other environments / version / host /
+  // capacity bound) take the general path, derived tables and all; so does a tick the kernel
+  // does not take (a large batch, a registry beyond its limits).
+  bool structural = false;
+  for (uint32_t i = 0; i < n_upd && !structural; ++i)
+    structural = row_is_structural(c, upd_idx[i], upd_rows[i], upd_env_masks, env_words, i);
+  if (!structural && c->tables_dirty)
+    if (int rc = rebuild_tables(c)) return rc;
+  const bool fast = !structural && tick_takes(c, n_tasks);
+  if (!fast) {
+    if (n_upd)
+      if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, upd_env_masks, env_words, n_upd)) return rc;
+    n_upd = 0;
+    if (c->tables_dirty)
+      if (int rc = rebuild_tables(c)) return rc;
+    if (!tick_takes(c, n_tasks)) {
+      if (n_rel)
+        if (int rc = ydc_release_slots(c, release_servant_idx, n_rel)) return rc;
+      if (!n_tasks) return YDC_OK;
+      return ydc_dispatch(c, tasks, n_tasks, flags, out_servant_idx, out_utilization, nullptr);
+    }
+  }
+  for (uint32_t i = 0; i < n_upd; ++i) {  // host mirror of the columns the rows replace
+    const uint32_t s = upd_idx[i];
+    c->h_nproc[s] = upd_rows[i].num_processors;
+    c->h_load[s] = upd_rows[i].current_load;
+    c->h_max_tasks[s] = upd_rows[i].max_tasks;
+    c->h_flags[s] = upd_rows[i].flags;
+  }
+  TickCall io;
+  io.tasks = tasks;
+  io.n_tasks = n_tasks;
+  io.upd_idx = upd_idx;
+  io.upd_rows = upd_rows;
+  io.n_upd = n_upd;
+  io.rel = release_servant_idx;
+  io.n_rel = n_rel;
+  io.flags = flags;
+  io.out_idx = out_servant_idx;
+  io.out_util = out_utilization;
+  return tick_run(c, io);
 }
 
 int ydc_host_register(void* p, size_t bytes) {

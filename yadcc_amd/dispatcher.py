@@ -40,7 +40,7 @@ class _RunningTask(C.Structure):
 
 class _TdStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("requests", "batches", "device_ns", "host_ns", "heartbeats",
-                                          "heartbeats_unchanged", "bookkeeper_rebuilds")]
+                                          "heartbeats_unchanged", "bookkeeper_rebuilds", "lease_pages")]
 
 
 def type_td_functions(L):
