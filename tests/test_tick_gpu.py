@@ -98,14 +98,21 @@ def test_beyond_the_kernels_registry_limits_falls_back(forced):
 
 
 def test_many_classes_and_wide_masks(forced):
-    """150 digests (3 mask words per servant), about one class per servant: mask rows of many words
-    in LDS; and past 2048 classes the batch pipeline takes over."""
+    """150 digests (3 mask words per servant), about one class per servant: an eligible-class mask
+    of many words in LDS; and past 4096 classes the batch pipeline takes over."""
     sv, tk = cases.random_case(seed=12, n_tasks=300, n_servants=900, n_envs=150, unknown_env_frac=0.02, self_frac=0.2)
     st = check(forced, sv, tk)
     assert st["n_classes"] > 256 and took_the_tick_kernel(st), st
     sv, tk = cases.random_case(seed=13, n_tasks=60, n_servants=3000, n_envs=150, self_frac=0.2)
     st = check(forced, sv, tk)
-    assert st["n_classes"] > 2048 and not took_the_tick_kernel(st), st
+    assert st["n_classes"] > 700 and took_the_tick_kernel(st), st
+    # every servant its own version: one class per servant
+    sv, tk = cases.random_case(seed=14, n_tasks=60, n_servants=4500, n_envs=3, self_frac=0.2)
+    sv["version"] = (20 + np.arange(4500)).astype(np.uint32)
+    sv["num_processors"][:] = 16
+    sv["max_tasks"][:] = 6
+    st = check(forced, sv, tk)
+    assert st["n_classes"] > 4096 and not took_the_tick_kernel(st), st
 
 
 @pytest.mark.parametrize("seed", range(6))

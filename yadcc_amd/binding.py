@@ -428,7 +428,8 @@ class Context:
         util = np.empty(n, np.float64) if want_util else None
         em = None
         if env_masks is not None:
-            em = np.ascontiguousarray(env_masks, dtype=np.uint64).reshape(len(ui), -1)
+            em = np.ascontiguousarray(env_masks, dtype=np.uint64)
+            em = em.reshape(len(ui), em.shape[-1] if em.ndim == 2 else max(1, em.size // max(1, len(ui))))
         self._check(lib().ydc_dispatch_tick(self._h, ui.ctypes.data, ur.ctypes.data,
                                             em.ctypes.data if em is not None else None,
                                             em.shape[1] if em is not None else 1, len(ui),

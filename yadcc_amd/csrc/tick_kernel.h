@@ -35,15 +35,12 @@
 
 namespace ydc {
 
-constexpr uint32_t kTickThreads = 1024;
-constexpr uint32_t kTickWaves = kTickThreads / 64;
-constexpr uint32_t kTickBlock = 64;          // requests staged (class masks built) at a time
+constexpr uint32_t kTickBlock = 64;          // results are flushed 64 requests at a time
 constexpr uint32_t kTickInlineTasks = 64;    // requests that travel as kernel arguments
 constexpr uint32_t kTickInlineUpd = 16;      // heartbeat rows ...
 constexpr uint32_t kTickInlineRel = 64;      // released grants ...
-constexpr uint32_t kTickMaxPerThread = 16;   // servants a thread keeps in registers
-constexpr uint32_t kTickMaxServants = kTickThreads * kTickMaxPerThread;
-constexpr uint32_t kTickMaxClasses = 2048;   // 64 requests x 32 mask words of LDS
+constexpr uint32_t kTickMaxServants = 16384;  // 1024 threads x 16 servants in registers
+constexpr uint32_t kTickMaxClasses = 4096;    // eligible-class mask of a request: 64 words of LDS
 constexpr uint64_t kTickNoKey = ~0ull;
 
 // The columns of a heartbeat that changes no structure (KeepServantAlive, task_dispatcher.cc:195-201).
@@ -85,294 +82,519 @@ struct TickArgs {
   uint32_t in_rel[kTickInlineRel];
 };
 
-// What travels through a reduction: the best candidate that is not on the requestor's host, and
-// the two lowest registry indexes among the candidates that are.
-struct TickCand {
-  uint32_t khi, klo, idx, own1, own2;
+// What travels through the common reduction: the best free eligible servant that is not on the
+// requestor's host — (key, registry index), first wins on equal keys.
+struct TickBest {
+  uint32_t khi, klo, idx;
+};
+// ... and through the rare one: the two lowest registry indexes among the free eligible servants
+// that ARE on the requestor's host (the first is `self`, task_dispatcher.cc:372-379).
+struct TickOwn {
+  uint32_t own1, own2;
 };
 
-__device__ __forceinline__ void tick_merge(TickCand& a, const TickCand& b) {
+__device__ __forceinline__ void tick_merge(TickBest& a, const TickBest& b) {
   const uint64_t ka = ((uint64_t)a.khi << 32) | a.klo, kb = ((uint64_t)b.khi << 32) | b.klo;
   const bool take = kb < ka || (kb == ka && b.idx < a.idx);
   a.khi = take ? b.khi : a.khi;
   a.klo = take ? b.klo : a.klo;
   a.idx = take ? b.idx : a.idx;
+}
+__device__ __forceinline__ void tick_merge(TickOwn& a, const TickOwn& b) {
   const uint32_t lo = min(a.own1, b.own1), hi = max(a.own1, b.own1);
   a.own2 = min(hi, min(a.own2, b.own2));
   a.own1 = lo;
 }
 
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void tick_dpp_step(TickCand& c) {
-  TickCand o;
+__device__ __forceinline__ void tick_dpp_step(TickBest& c) {
+  TickBest o;
   o.khi = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.khi);
   o.klo = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.klo);
   o.idx = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.idx);
+  tick_merge(c, o);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void tick_dpp_step(TickOwn& c) {
+  TickOwn o;
   o.own1 = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.own1);
   o.own2 = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.own2);
   tick_merge(c, o);
 }
 
-// Lane 15 of every row ends up with its row's result (disjoint ranges: nothing is merged twice,
-// which the "two lowest" part relies on).
-__device__ __forceinline__ void tick_row_reduce(TickCand& c) {
-  tick_dpp_step<0x111, 0xf>(c);  // row_shr:1
-  tick_dpp_step<0x112, 0xf>(c);  // row_shr:2
-  tick_dpp_step<0x114, 0xf>(c);  // row_shr:4
-  tick_dpp_step<0x118, 0xf>(c);  // row_shr:8
+// Inclusive scan steps inside a row of 16 lanes: lane n - 1 ends up with the result of lanes
+// 0 .. n - 1 (disjoint ranges: nothing is merged twice, which the "two lowest" merge relies on).
+template <int N, class T>
+__device__ __forceinline__ void tick_row_reduce(T& c) {
+  if (N > 1) tick_dpp_step<0x111, 0xf>(c);  // row_shr:1
+  if (N > 2) tick_dpp_step<0x112, 0xf>(c);  // row_shr:2
+  if (N > 4) tick_dpp_step<0x114, 0xf>(c);  // row_shr:4
+  if (N > 8) tick_dpp_step<0x118, 0xf>(c);  // row_shr:8
 }
 
-__device__ __forceinline__ TickCand tick_readlane(const TickCand& c, int lane) {
-  TickCand r;
-  r.khi = (uint32_t)__builtin_amdgcn_readlane((int)c.khi, lane);
-  r.klo = (uint32_t)__builtin_amdgcn_readlane((int)c.klo, lane);
-  r.idx = (uint32_t)__builtin_amdgcn_readlane((int)c.idx, lane);
-  r.own1 = (uint32_t)__builtin_amdgcn_readlane((int)c.own1, lane);
-  r.own2 = (uint32_t)__builtin_amdgcn_readlane((int)c.own2, lane);
-  return r;
+// A workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every global
+// store in flight (vmcnt(0)) — the winner's `++running_tasks` store of the pick before would be
+// waited for by every pick (measured: 2 us per pick instead of 0.4).
+__device__ __forceinline__ void tick_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// The workgroup's result, the same in every thread. `part` = 5 x 16 words of LDS that nobody else
-// touches until two reductions later (the caller alternates between two of them).
-__device__ __forceinline__ TickCand tick_block_reduce(TickCand c, uint32_t* part) {
+__device__ __forceinline__ uint32_t tick_rl(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// The workgroup's result, the same in every thread. `part`: 3 x 16 (2 x 16) words of LDS that
+// nobody else touches until two reductions later (the callers alternate between two of them).
+template <int WAVES>
+__device__ __forceinline__ TickBest tick_block_reduce(TickBest c, uint32_t* part) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  tick_row_reduce(c);
+  tick_row_reduce<16>(c);
   tick_dpp_step<0x142, 0xa>(c);  // row_bcast:15
   tick_dpp_step<0x143, 0xc>(c);  // row_bcast:31
   if (lane == 63) {
     part[wave] = c.khi;
     part[16 + wave] = c.klo;
     part[32 + wave] = c.idx;
-    part[48 + wave] = c.own1;
-    part[64 + wave] = c.own2;
   }
-  __syncthreads();
-  TickCand w{0xFFFFFFFFu, 0xFFFFFFFFu, kNone, kNone, kNone};
-  if (lane < kTickWaves) {
+  tick_lds_barrier();
+  TickBest w{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+  if (lane < WAVES) {
     w.khi = part[lane];
     w.klo = part[16 + lane];
     w.idx = part[32 + lane];
-    w.own1 = part[48 + lane];
-    w.own2 = part[64 + lane];
   }
-  tick_row_reduce(w);
-  return tick_readlane(w, 15);
+  tick_row_reduce<WAVES>(w);
+  return TickBest{tick_rl(w.khi, WAVES - 1), tick_rl(w.klo, WAVES - 1), tick_rl(w.idx, WAVES - 1)};
+}
+template <int WAVES>
+__device__ __forceinline__ TickOwn tick_block_reduce(TickOwn c, uint32_t* part) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  tick_row_reduce<16>(c);
+  tick_dpp_step<0x142, 0xa>(c);
+  tick_dpp_step<0x143, 0xc>(c);
+  if (lane == 63) {
+    part[wave] = c.own1;
+    part[16 + wave] = c.own2;
+  }
+  tick_lds_barrier();
+  TickOwn w{kNone, kNone};
+  if (lane < WAVES) {
+    w.own1 = part[lane];
+    w.own2 = part[16 + lane];
+  }
+  tick_row_reduce<WAVES>(w);
+  return TickOwn{tick_rl(w.own1, WAVES - 1), tick_rl(w.own2, WAVES - 1)};
 }
 
-// Key of servant state (dispatch_core.h closed forms; the fp64 key is the reference's own compare).
+// Key of a servant's state (dispatch_core.h closed forms; the fp64 key is the reference's own compare).
 __device__ __forceinline__ uint64_t tick_key(uint32_t nproc, uint32_t load, uint32_t max_tasks,
                                              uint32_t flags, uint32_t r, bool in_class) {
   if (!in_class || servant_slot_count(nproc, load, max_tasks, r, flags) == 0) return kTickNoKey;
   return slot_key_fp64(slot_tier(nproc, flags, r), r, slot_capacity(nproc, load, max_tasks, r));
 }
 
-// K: servants per thread (servant k * 1024 + t is slot k of thread t). COLD: the columns a key is
-// recomputed from stay in registers too (K <= 4); otherwise the winner's thread reads them again.
-template <int K, bool COLD>
-__global__ __launch_bounds__(kTickThreads) void k_tick(const TickArgs a) {
-  extern __shared__ uint64_t s_mask[];  // [kTickBlock][W]
-  __shared__ uint32_t s_env[kTickBlock], s_minv[kTickBlock], s_rip[kTickBlock], s_out[kTickBlock];
-  __shared__ uint32_t s_any[kTickBlock];
-  __shared__ double s_util[kTickBlock];
-  __shared__ uint32_t s_part[2][80];
-  const uint32_t t = threadIdx.x, lane = t & 63;
-  const uint32_t S = a.S, W = a.W;
+// THREADS x K >= S: servant k * THREADS + t is slot k of thread t. As few waves as hold the
+// registry: what a pick costs is the reduction, and every wave of a SIMD pays it again (measured:
+// 1024 threads x 2 servants 1.7 us per pick, the issue slots of 4 waves per SIMD). COLD: the
+// columns a key is recomputed from stay in registers too; otherwise the owner reads them again.
+// No global store and (COLD) no global load sits inside the pick loop: the compiler's wait-count
+// bookkeeping makes every pick wait for the stores of the pick before as soon as the loop touches a
+// register that was once loaded (measured: 2 us per pick) — running_tasks goes back at the end.
+#ifdef YDC_PHASE_PROBE
+// Measurement build (`make probe`, tools/tick_probe.py): thread 0 leaves the 100 MHz wall clock at
+// the kernel's phase boundaries in ydc_phase_probe[0 .. 31].
+#define YDC_TICK_STAMP(slot)                                         \
+  do {                                                               \
+    if (threadIdx.x == 0) ydc_phase_probe[slot] = wall_clock64();    \
+  } while (0)
+#else
+#define YDC_TICK_STAMP(slot) \
+  do {                       \
+  } while (0)
+#endif
 
-  // ---- registry deltas first: heartbeat rows, released grants ----
-  if (a.n_upd | a.n_rel) {
-    for (uint32_t u = t; u < a.n_upd; u += kTickThreads) {
-      const uint32_t s = a.upd_idx ? a.upd_idx[u] : a.in_upd_idx[u];
-      const TickRow r = a.upd_rows ? a.upd_rows[u] : a.in_upd[u];
-      if (s < S) {
-        a.nproc[s] = r.nproc;
-        a.load[s] = r.load;
-        a.max_tasks[s] = r.max_tasks;
-        a.flags[s] = r.flags;
+template <int THREADS, int K, bool COLD>
+__global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int G = K < 8 ? K : 8;  // servants whose columns are in flight together
+  extern __shared__ uint64_t s_mask[];  // [W]: eligible classes of the current request signature
+  __shared__ uint32_t s_out[kTickBlock];
+  __shared__ double s_util[kTickBlock];
+  __shared__ uint32_t s_part[2][48], s_part_own[2][32];
+  __shared__ uint32_t s_own_flag[3];
+  // The payload that travels as kernel arguments, staged once: the argument segment may live in
+  // host memory, where every scalar load of it is a PCIe round trip.
+  __shared__ uint32_t s_env[kTickBlock], s_minv[kTickBlock], s_rip[kTickBlock];
+  __shared__ uint32_t s_rel[kTickInlineRel], s_uidx[kTickInlineUpd];
+  __shared__ TickRow s_urow[kTickInlineUpd];
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  YDC_TICK_STAMP(0);
+  // Everything the kernel reads from the head of its argument block, fetched in ONE go (the
+  // compiler would fetch each field where it is first needed: a dozen dependent round trips).
+  uint32_t* const p_nproc = a.nproc;
+  uint32_t* const p_load = a.load;
+  uint32_t* const p_maxt = a.max_tasks;
+  uint32_t* const p_flags = a.flags;
+  const uint32_t* const p_class_of = a.class_of;
+  const uint32_t* const p_ip = a.ip;
+  uint32_t* const p_running = a.running;
+  uint32_t* const p_rw = a.rw;
+  uint32_t* const p_run_out = a.run_out;
+  const uint64_t* const p_cls_env = a.cls_env;
+  const uint32_t* const p_cls_ver = a.cls_ver;
+  const uint32_t S = a.S, C = a.C, EW = a.EW, W = a.W, n_tasks = a.n_tasks, n_upd = a.n_upd, n_rel = a.n_rel;
+  const uint32_t *const p_tenv = a.t_env, *const p_tminv = a.t_minv, *const p_trip = a.t_rip;
+  const uint32_t* const p_upd_idx = a.upd_idx;
+  const TickRow* const p_upd_rows = a.upd_rows;
+  const uint32_t* const p_rel = a.rel;
+  uint32_t* const p_out_idx = a.out_idx;
+  double* const p_out_util = a.out_util;
+  TickDone* const p_done = a.done;
+  const uint32_t seq = a.seq;
+  asm volatile("" ::"s"(p_nproc), "s"(p_load), "s"(p_maxt), "s"(p_flags), "s"(p_class_of), "s"(p_ip),
+               "s"(p_running), "s"(p_rw), "s"(p_run_out), "s"(p_cls_env), "s"(p_cls_ver));
+  asm volatile("" ::"s"(S), "s"(C), "s"(EW), "s"(W), "s"(n_tasks), "s"(n_upd), "s"(n_rel), "s"(p_tenv),
+               "s"(p_tminv), "s"(p_trip), "s"(p_upd_idx), "s"(p_upd_rows), "s"(p_rel), "s"(p_out_idx),
+               "s"(p_out_util), "s"(p_done), "s"(seq));
+  YDC_TICK_STAMP(1);
+  if (t < 3) s_own_flag[t] = 0;
+  if (t < kTickBlock) {
+    if (!p_tenv && t < n_tasks) {
+      s_env[t] = a.in_env[t];
+      s_minv[t] = a.in_minv[t];
+      s_rip[t] = a.in_rip[t];
+    }
+    if (!p_rel && t < n_rel) s_rel[t] = a.in_rel[t];
+    if (!p_upd_idx && t < n_upd) {
+      s_uidx[t] = a.in_upd_idx[t];
+      s_urow[t] = a.in_upd[t];
+    }
+  }
+
+  // ---- long delta lists (beyond what travels as arguments): applied to the columns first ----
+  if ((p_upd_idx && n_upd) || (p_rel && n_rel)) {
+    if (p_upd_idx)
+      for (uint32_t u = t; u < n_upd; u += THREADS) {
+        const uint32_t s = p_upd_idx[u];
+        const TickRow r = p_upd_rows[u];
+        if (s < S) {
+          p_nproc[s] = r.nproc;
+          p_load[s] = r.load;
+          p_maxt[s] = r.max_tasks;
+          p_flags[s] = r.flags;
+        }
       }
-    }
-    for (uint32_t j = t; j < a.n_rel; j += kTickThreads) {
-      const uint32_t s = a.rel ? a.rel[j] : a.in_rel[j];
-      if (s < S) atomicSub(&a.running[s], 1u);
-    }
+    if (p_rel)
+      for (uint32_t j = t; j < n_rel; j += THREADS) {
+        const uint32_t s = p_rel[j];
+        if (s < S) atomicSub(&p_running[s], 1u);
+      }
     __syncthreads();  // (stores and atomics have reached the L2 this workgroup reads from)
   }
 
-  // ---- the registry into registers ----
+  // ---- the registry into registers: G servants' columns in flight at a time ----
   uint64_t key[K];
-  uint32_t cls[K], ip[K];
-  uint32_t c_nproc[COLD ? K : 1], c_load[COLD ? K : 1], c_maxt[COLD ? K : 1], c_flags[COLD ? K : 1],
-      c_run[COLD ? K : 1];
-  const bool copy_run = a.rw != a.running;
+  uint32_t cls[K], ip[K], c_run[K];
+  uint32_t c_nproc[COLD ? K : 1], c_load[COLD ? K : 1], c_maxt[COLD ? K : 1], c_flags[COLD ? K : 1];
+  uint32_t in_cls = 0;   // bit k: servant k of this thread accepts tasks at all (max_tasks != 0)
+  uint32_t changed = 0;  // bit k: running_tasks of servant k is to be written back
+  const bool copy_run = p_rw != p_running;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const uint32_t s = (uint32_t)k * kTickThreads + t;
-    key[k] = kTickNoKey;
-    cls[k] = 0;
-    ip[k] = 0;
-    if (COLD) c_nproc[k] = c_load[k] = c_maxt[k] = c_flags[k] = c_run[k] = 0;
-    if (s < S) {
-      const uint32_t np = a.nproc[s], ld = a.load[s], mt = a.max_tasks[s], fl = a.flags[s],
-                     r = a.running[s], co = a.class_of[s];
-      ip[k] = a.ip[s];
-      cls[k] = co == kNone ? 0u : co;
-      key[k] = tick_key(np, ld, mt, fl, r, co != kNone);
-      if (copy_run) a.rw[s] = r;
+  for (int g = 0; g < K; g += G) {
+    uint32_t l_np[G], l_ld[G], l_mt[G], l_fl[G], l_r[G], l_co[G], l_ip[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const uint32_t s = (uint32_t)(g + j) * THREADS + t, sc = s < S ? s : 0;  // (S == 0: nothing is read)
+      l_np[j] = l_ld[j] = l_mt[j] = l_fl[j] = l_r[j] = l_ip[j] = 0;
+      l_co[j] = kNone;
+      if (S) {
+        l_np[j] = p_nproc[sc];
+        l_ld[j] = p_load[sc];
+        l_mt[j] = p_maxt[sc];
+        l_fl[j] = p_flags[sc];
+        l_r[j] = p_running[sc];
+        l_co[j] = p_class_of[sc];
+        l_ip[j] = p_ip[sc];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int k = g + j;
+      const uint32_t s = (uint32_t)k * THREADS + t;
+      const bool live = s < S, inc = live && l_co[j] != kNone;
+      ip[k] = live ? l_ip[j] : 0u;
+      cls[k] = inc ? l_co[j] : 0u;
+      in_cls |= (inc ? 1u : 0u) << k;
+      c_run[k] = l_r[j];
+      key[k] = tick_key(l_np[j], l_ld[j], l_mt[j], l_fl[j], l_r[j], inc);
       if (COLD) {
-        c_nproc[k] = np;
-        c_load[k] = ld;
-        c_maxt[k] = mt;
-        c_flags[k] = fl | (co != kNone ? 0x80000000u : 0u);
-        c_run[k] = r;
+        c_nproc[k] = l_np[j];
+        c_load[k] = l_ld[j];
+        c_maxt[k] = l_mt[j];
+        c_flags[k] = l_fl[j];
       }
+      if (copy_run && live) p_rw[s] = l_r[j];
     }
   }
+  YDC_TICK_STAMP(2);
+  tick_lds_barrier();  // (the staged arguments)
+  YDC_TICK_STAMP(3);
 
-  uint32_t n_granted = 0, n_timeout = 0, n_envnf = 0;  // (thread 0's are reported)
-  uint32_t red = 0;                                     // reductions so far (buffer parity)
-
-  for (uint32_t base = 0; base < a.n_tasks; base += kTickBlock) {
-    const uint32_t nb = min(kTickBlock, a.n_tasks - base);
-    if (t < nb) {
-      s_env[t] = a.t_env ? a.t_env[base + t] : a.in_env[base + t];
-      s_minv[t] = a.t_env ? a.t_minv[base + t] : a.in_minv[base + t];
-      s_rip[t] = a.t_env ? a.t_rip[base + t] : a.in_rip[base + t];
-    }
-    __syncthreads();
-    // Class masks of the block: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
-    {
-      const uint32_t cpad = W * 64, total = nb * cpad;
-      for (uint32_t j = t; j < total; j += kTickThreads) {  // (whole waves: total is a multiple of 64)
-        const uint32_t i = j / cpad, c = j - i * cpad;
-        const uint32_t env = s_env[i];
-        bool bit = false;
-        if (c < a.C && env < 64 * a.EW)
-          bit = ((a.cls_env[(size_t)c * a.EW + (env >> 6)] >> (env & 63)) & 1u) && a.cls_ver[c] >= s_minv[i];
-        const uint64_t word = __ballot(bit);
-        if (lane == 0) s_mask[i * W + (c >> 6)] = word;
+  // ---- short delta lists travel as arguments: the owner patches its registers ----
+  // Heartbeat rows: the columns first (stores only), then the registers.
+  if (!p_upd_idx && n_upd) {
+    for (uint32_t u = 0; u < n_upd; ++u) {
+      const uint32_t s = s_uidx[u];
+      if (s < S && s % THREADS == t) {
+        const TickRow r = s_urow[u];
+        p_nproc[s] = r.nproc;
+        p_load[s] = r.load;
+        p_maxt[s] = r.max_tasks;
+        p_flags[s] = r.flags;
       }
     }
-    __syncthreads();
-    if (t < nb) {
-      uint64_t any = 0;
-      for (uint32_t w = 0; w < W; ++w) any |= s_mask[t * W + w];
-      s_any[t] = any != 0;
-    }
-    __syncthreads();
-
-    for (uint32_t i = 0; i < nb; ++i) {
-      if (!s_any[i]) {  // nobody advertises the environment at that version: :105-108
-        if (t == 0) {
-          s_out[i] = kIdxEnvNotFound;
-          s_util[i] = -1.0;
-        }
-        ++n_envnf;
-        continue;
-      }
-      const uint32_t rip = s_rip[i];
-      const uint64_t* mrow = s_mask + i * W;
-      const uint64_t m0 = mrow[0];
-      TickCand mine{0xFFFFFFFFu, 0xFFFFFFFFu, kNone, kNone, kNone};
-      uint64_t bk = kTickNoKey;
+    for (uint32_t u = 0; u < n_upd; ++u) {
+      const uint32_t s = s_uidx[u];
+      if (s < S && s % THREADS == t) {
+        const TickRow r = s_urow[u];
+        const uint32_t wk = s / THREADS;
+        uint32_t run = 0;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (key[k] == kTickNoKey) continue;
-        const uint64_t m = W == 1 ? m0 : mrow[cls[k] >> 6];
-        if (!((m >> (cls[k] & 63)) & 1u)) continue;
-        const uint32_t s = (uint32_t)k * kTickThreads + t;
-        if (ip[k] == rip) {  // a candidate on the requestor's own host (ascending s: first, second)
-          if (mine.own1 == kNone) mine.own1 = s;
-          else if (mine.own2 == kNone) mine.own2 = s;
-        } else if (key[k] < bk) {
-          bk = key[k];
-          mine.idx = s;
-        }
-      }
-      mine.khi = (uint32_t)(bk >> 32);
-      mine.klo = (uint32_t)bk;
-      TickCand best = tick_block_reduce(mine, s_part[red++ & 1]);
-      if (best.own2 != kNone) {
-        // Several eligible free servants on the requestor's host: only the first of them is `self`
-        // (:372-379), the others compete like everybody else.
-        TickCand again{0xFFFFFFFFu, 0xFFFFFFFFu, kNone, kNone, kNone};
-        bk = kTickNoKey;
+        for (int k = 0; k < K; ++k) run = (uint32_t)k == wk ? c_run[k] : run;
+        const uint64_t nk = tick_key(r.nproc, r.load, r.max_tasks, r.flags, run, (in_cls >> wk) & 1u);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          if (key[k] == kTickNoKey) continue;
-          const uint64_t m = W == 1 ? m0 : mrow[cls[k] >> 6];
-          if (!((m >> (cls[k] & 63)) & 1u)) continue;
-          const uint32_t s = (uint32_t)k * kTickThreads + t;
-          if (s != best.own1 && key[k] < bk) {
-            bk = key[k];
-            again.idx = s;
-          }
-        }
-        again.khi = (uint32_t)(bk >> 32);
-        again.klo = (uint32_t)bk;
-        const TickCand b2 = tick_block_reduce(again, s_part[red++ & 1]);
-        best.khi = b2.khi;
-        best.klo = b2.klo;
-        best.idx = b2.idx;
-      }
-      const uint32_t winner = best.idx != kNone ? best.idx : best.own1;  // :392-396
-      if (winner == kNone) {  // eligible servants exist, none is free: Timeout with timeout == now (:116-118)
-        if (t == 0) {
-          s_out[i] = kIdxTimeout;
-          s_util[i] = -1.0;
-        }
-        ++n_timeout;
-        continue;
-      }
-      ++n_granted;
-      if ((winner & (kTickThreads - 1)) == t) {
-        const uint32_t wk = winner / kTickThreads;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          if ((uint32_t)k != wk) continue;
-          s_out[i] = winner;
-          s_util[i] = __longlong_as_double((long long)(key[k] & 0x7FFFFFFFFFFFFFFFull));
-          uint32_t np, ld, mt, fl, r;
+          const bool me = (uint32_t)k == wk;
+          key[k] = me ? nk : key[k];
           if (COLD) {
-            np = c_nproc[k];
-            ld = c_load[k];
-            mt = c_maxt[k];
-            fl = c_flags[k];
-            r = c_run[k] + 1;
-            c_run[k] = r;
-          } else {
-            np = a.nproc[winner];
-            ld = a.load[winner];
-            mt = a.max_tasks[winner];
-            fl = a.flags[winner];
-            r = a.rw[winner] + 1;
+            c_nproc[k] = me ? r.nproc : c_nproc[k];
+            c_load[k] = me ? r.load : c_load[k];
+            c_maxt[k] = me ? r.max_tasks : c_maxt[k];
+            c_flags[k] = me ? r.flags : c_flags[k];
           }
-          a.rw[winner] = r;  // ++pick->running_tasks (:123)
-          key[k] = tick_key(np, ld, mt, fl & 3u, r, true);
         }
       }
     }
-    __syncthreads();
-    if (t < nb) {
-      a.out_idx[base + t] = s_out[t];
-      if (a.out_util) a.out_util[base + t] = s_util[t];
-    }
-    // (the next block's staging writes s_env / s_mask: every read of this block is behind the barrier above)
   }
-
-  if (a.run_out) {
+  // Released grants: FreeTask's --running_tasks (:181). This thread is the only one that knows servant s.
+  if (!p_rel && n_rel) {
+    for (uint32_t j = 0; j < n_rel; ++j) {
+      const uint32_t s = s_rel[j];
+      if (s < S && s % THREADS == t) {
+        const uint32_t wk = s / THREADS;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if ((uint32_t)k == wk) {
+            c_run[k] -= 1;
+            changed |= 1u << k;
+          }
+      }
+    }
+    // (one key per touched servant, whatever the number of its released grants)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t s = (uint32_t)k * kTickThreads + t;
-      if (s < S) a.run_out[s] = COLD ? c_run[k] : a.rw[s];
+      if (!((changed >> k) & 1u)) continue;
+      const uint32_t s = (uint32_t)k * THREADS + t;
+      uint32_t np, ld, mt, fl;
+      if (COLD) {
+        np = c_nproc[k];
+        ld = c_load[k];
+        mt = c_maxt[k];
+        fl = c_flags[k];
+      } else {  // (after this thread's own row stores above: same thread, same address)
+        np = p_nproc[s];
+        ld = p_load[s];
+        mt = p_maxt[s];
+        fl = p_flags[s];
+      }
+      key[k] = tick_key(np, ld, mt, fl, c_run[k], (in_cls >> k) & 1u);
     }
   }
+
+  YDC_TICK_STAMP(4);
+  uint32_t n_granted = 0, n_timeout = 0, n_envnf = 0;  // (thread 0's are reported)
+  uint32_t red = 0, pk = 0;  // reductions / picks so far (LDS buffer rotation)
+  // The request signature (digest, version threshold, requestor) the cached values below belong to:
+  // one RPC's requests share it (scheduler_service_impl.cc:228-264), so it rarely changes inside a call.
+  uint32_t p_env = 0, p_minv = 0, p_rip = 0;
+  bool have_sig = false, any = false, dirty = true;
+  uint32_t elig = 0, ownb = 0;  // bit k: servant k is eligible for / on the host of the signature
+  TickBest mine{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+  TickOwn mine_own{kNone, kNone};
+  for (uint32_t i = 0; i < n_tasks; ++i) {
+    const uint32_t oi = i & (kTickBlock - 1);
+    if (p_tenv && oi == 0) {  // the next 64 requests' columns (device or mapped host memory)
+      if (t < kTickBlock && i + t < n_tasks) {
+        s_env[t] = p_tenv[i + t];
+        s_minv[t] = p_tminv[i + t];
+        s_rip[t] = p_trip[i + t];
+      }
+      tick_lds_barrier();
+    }
+    // (the same in every thread: say so, the barriers and ballots below sit behind tests of them)
+    const uint32_t env = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[oi]),
+                   minv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[oi]),
+                   rip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[oi]);
+    if (!have_sig || env != p_env || minv != p_minv || rip != p_rip) {
+      have_sig = true;
+      p_env = env;
+      p_minv = minv;
+      p_rip = rip;
+      // Eligible classes: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
+      for (uint32_t c = t; c < W * 64; c += THREADS) {  // (whole waves)
+        bool bit = false;
+        if (c < C && env < 64 * EW)
+          bit = ((p_cls_env[(size_t)c * EW + (env >> 6)] >> (env & 63)) & 1u) && p_cls_ver[c] >= minv;
+        const uint64_t word = __ballot(bit);
+        if (lane == 0) s_mask[c >> 6] = word;
+      }
+      tick_lds_barrier();
+      uint64_t any_w = 0;
+      for (uint32_t w = 0; w < W; ++w) any_w |= s_mask[w];
+      any = any_w != 0;
+      elig = ownb = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint64_t m = s_mask[cls[k] >> 6];
+        elig |= (uint32_t)((m >> (cls[k] & 63)) & ((in_cls >> k) & 1u)) << k;
+        ownb |= (ip[k] == rip ? 1u : 0u) << k;
+      }
+      dirty = true;
+      tick_lds_barrier();  // (s_mask is rewritten at the next change of signature)
+      if (i == 0) YDC_TICK_STAMP(5);
+    }
+    if (!any) {  // nobody advertises the environment at that version: :105-108
+      if (t == 0) {
+        s_out[oi] = kIdxEnvNotFound;
+        s_util[oi] = -1.0;
+      }
+      ++n_envnf;
+    } else {
+      if (dirty) {  // this thread's candidates: its state (or the signature) changed
+        uint64_t bk = kTickNoKey;
+        mine.idx = mine_own.own1 = mine_own.own2 = kNone;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+          const uint32_t s = (uint32_t)k * THREADS + t;
+          if ((ownb >> k) & 1u) {  // on the requestor's own host (ascending s: first, second)
+            if (mine_own.own1 == kNone) mine_own.own1 = s;
+            else if (mine_own.own2 == kNone) mine_own.own2 = s;
+          } else if (key[k] < bk) {
+            bk = key[k];
+            mine.idx = s;
+          }
+        }
+        mine.khi = (uint32_t)(bk >> 32);
+        mine.klo = (uint32_t)bk;
+        dirty = false;
+      }
+      if (i == 2) YDC_TICK_STAMP(24);
+      // Own-host candidates are rare: a flag says whether the second reduction is needed at all.
+      const uint32_t fl_i = pk % 3;
+      if (__ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
+      TickBest best = tick_block_reduce<WAVES>(mine, s_part[red++ & 1]);
+      if (i == 2) YDC_TICK_STAMP(25);
+      const bool own_any = s_own_flag[fl_i] != 0;
+      if (t == 0) s_own_flag[(pk + 2) % 3] = 0;
+      ++pk;
+      TickOwn own{kNone, kNone};
+      if (own_any) {
+        own = tick_block_reduce<WAVES>(mine_own, s_part_own[red++ & 1]);
+        if (own.own2 != kNone) {
+          // Several eligible free servants on the requestor's host: only the first of them is
+          // `self` (:372-379), the others compete like everybody else.
+          TickBest again{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+          uint64_t bk = kTickNoKey;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+            const uint32_t s = (uint32_t)k * THREADS + t;
+            if (s != own.own1 && key[k] < bk) {
+              bk = key[k];
+              again.idx = s;
+            }
+          }
+          again.khi = (uint32_t)(bk >> 32);
+          again.klo = (uint32_t)bk;
+          best = tick_block_reduce<WAVES>(again, s_part[red++ & 1]);
+        }
+      }
+      if (i == 2) YDC_TICK_STAMP(26);
+      const uint32_t winner = best.idx != kNone ? best.idx : own.own1;  // :392-396
+      if (winner == kNone) {  // eligible servants exist, none is free: Timeout with timeout == now (:116-118)
+        if (t == 0) {
+          s_out[oi] = kIdxTimeout;
+          s_util[oi] = -1.0;
+        }
+        ++n_timeout;
+      } else {
+        ++n_granted;
+        if (winner % THREADS == t) {
+          const uint32_t wk = winner / THREADS;
+          uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
+          uint64_t kw = 0;
+          if (!COLD) {
+            np = p_nproc[winner];
+            ld = p_load[winner];
+            mt = p_maxt[winner];
+            fl = p_flags[winner];
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) {  // (selects, not branches: the key is computed once below)
+            const bool me = (uint32_t)k == wk;
+            kw = me ? key[k] : kw;
+            run = me ? c_run[k] : run;
+            if (COLD) {
+              np = me ? c_nproc[k] : np;
+              ld = me ? c_load[k] : ld;
+              mt = me ? c_maxt[k] : mt;
+              fl = me ? c_flags[k] : fl;
+            }
+          }
+          s_out[oi] = winner;
+          s_util[oi] = __longlong_as_double((long long)(kw & 0x7FFFFFFFFFFFFFFFull));
+          run += 1;  // ++pick->running_tasks (:123); written back at the end
+          const uint64_t nk = tick_key(np, ld, mt, fl, run, true);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool me = (uint32_t)k == wk;
+            key[k] = me ? nk : key[k];
+            c_run[k] = me ? run : c_run[k];
+          }
+          changed |= 1u << wk;
+          dirty = true;
+        }
+      }
+    }
+    if (i < 16) YDC_TICK_STAMP(8 + i);  // (pick i done)
+    if (oi == kTickBlock - 1 || i + 1 == n_tasks) {
+      tick_lds_barrier();
+      const uint32_t first = i - oi;
+      if (t <= oi) {
+        p_out_idx[first + t] = s_out[t];
+        if (p_out_util) p_out_util[first + t] = s_util[t];
+      }
+    }
+  }
+
+  // running_tasks goes back: the servants this call touched (released grants, picks).
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t s = (uint32_t)k * THREADS + t;
+    if ((changed >> k) & 1u) p_rw[s] = c_run[k];
+    if (p_run_out && s < S) p_run_out[s] = c_run[k];
+  }
   // Results first, then the stamp the host spins on.
+  YDC_TICK_STAMP(6);
   __threadfence_system();
   __syncthreads();
+  YDC_TICK_STAMP(7);
   if (t == 0) {
-    a.done->granted = n_granted;
-    a.done->timeouts = n_timeout;
-    a.done->env_not_found = n_envnf;
-    __hip_atomic_store(&a.done->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    p_done->granted = n_granted;
+    p_done->timeouts = n_timeout;
+    p_done->env_not_found = n_envnf;
+    __hip_atomic_store(&p_done->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

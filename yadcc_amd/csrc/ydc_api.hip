@@ -1957,9 +1957,9 @@ struct TickCall {
   bool out_on_device = false;
 };
 
-template <int K, bool COLD>
+template <int THREADS, int K, bool COLD>
 void tick_launch(ydc_context* c, const TickArgs& a, size_t lds) {
-  YDC_LAUNCH(c, "k_tick", (k_tick<K, COLD>), dim3(1), dim3(kTickThreads), lds, c->stream, a);
+  YDC_LAUNCH(c, "k_tick", (k_tick<THREADS, K, COLD>), dim3(1), dim3(THREADS), lds, c->stream, a);
 }
 
 int tick_run(ydc_context* c, const TickCall& io) {
@@ -2063,13 +2063,17 @@ int tick_run(ydc_context* c, const TickCall& io) {
     c->ksamples_used = 0;
     for (int s = 0; s <= 6; ++s) mark(c, s);
   }
-  const size_t lds = (size_t)kTickBlock * W * 8;
-  const uint32_t per_thread = std::max(1u, ceil_div(S, kTickThreads));
-  if (per_thread <= 1) tick_launch<1, true>(c, a, lds);
-  else if (per_thread <= 2) tick_launch<2, true>(c, a, lds);
-  else if (per_thread <= 4) tick_launch<4, true>(c, a, lds);
-  else if (per_thread <= 8) tick_launch<8, false>(c, a, lds);
-  else tick_launch<16, false>(c, a, lds);
+  // As few waves as hold the registry in registers, at most 16 servants per thread
+  // (tick_kernel.h): 256 threads up to 4096 servants, 512 up to 8192, 1024 beyond.
+  const size_t lds = (size_t)W * 8;
+  const uint32_t per_thread = std::max(1u, ceil_div(S, 256u));
+  if (per_thread <= 1) tick_launch<256, 1, true>(c, a, lds);
+  else if (per_thread <= 2) tick_launch<256, 2, true>(c, a, lds);
+  else if (per_thread <= 4) tick_launch<256, 4, true>(c, a, lds);
+  else if (per_thread <= 8) tick_launch<256, 8, true>(c, a, lds);
+  else if (per_thread <= 16) tick_launch<256, 16, true>(c, a, lds);
+  else if (per_thread <= 32) tick_launch<512, 16, true>(c, a, lds);
+  else tick_launch<1024, 16, false>(c, a, lds);
   HIP_TRY(c, hipGetLastError());
   mark(c, 7);
 
@@ -2409,14 +2413,17 @@ int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant
     structural = row_is_structural(c, upd_idx[i], upd_rows[i], upd_env_masks, env_words, i);
   if (!structural && c->tables_dirty)
     if (int rc = rebuild_tables(c)) return rc;
-  const bool fast = !structural && tick_takes(c, n_tasks);
+  // (registry deltas ride in the launch only with COMMIT: running_tasks goes back once, into the
+  // column the picks work on)
+  const bool fast = !structural && tick_takes(c, n_tasks) &&
+                    ((flags & YDC_DISPATCH_COMMIT) || (!n_upd && !n_rel));
   if (!fast) {
     if (n_upd)
       if (int rc = ydc_update_servants_wide(c, upd_idx, upd_rows, upd_env_masks, env_words, n_upd)) return rc;
     n_upd = 0;
     if (c->tables_dirty)
       if (int rc = rebuild_tables(c)) return rc;
-    if (!tick_takes(c, n_tasks)) {
+    if (!tick_takes(c, n_tasks) || (n_rel && !(flags & YDC_DISPATCH_COMMIT))) {
       if (n_rel)
         if (int rc = ydc_release_slots(c, release_servant_idx, n_rel)) return rc;
       if (!n_tasks) return YDC_OK;
