@@ -146,13 +146,18 @@ def _rows_of(sv, idx, flags):
     return rows
 
 
+@pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("n_servants,n_envs,big", [(60, 1, False), (700, 3, False), (2500, 4, True), (9000, 2, True),
                                                    (400, 150, False)])
-def test_ticks_with_heartbeats_and_releases(n_servants, n_envs, big):
+def test_ticks_with_heartbeats_and_releases(n_servants, n_envs, big, resident, monkeypatch):
     """Sequences of scheduler turns: heartbeats (new load / memory / capacity figures — and now and
     then another version or environment set, which changes structure and takes the general path),
     released grants, a handful of requests — COMMITted; the oracle replays every turn on its own
-    snapshot. Delta lists beyond what travels as kernel arguments (16 rows, 64 releases) included."""
+    snapshot. Delta lists beyond what travels as kernel arguments (16 rows, 64 releases) included.
+    resident = 1: the kernel of a turn stays on its CU and takes the following turns from its
+    mailbox (until a turn it does not take — a structural heartbeat, a long list — ends it);
+    resident = 0: every turn is a launch."""
+    monkeypatch.setenv("YDC_RESIDENT", resident)
     rng = np.random.default_rng(77 + n_servants)
     sv, _ = cases.random_case(seed=5 + n_servants, n_tasks=3 * n_servants, n_servants=n_servants, n_envs=n_envs,
                               shared_ip_frac=0.1)
@@ -249,4 +254,73 @@ def test_tick_then_batch_then_tick_share_the_registry():
         assert took_the_tick_kernel(c.stats()) == (n == 20)
         sv["running_tasks"] = wrun
         assert np.array_equal(c.get_running(), wrun)
+    c.close()
+
+
+def test_resident_kernel_idle_exit_and_relaunch(monkeypatch):
+    """The resident kernel leaves by itself when nobody has asked for a while; the next turn launches
+    a new one — also when the command and the exit cross (turns spaced around the idle time)."""
+    import time
+    monkeypatch.setenv("YDC_RESIDENT_IDLE_MS", "2")
+    rng = np.random.default_rng(5)
+    sv, _ = cases.random_case(seed=77, n_tasks=20000, n_servants=1500, n_envs=3)
+    sv = {k: np.array(v, copy=True) for k, v in sv.items()}
+    c = binding.Context(device=0)
+    c.upload_servants(pack.to_abi_columns(sv))
+    held = []
+    for turn in range(300):
+        rel = [held.pop(int(rng.integers(len(held)))) for _ in range(min(len(held), int(rng.integers(0, 4))))]
+        for s in rel:
+            sv["running_tasks"][s] -= 1
+        tk = synth.make_tasks(int(rng.integers(1, 9)), sv, n_envs=3, seed=int(rng.integers(1 << 30)), self_frac=0.2)
+        want, _, wrun = O.dispatch(sv, tk, "scan")
+        got, _ = c.dispatch_tick(tk, release_idx=rel)
+        assert np.array_equal(got, want), turn
+        sv["running_tasks"] = wrun
+        held.extend(int(s) for s in got if s < O.IDX_ENV_NOT_FOUND)
+        time.sleep(float(rng.choice([0.0, 0.0015, 0.002, 0.0025, 0.01])))
+    assert np.array_equal(c.get_running(), sv["running_tasks"])
+    c.close()
+
+
+def test_resident_kernel_and_everything_else_interleaved():
+    """Every other entry point ends the resident kernel first and sees what it left in HBM: large
+    batches, device-pointer batches, row updates, releases, get / set of running_tasks, a removed
+    servant — interleaved with resident turns, each step against the oracle's snapshot."""
+    rng = np.random.default_rng(8)
+    sv, _ = cases.random_case(seed=78, n_tasks=30000, n_servants=800, n_envs=3, shared_ip_frac=0.05)
+    sv = {k: np.array(v, copy=True) for k, v in sv.items()}
+    c = binding.Context(device=0)
+    c.upload_servants(pack.to_abi_columns(sv))
+    for turn in range(60):
+        tk = synth.make_tasks(int(rng.integers(1, 30)), sv, n_envs=3, seed=int(rng.integers(1 << 30)), self_frac=0.2)
+        want, _, wrun = O.dispatch(sv, tk, "scan")
+        got, _ = c.dispatch_tick(tk)
+        assert np.array_equal(got, want), turn
+        sv["running_tasks"] = wrun
+        what = turn % 6
+        if what == 0:  # a large committed batch through the pipeline
+            tk = synth.make_tasks(2000, sv, n_envs=3, seed=int(rng.integers(1 << 30)), self_frac=0.2)
+            want, _, wrun = O.dispatch(sv, tk, "sorted")
+            got, _, _ = c.dispatch(tk, commit=True, want_util=False, want_running=False)
+            assert np.array_equal(got, want), turn
+            sv["running_tasks"] = wrun
+        elif what == 1:
+            assert np.array_equal(c.get_running(), sv["running_tasks"])
+        elif what == 2:  # released grants through the plain entry point
+            busy = np.nonzero(sv["running_tasks"] > 0)[0]
+            rel = rng.choice(busy, size=min(5, len(busy)), replace=False).astype(np.uint32)
+            c.release_slots(rel)
+            sv["running_tasks"][rel] -= 1
+        elif what == 3:  # a structural heartbeat through the plain entry point
+            s = int(rng.integers(len(sv["version"])))
+            sv["version"][s] = 19 + int(rng.integers(0, 3))
+            c.update_servants([s], _rows_of(sv, np.array([s]), pack.servant_flags(sv)))
+        elif what == 4:  # a servant expires
+            s = int(rng.integers(len(sv["version"])))
+            c.remove_servants([s])
+            sv = {k: np.delete(v, s, axis=0) for k, v in sv.items()}
+        else:
+            c.set_running(sv["running_tasks"])
+    assert np.array_equal(c.get_running(), sv["running_tasks"])
     c.close()

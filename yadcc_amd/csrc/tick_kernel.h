@@ -53,6 +53,25 @@ struct TickDone {
   uint32_t seq, granted, timeouts, env_not_found;
 };
 
+// The mailbox of a resident kernel (page-locked, coherent host memory). The host sends a command by
+// storing its payload and then the eight granules {word, command number} of `head`; the kernel's
+// wave 0 polls `head` (one 64-byte read per poll) and acts when all eight carry the number it
+// waits for. What does not fit the head — requests beyond the first, released grants beyond four,
+// heartbeat rows — lies in the arrays, stored before the head and read after it. The answer comes
+// back the same way (`reply`, then the arrays for more than seven placements / utilisations).
+constexpr uint32_t kTickCmdTick = 1, kTickCmdQuit = 2;
+struct TickBox {
+  unsigned long long head[8];  // {cmd | n_tasks << 8 | n_upd << 16 | n_rel << 24}, env, minv, rip, rel[0 .. 3]
+  unsigned long long reply[8];  // {granted | timeouts << 8 | env_not_found << 16}, placement 0 .. 6
+  uint32_t env[kTickInlineTasks], minv[kTickInlineTasks], rip[kTickInlineTasks];
+  uint32_t rel[kTickInlineRel];
+  uint32_t upd_idx[kTickInlineUpd];
+  TickRow upd[kTickInlineUpd];
+  uint32_t out_idx[kTickInlineTasks];
+  double out_util[kTickInlineTasks];
+  uint32_t alive;  // the kernel clears it when it leaves (QUIT, or nobody asked for idle_ticks)
+};
+
 struct TickArgs {
   // resident registry
   uint32_t *nproc, *load, *max_tasks, *flags;  // (written by the heartbeat rows of this tick)
@@ -75,6 +94,8 @@ struct TickArgs {
   uint32_t* out_idx;
   double* out_util;  // nullable
   TickDone* done;
+  TickBox* box;  // non-NULL: stay resident after this command and take the next ones from the mailbox
+  unsigned long long idle_ticks;  // ... until nobody has sent one for this long (100 MHz ticks)
   uint32_t seq;
   uint32_t in_env[kTickInlineTasks], in_minv[kTickInlineTasks], in_rip[kTickInlineTasks];
   uint32_t in_upd_idx[kTickInlineUpd];
@@ -217,16 +238,18 @@ template <int THREADS, int K, bool COLD>
 __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   constexpr int WAVES = THREADS / 64;
   constexpr int G = K < 8 ? K : 8;  // servants whose columns are in flight together
-  extern __shared__ uint64_t s_mask[];  // [W]: eligible classes of the current request signature
+  extern __shared__ uint64_t s_mask[];  // [W]: eligible classes of the current (digest, version threshold)
   __shared__ uint32_t s_out[kTickBlock];
   __shared__ double s_util[kTickBlock];
   __shared__ uint32_t s_part[2][48], s_part_own[2][32];
   __shared__ uint32_t s_own_flag[3];
-  // The payload that travels as kernel arguments, staged once: the argument segment may live in
-  // host memory, where every scalar load of it is a PCIe round trip.
+  // The payload of a command — kernel arguments for the first, the mailbox for the ones a resident
+  // kernel is sent later — staged once: the argument segment may live in host memory, where
+  // every scalar load of it is a PCIe round trip.
   __shared__ uint32_t s_env[kTickBlock], s_minv[kTickBlock], s_rip[kTickBlock];
   __shared__ uint32_t s_rel[kTickInlineRel], s_uidx[kTickInlineUpd];
   __shared__ TickRow s_urow[kTickInlineUpd];
+  __shared__ uint32_t s_cmd[4];  // resident kernel: {word 0 of the command head, 1 = leave}
   const uint32_t t = threadIdx.x, lane = t & 63;
   YDC_TICK_STAMP(0);
   // Everything the kernel reads from the head of its argument block, fetched in ONE go (the
@@ -242,7 +265,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   uint32_t* const p_run_out = a.run_out;
   const uint64_t* const p_cls_env = a.cls_env;
   const uint32_t* const p_cls_ver = a.cls_ver;
-  const uint32_t S = a.S, C = a.C, EW = a.EW, W = a.W, n_tasks = a.n_tasks, n_upd = a.n_upd, n_rel = a.n_rel;
+  const uint32_t S = a.S, C = a.C, EW = a.EW, W = a.W;
+  uint32_t n_tasks = a.n_tasks, n_upd = a.n_upd, n_rel = a.n_rel;
   const uint32_t *const p_tenv = a.t_env, *const p_tminv = a.t_minv, *const p_trip = a.t_rip;
   const uint32_t* const p_upd_idx = a.upd_idx;
   const TickRow* const p_upd_rows = a.upd_rows;
@@ -250,9 +274,11 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   uint32_t* const p_out_idx = a.out_idx;
   double* const p_out_util = a.out_util;
   TickDone* const p_done = a.done;
-  const uint32_t seq = a.seq;
+  TickBox* const box = a.box;
+  const unsigned long long idle_ticks = a.idle_ticks;
+  uint32_t seq = a.seq;
   asm volatile("" ::"s"(p_nproc), "s"(p_load), "s"(p_maxt), "s"(p_flags), "s"(p_class_of), "s"(p_ip),
-               "s"(p_running), "s"(p_rw), "s"(p_run_out), "s"(p_cls_env), "s"(p_cls_ver));
+               "s"(p_running), "s"(p_rw), "s"(p_run_out), "s"(p_cls_env), "s"(p_cls_ver), "s"(box), "s"(idle_ticks));
   asm volatile("" ::"s"(S), "s"(C), "s"(EW), "s"(W), "s"(n_tasks), "s"(n_upd), "s"(n_rel), "s"(p_tenv),
                "s"(p_tminv), "s"(p_trip), "s"(p_upd_idx), "s"(p_upd_rows), "s"(p_rel), "s"(p_out_idx),
                "s"(p_out_util), "s"(p_done), "s"(seq));
@@ -337,264 +363,364 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     }
   }
   YDC_TICK_STAMP(2);
-  tick_lds_barrier();  // (the staged arguments)
-  YDC_TICK_STAMP(3);
 
-  // ---- short delta lists travel as arguments: the owner patches its registers ----
-  // Heartbeat rows: the columns first (stores only), then the registers.
-  if (!p_upd_idx && n_upd) {
-    for (uint32_t u = 0; u < n_upd; ++u) {
-      const uint32_t s = s_uidx[u];
-      if (s < S && s % THREADS == t) {
-        const TickRow r = s_urow[u];
-        p_nproc[s] = r.nproc;
-        p_load[s] = r.load;
-        p_maxt[s] = r.max_tasks;
-        p_flags[s] = r.flags;
-      }
-    }
-    for (uint32_t u = 0; u < n_upd; ++u) {
-      const uint32_t s = s_uidx[u];
-      if (s < S && s % THREADS == t) {
-        const TickRow r = s_urow[u];
-        const uint32_t wk = s / THREADS;
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) run = (uint32_t)k == wk ? c_run[k] : run;
-        const uint64_t nk = tick_key(r.nproc, r.load, r.max_tasks, r.flags, run, (in_cls >> wk) & 1u);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const bool me = (uint32_t)k == wk;
-          key[k] = me ? nk : key[k];
-          if (COLD) {
-            c_nproc[k] = me ? r.nproc : c_nproc[k];
-            c_load[k] = me ? r.load : c_load[k];
-            c_maxt[k] = me ? r.max_tasks : c_maxt[k];
-            c_flags[k] = me ? r.flags : c_flags[k];
-          }
-        }
-      }
-    }
-  }
-  // Released grants: FreeTask's --running_tasks (:181). This thread is the only one that knows servant s.
-  if (!p_rel && n_rel) {
-    for (uint32_t j = 0; j < n_rel; ++j) {
-      const uint32_t s = s_rel[j];
-      if (s < S && s % THREADS == t) {
-        const uint32_t wk = s / THREADS;
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if ((uint32_t)k == wk) {
-            c_run[k] -= 1;
-            changed |= 1u << k;
-          }
-      }
-    }
-    // (one key per touched servant, whatever the number of its released grants)
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (!((changed >> k) & 1u)) continue;
-      const uint32_t s = (uint32_t)k * THREADS + t;
-      uint32_t np, ld, mt, fl;
-      if (COLD) {
-        np = c_nproc[k];
-        ld = c_load[k];
-        mt = c_maxt[k];
-        fl = c_flags[k];
-      } else {  // (after this thread's own row stores above: same thread, same address)
-        np = p_nproc[s];
-        ld = p_load[s];
-        mt = p_maxt[s];
-        fl = p_flags[s];
-      }
-      key[k] = tick_key(np, ld, mt, fl, c_run[k], (in_cls >> k) & 1u);
-    }
-  }
-
-  YDC_TICK_STAMP(4);
-  uint32_t n_granted = 0, n_timeout = 0, n_envnf = 0;  // (thread 0's are reported)
+  // What survives from one command of a resident kernel to the next: the eligible-class mask of
+  // the last (digest, version threshold), the host the own-host bits belong to, and every
+  // thread's cached candidates — a thread whose servants no command touches never rescans.
   uint32_t red = 0, pk = 0;  // reductions / picks so far (LDS buffer rotation)
-  // The request signature (digest, version threshold, requestor) the cached values below belong to:
-  // one RPC's requests share it (scheduler_service_impl.cc:228-264), so it rarely changes inside a call.
   uint32_t p_env = 0, p_minv = 0, p_rip = 0;
   bool have_sig = false, any = false, dirty = true;
   uint32_t elig = 0, ownb = 0;  // bit k: servant k is eligible for / on the host of the signature
   TickBest mine{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
   TickOwn mine_own{kNone, kNone};
-  for (uint32_t i = 0; i < n_tasks; ++i) {
-    const uint32_t oi = i & (kTickBlock - 1);
-    if (p_tenv && oi == 0) {  // the next 64 requests' columns (device or mapped host memory)
-      if (t < kTickBlock && i + t < n_tasks) {
-        s_env[t] = p_tenv[i + t];
-        s_minv[t] = p_tminv[i + t];
-        s_rip[t] = p_trip[i + t];
-      }
-      tick_lds_barrier();
-    }
-    // (the same in every thread: say so, the barriers and ballots below sit behind tests of them)
-    const uint32_t env = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[oi]),
-                   minv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[oi]),
-                   rip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[oi]);
-    if (!have_sig || env != p_env || minv != p_minv || rip != p_rip) {
-      have_sig = true;
-      p_env = env;
-      p_minv = minv;
-      p_rip = rip;
-      // Eligible classes: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
-      for (uint32_t c = t; c < W * 64; c += THREADS) {  // (whole waves)
-        bool bit = false;
-        if (c < C && env < 64 * EW)
-          bit = ((p_cls_env[(size_t)c * EW + (env >> 6)] >> (env & 63)) & 1u) && p_cls_ver[c] >= minv;
-        const uint64_t word = __ballot(bit);
-        if (lane == 0) s_mask[c >> 6] = word;
-      }
-      tick_lds_barrier();
-      uint64_t any_w = 0;
-      for (uint32_t w = 0; w < W; ++w) any_w |= s_mask[w];
-      any = any_w != 0;
-      elig = ownb = 0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint64_t m = s_mask[cls[k] >> 6];
-        elig |= (uint32_t)((m >> (cls[k] & 63)) & ((in_cls >> k) & 1u)) << k;
-        ownb |= (ip[k] == rip ? 1u : 0u) << k;
-      }
-      dirty = true;
-      tick_lds_barrier();  // (s_mask is rewritten at the next change of signature)
-      if (i == 0) YDC_TICK_STAMP(5);
-    }
-    if (!any) {  // nobody advertises the environment at that version: :105-108
-      if (t == 0) {
-        s_out[oi] = kIdxEnvNotFound;
-        s_util[oi] = -1.0;
-      }
-      ++n_envnf;
-    } else {
-      if (dirty) {  // this thread's candidates: its state (or the signature) changed
-        uint64_t bk = kTickNoKey;
-        mine.idx = mine_own.own1 = mine_own.own2 = kNone;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
-          const uint32_t s = (uint32_t)k * THREADS + t;
-          if ((ownb >> k) & 1u) {  // on the requestor's own host (ascending s: first, second)
-            if (mine_own.own1 == kNone) mine_own.own1 = s;
-            else if (mine_own.own2 == kNone) mine_own.own2 = s;
-          } else if (key[k] < bk) {
-            bk = key[k];
-            mine.idx = s;
-          }
-        }
-        mine.khi = (uint32_t)(bk >> 32);
-        mine.klo = (uint32_t)bk;
-        dirty = false;
-      }
-      if (i == 2) YDC_TICK_STAMP(24);
-      // Own-host candidates are rare: a flag says whether the second reduction is needed at all.
-      const uint32_t fl_i = pk % 3;
-      if (__ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
-      TickBest best = tick_block_reduce<WAVES>(mine, s_part[red++ & 1]);
-      if (i == 2) YDC_TICK_STAMP(25);
-      const bool own_any = s_own_flag[fl_i] != 0;
-      if (t == 0) s_own_flag[(pk + 2) % 3] = 0;
-      ++pk;
-      TickOwn own{kNone, kNone};
-      if (own_any) {
-        own = tick_block_reduce<WAVES>(mine_own, s_part_own[red++ & 1]);
-        if (own.own2 != kNone) {
-          // Several eligible free servants on the requestor's host: only the first of them is
-          // `self` (:372-379), the others compete like everybody else.
-          TickBest again{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
-          uint64_t bk = kTickNoKey;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
-            const uint32_t s = (uint32_t)k * THREADS + t;
-            if (s != own.own1 && key[k] < bk) {
-              bk = key[k];
-              again.idx = s;
-            }
-          }
-          again.khi = (uint32_t)(bk >> 32);
-          again.klo = (uint32_t)bk;
-          best = tick_block_reduce<WAVES>(again, s_part[red++ & 1]);
+
+  for (;;) {  // one command per turn (a kernel that is not resident takes one turn)
+    tick_lds_barrier();  // (the staged command)
+    YDC_TICK_STAMP(3);
+    // ---- short delta lists: the owner patches its registers ----
+    // Heartbeat rows: the columns first (stores only), then the registers.
+    if (!p_upd_idx && n_upd) {
+      for (uint32_t u = 0; u < n_upd; ++u) {
+        const uint32_t s = s_uidx[u];
+        if (s < S && s % THREADS == t) {
+          const TickRow r = s_urow[u];
+          p_nproc[s] = r.nproc;
+          p_load[s] = r.load;
+          p_maxt[s] = r.max_tasks;
+          p_flags[s] = r.flags;
         }
       }
-      if (i == 2) YDC_TICK_STAMP(26);
-      const uint32_t winner = best.idx != kNone ? best.idx : own.own1;  // :392-396
-      if (winner == kNone) {  // eligible servants exist, none is free: Timeout with timeout == now (:116-118)
-        if (t == 0) {
-          s_out[oi] = kIdxTimeout;
-          s_util[oi] = -1.0;
-        }
-        ++n_timeout;
-      } else {
-        ++n_granted;
-        if (winner % THREADS == t) {
-          const uint32_t wk = winner / THREADS;
-          uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
-          uint64_t kw = 0;
-          if (!COLD) {
-            np = p_nproc[winner];
-            ld = p_load[winner];
-            mt = p_maxt[winner];
-            fl = p_flags[winner];
-          }
+      for (uint32_t u = 0; u < n_upd; ++u) {
+        const uint32_t s = s_uidx[u];
+        if (s < S && s % THREADS == t) {
+          const TickRow r = s_urow[u];
+          const uint32_t wk = s / THREADS;
+          uint32_t run = 0;
 #pragma unroll
-          for (int k = 0; k < K; ++k) {  // (selects, not branches: the key is computed once below)
-            const bool me = (uint32_t)k == wk;
-            kw = me ? key[k] : kw;
-            run = me ? c_run[k] : run;
-            if (COLD) {
-              np = me ? c_nproc[k] : np;
-              ld = me ? c_load[k] : ld;
-              mt = me ? c_maxt[k] : mt;
-              fl = me ? c_flags[k] : fl;
-            }
-          }
-          s_out[oi] = winner;
-          s_util[oi] = __longlong_as_double((long long)(kw & 0x7FFFFFFFFFFFFFFFull));
-          run += 1;  // ++pick->running_tasks (:123); written back at the end
-          const uint64_t nk = tick_key(np, ld, mt, fl, run, true);
+          for (int k = 0; k < K; ++k) run = (uint32_t)k == wk ? c_run[k] : run;
+          const uint64_t nk = tick_key(r.nproc, r.load, r.max_tasks, r.flags, run, (in_cls >> wk) & 1u);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool me = (uint32_t)k == wk;
             key[k] = me ? nk : key[k];
-            c_run[k] = me ? run : c_run[k];
+            if (COLD) {
+              c_nproc[k] = me ? r.nproc : c_nproc[k];
+              c_load[k] = me ? r.load : c_load[k];
+              c_maxt[k] = me ? r.max_tasks : c_maxt[k];
+              c_flags[k] = me ? r.flags : c_flags[k];
+            }
           }
-          changed |= 1u << wk;
           dirty = true;
         }
       }
     }
-    if (i < 16) YDC_TICK_STAMP(8 + i);  // (pick i done)
-    if (oi == kTickBlock - 1 || i + 1 == n_tasks) {
-      tick_lds_barrier();
-      const uint32_t first = i - oi;
-      if (t <= oi) {
-        p_out_idx[first + t] = s_out[t];
-        if (p_out_util) p_out_util[first + t] = s_util[t];
+    // Released grants: FreeTask's --running_tasks (:181). This thread is the only one that knows servant s.
+    if (!p_rel && n_rel) {
+      uint32_t touched = 0;
+      for (uint32_t j = 0; j < n_rel; ++j) {
+        const uint32_t s = s_rel[j];
+        if (s < S && s % THREADS == t) {
+          const uint32_t wk = s / THREADS;
+#pragma unroll
+          for (int k = 0; k < K; ++k) c_run[k] -= (uint32_t)k == wk ? 1u : 0u;
+          touched |= 1u << wk;
+        }
+      }
+      // (one key per touched servant, whatever the number of its released grants)
+      if (touched) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (!((touched >> k) & 1u)) continue;
+          const uint32_t s = (uint32_t)k * THREADS + t;
+          uint32_t np, ld, mt, fl;
+          if (COLD) {
+            np = c_nproc[k];
+            ld = c_load[k];
+            mt = c_maxt[k];
+            fl = c_flags[k];
+          } else {  // (after this thread's own row stores above: same thread, same address)
+            np = p_nproc[s];
+            ld = p_load[s];
+            mt = p_maxt[s];
+            fl = p_flags[s];
+          }
+          key[k] = tick_key(np, ld, mt, fl, c_run[k], (in_cls >> k) & 1u);
+        }
+        changed |= touched;
+        dirty = true;
       }
     }
-  }
+    YDC_TICK_STAMP(4);
 
-  // running_tasks goes back: the servants this call touched (released grants, picks).
+    uint32_t n_granted = 0, n_timeout = 0, n_envnf = 0;  // (thread 0's are reported)
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+      const uint32_t oi = i & (kTickBlock - 1);
+      if (p_tenv && oi == 0) {  // the next 64 requests' columns (device or mapped host memory)
+        if (t < kTickBlock && i + t < n_tasks) {
+          s_env[t] = p_tenv[i + t];
+          s_minv[t] = p_tminv[i + t];
+          s_rip[t] = p_trip[i + t];
+        }
+        tick_lds_barrier();
+      }
+      // (the same in every thread: say so, the barriers and ballots below sit behind tests of them)
+      const uint32_t env = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[oi]),
+                     minv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[oi]),
+                     rip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[oi]);
+      // The request signature the cached values belong to: one RPC's requests share it
+      // (scheduler_service_impl.cc:228-264), and digests and version thresholds are few.
+      if (!have_sig || env != p_env || minv != p_minv) {
+        // Eligible classes: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
+        for (uint32_t c = t; c < W * 64; c += THREADS) {  // (whole waves)
+          bool bit = false;
+          if (c < C && env < 64 * EW)
+            bit = ((p_cls_env[(size_t)c * EW + (env >> 6)] >> (env & 63)) & 1u) && p_cls_ver[c] >= minv;
+          const uint64_t word = __ballot(bit);
+          if (lane == 0) s_mask[c >> 6] = word;
+        }
+        tick_lds_barrier();
+        uint64_t any_w = 0;
+        for (uint32_t w = 0; w < W; ++w) any_w |= s_mask[w];
+        any = any_w != 0;
+        elig = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const uint32_t s = (uint32_t)k * THREADS + t;
-    if ((changed >> k) & 1u) p_rw[s] = c_run[k];
-    if (p_run_out && s < S) p_run_out[s] = c_run[k];
-  }
-  // Results first, then the stamp the host spins on.
-  YDC_TICK_STAMP(6);
-  __threadfence_system();
-  __syncthreads();
-  YDC_TICK_STAMP(7);
-  if (t == 0) {
-    p_done->granted = n_granted;
-    p_done->timeouts = n_timeout;
-    p_done->env_not_found = n_envnf;
-    __hip_atomic_store(&p_done->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int k = 0; k < K; ++k) {
+          const uint64_t m = s_mask[cls[k] >> 6];
+          elig |= (uint32_t)((m >> (cls[k] & 63)) & ((in_cls >> k) & 1u)) << k;
+        }
+        dirty = true;
+        tick_lds_barrier();  // (s_mask is rewritten at the next change)
+        if (i == 0) YDC_TICK_STAMP(5);
+      }
+      if (!have_sig || rip != p_rip) {
+        uint32_t nb = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb |= (ip[k] == rip ? 1u : 0u) << k;
+        // (another requestor only matters to the threads that hold a servant of the old or the new host)
+        if (nb | ownb) dirty = true;
+        ownb = nb;
+      }
+      have_sig = true;
+      p_env = env;
+      p_minv = minv;
+      p_rip = rip;
+      if (!any) {  // nobody advertises the environment at that version: :105-108
+        if (t == 0) {
+          s_out[oi] = kIdxEnvNotFound;
+          s_util[oi] = -1.0;
+        }
+        ++n_envnf;
+      } else {
+        if (dirty) {  // this thread's candidates: its state (or the signature) changed
+          uint64_t bk = kTickNoKey;
+          mine.idx = mine_own.own1 = mine_own.own2 = kNone;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+            const uint32_t s = (uint32_t)k * THREADS + t;
+            if ((ownb >> k) & 1u) {  // on the requestor's own host (ascending s: first, second)
+              if (mine_own.own1 == kNone) mine_own.own1 = s;
+              else if (mine_own.own2 == kNone) mine_own.own2 = s;
+            } else if (key[k] < bk) {
+              bk = key[k];
+              mine.idx = s;
+            }
+          }
+          mine.khi = (uint32_t)(bk >> 32);
+          mine.klo = (uint32_t)bk;
+          dirty = false;
+        }
+        if (i == 2) YDC_TICK_STAMP(24);
+        // Own-host candidates are rare: a flag says whether the second reduction is needed at all.
+        const uint32_t fl_i = pk % 3;
+        if (__ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
+        TickBest best = tick_block_reduce<WAVES>(mine, s_part[red++ & 1]);
+        if (i == 2) YDC_TICK_STAMP(25);
+        const bool own_any = s_own_flag[fl_i] != 0;
+        if (t == 0) s_own_flag[(pk + 2) % 3] = 0;
+        ++pk;
+        TickOwn own{kNone, kNone};
+        if (own_any) {
+          own = tick_block_reduce<WAVES>(mine_own, s_part_own[red++ & 1]);
+          if (own.own2 != kNone) {
+            // Several eligible free servants on the requestor's host: only the first of them is
+            // `self` (:372-379), the others compete like everybody else.
+            TickBest again{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+            uint64_t bk = kTickNoKey;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+              const uint32_t s = (uint32_t)k * THREADS + t;
+              if (s != own.own1 && key[k] < bk) {
+                bk = key[k];
+                again.idx = s;
+              }
+            }
+            again.khi = (uint32_t)(bk >> 32);
+            again.klo = (uint32_t)bk;
+            best = tick_block_reduce<WAVES>(again, s_part[red++ & 1]);
+          }
+        }
+        if (i == 2) YDC_TICK_STAMP(26);
+        const uint32_t winner = best.idx != kNone ? best.idx : own.own1;  // :392-396
+        if (winner == kNone) {  // eligible servants exist, none is free: Timeout with timeout == now (:116-118)
+          if (t == 0) {
+            s_out[oi] = kIdxTimeout;
+            s_util[oi] = -1.0;
+          }
+          ++n_timeout;
+        } else {
+          ++n_granted;
+          if (winner % THREADS == t) {
+            const uint32_t wk = winner / THREADS;
+            uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
+            uint64_t kw = 0;
+            if (!COLD) {
+              np = p_nproc[winner];
+              ld = p_load[winner];
+              mt = p_maxt[winner];
+              fl = p_flags[winner];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {  // (selects, not branches: the key is computed once below)
+              const bool me = (uint32_t)k == wk;
+              kw = me ? key[k] : kw;
+              run = me ? c_run[k] : run;
+              if (COLD) {
+                np = me ? c_nproc[k] : np;
+                ld = me ? c_load[k] : ld;
+                mt = me ? c_maxt[k] : mt;
+                fl = me ? c_flags[k] : fl;
+              }
+            }
+            s_out[oi] = winner;
+            s_util[oi] = __longlong_as_double((long long)(kw & 0x7FFFFFFFFFFFFFFFull));
+            run += 1;  // ++pick->running_tasks (:123); written back at the end
+            const uint64_t nk = tick_key(np, ld, mt, fl, run, true);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const bool me = (uint32_t)k == wk;
+              key[k] = me ? nk : key[k];
+              c_run[k] = me ? run : c_run[k];
+            }
+            changed |= 1u << wk;
+            dirty = true;
+          }
+        }
+      }
+      if (i < 16) YDC_TICK_STAMP(8 + i);  // (pick i done)
+      if (oi == kTickBlock - 1 || i + 1 == n_tasks) {
+        tick_lds_barrier();
+        const uint32_t first = i - oi;
+        if (t <= oi) {
+          p_out_idx[first + t] = s_out[t];
+          if (p_out_util) p_out_util[first + t] = s_util[t];
+        }
+      }
+    }
+
+    if (box) {
+      // Resident: the answer first. Granules {word, command number} — every granule says by itself
+      // that it is this command's (8-byte stores are atomic; no fence, no order between them):
+      // granule 0 the counters, granules 1 .. 7 the first seven placements. Longer answers (and
+      // the utilisations) lie in the arrays stored above, ahead of the granules.
+      if (t < 64) {  // (wave 0: the array stores above are this wave's own)
+        if (n_tasks > 7 || p_out_util) __threadfence_system();
+        if (t < 8) {
+          const uint32_t word = t == 0 ? (n_granted | (n_timeout << 8) | (n_envnf << 16))
+                                       : (t - 1 < n_tasks ? s_out[t - 1] : 0u);
+          __hip_atomic_store(&box->reply[t], ((unsigned long long)seq << 32) | word, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    // running_tasks goes back: the servants this command touched (released grants, picks).
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t s = (uint32_t)k * THREADS + t;
+      if ((changed >> k) & 1u) p_rw[s] = c_run[k];
+      if (p_run_out && s < S) p_run_out[s] = c_run[k];
+    }
+    changed = 0;
+    if (!box) {
+      // Results first, then the stamp the host spins on.
+      YDC_TICK_STAMP(6);
+      __threadfence_system();
+      __syncthreads();
+      YDC_TICK_STAMP(7);
+      if (t == 0) {
+        p_done->granted = n_granted;
+        p_done->timeouts = n_timeout;
+        p_done->env_not_found = n_envnf;
+        __hip_atomic_store(&p_done->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+
+    // ---- resident: wait for the next command (wave 0 polls the mailbox, the others wait at the barrier) ----
+    ++seq;
+    if (seq == 0) seq = 1;
+    if (t < 64) {
+      const unsigned long long t0 = wall_clock64();
+      uint32_t word = 0, leave = 0;
+      for (;;) {
+        const unsigned long long g =
+            __hip_atomic_load(&box->head[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool mine_ok = (uint32_t)(g >> 32) == seq;
+        if ((__ballot(mine_ok) & 0xFFull) == 0xFFull) {
+          word = (uint32_t)g;
+          break;
+        }
+        if (wall_clock64() - t0 > idle_ticks) {  // nobody has asked for a while: give the CU back
+          leave = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      // head: {cmd | n_tasks << 8 | n_upd << 16 | n_rel << 24}, env, minv, rip, rel[0 .. 3]
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 0);
+      if (!leave) {
+        if (lane == 1) s_env[0] = word;
+        if (lane == 2) s_minv[0] = word;
+        if (lane == 3) s_rip[0] = word;
+        if (lane >= 4 && lane < 8) s_rel[lane - 4] = word;
+        const uint32_t nt = (w0 >> 8) & 0xFF, nu = (w0 >> 16) & 0xFF, nr = w0 >> 24;
+        // (what does not fit the head was stored before it; this read follows the head's)
+        if (nt > 1 && lane < nt) {
+          s_env[lane] = __hip_atomic_load(&box->env[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_minv[lane] = __hip_atomic_load(&box->minv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_rip[lane] = __hip_atomic_load(&box->rip[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (nr > 4 && lane < nr) s_rel[lane] = __hip_atomic_load(&box->rel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane < nu) {
+          s_uidx[lane] = __hip_atomic_load(&box->upd_idx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          TickRow r;
+          r.nproc = __hip_atomic_load(&box->upd[lane].nproc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          r.load = __hip_atomic_load(&box->upd[lane].load, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          r.max_tasks = __hip_atomic_load(&box->upd[lane].max_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          r.flags = __hip_atomic_load(&box->upd[lane].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_urow[lane] = r;
+        }
+      }
+      if (lane == 0) {
+        s_cmd[0] = w0;
+        s_cmd[1] = leave ? 2u : ((w0 & 0xFF) == kTickCmdQuit ? 1u : 0u);
+      }
+    }
+    tick_lds_barrier();  // (s_cmd; the barrier at the top of the next turn covers the staged payload again)
+    const uint32_t w0 = s_cmd[0], going = s_cmd[1];
+    if (going) {
+      // Leaving: a QUIT is answered (the host waits for it), an idle exit is not. `alive` last.
+      if (t == 0) {
+        if (going == 1)
+          __hip_atomic_store(&box->reply[0], ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&box->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    n_tasks = (w0 >> 8) & 0xFF;
+    n_upd = (w0 >> 16) & 0xFF;
+    n_rel = w0 >> 24;
   }
 }
 

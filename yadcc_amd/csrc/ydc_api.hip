@@ -282,6 +282,16 @@ struct ydc_context {
   uint32_t tick_seq = 0;
   uint32_t opt_small_batch = 64;  // batches up to this many requests take it (small_batch=0: none does)
   uint64_t tick_batches = 0;
+  // The resident form: the kernel of a COMMITting tick stays on its CU, the registry in its
+  // registers, and takes the following ticks from a page-locked mailbox (tick_kernel.h: TickBox) —
+  // no launch, no column loads. Every other use of the context ends it first (resident_stop).
+  bool opt_resident = true;        // (resident=0: every tick is a launch)
+  uint32_t opt_resident_idle_ms = 50;  // the kernel leaves by itself when nobody has asked for this long
+  TickBox *h_box = nullptr, *d_box = nullptr;
+  hipStream_t res_stream = nullptr;
+  hipEvent_t res_ev = nullptr;
+  bool res_live = false;  // a resident kernel was launched and has not been seen to leave
+  uint64_t tick_resident = 0, tick_launches = 0;
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
@@ -343,6 +353,7 @@ struct ydc_context {
 namespace {
 
 void stream_release(ydc_context* c);  // streaming mode, defined further down
+void resident_stop(ydc_context* c);   // small-batch path's resident kernel, defined further down
 void group_release(ydc_context* c);   // multi-GPU group, defined further down
 
 // Errors raised before (or without) a context: process-wide, written from any thread.
@@ -444,6 +455,7 @@ int fail(ydc_context* ctx, int code, const char* fmt, ...) {
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 int rebuild_tables(ydc_context* c) {
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   const uint32_t n = c->n_servants;
   c->tables.build(n, c->h_env.data(), c->h_version.data(), c->h_max_tasks.data(),
                   c->h_nproc.data(), c->h_ip.data(), c->env_words, (uint32_t)c->h_alias_ip.size(),
@@ -729,6 +741,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("binsort_max_slots")) c->opt_binsort_max_slots = (uint32_t)atoll(s);
   if (const char* s = tune_value("shard_margin")) c->opt_shard_margin = atoll(s);
   if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
+  if (const char* s = tune_value("resident")) c->opt_resident = atoi(s) != 0;
+  if (const char* s = tune_value("resident_idle_ms")) c->opt_resident_idle_ms = (uint32_t)std::max(1, atoi(s));
   if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -738,6 +752,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
 int ydc_destroy(ydc_context* c) {
   if (!c) return YDC_OK;
   (void)hipSetDevice(c->device);
+  resident_stop(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   stream_release(c);
   group_release(c);
@@ -775,6 +790,9 @@ int ydc_destroy(ydc_context* c) {
   if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_box) (void)hipHostFree(c->h_box);
+  if (c->res_ev) (void)hipEventDestroy(c->res_ev);
+  if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   if (c->h_tick_done) (void)hipHostFree(c->h_tick_done);
   if (c->h_tick_io) (void)hipHostFree(c->h_tick_io);
   c->d_ip.release();
@@ -798,6 +816,7 @@ int ydc_upload_servants(ydc_context* c, const ydc_servant_soa* sv, uint32_t n) {
   if (c->max_servants && n > c->max_servants)
     return fail(c, YDC_ERR_CAPACITY, "%u servants > max_servants %u", n, c->max_servants);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   if (int rc = reserve_registry(c, n)) return rc;
   c->n_servants = n;
@@ -849,6 +868,7 @@ int ydc_update_servants_wide(ydc_context* c, const uint32_t* idx, const ydc_serv
     return fail(c, YDC_ERR_INVALID_ARGUMENT,
                 "the table holds %u mask words per servant: use ydc_update_servants_wide", c->env_words);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   // Appends first (they may need bigger buffers).
   uint32_t new_n = c->n_servants;
   for (uint32_t i = 0; i < n; ++i) {
@@ -940,6 +960,7 @@ int ydc_set_host_aliases(ydc_context* c, const uint32_t* ip_id, const uint32_t* 
     if (servant_idx[i] >= c->n_servants)
       return fail(c, YDC_ERR_INVALID_ARGUMENT, "alias %u names servant %u of %u", i, servant_idx[i], c->n_servants);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->h_alias_ip.assign(ip_id, ip_id + n);
   c->h_alias_servant.assign(servant_idx, servant_idx + n);
@@ -953,6 +974,7 @@ int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
     if (idx[i] >= c->n_servants || (i && idx[i] <= idx[i - 1]))
       return fail(c, YDC_ERR_INVALID_ARGUMENT, "removed rows must be ascending and < %u", c->n_servants);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   const uint32_t S = c->n_servants, kept = S - n, EW = c->env_words;
   // Device: order-preserving compaction of the six resident columns into spare buffers,
   // which then take their place (running_tasks of the survivors never leaves the device).
@@ -1004,6 +1026,7 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
   if (!c || (n && !servant_idx)) return YDC_ERR_INVALID_ARGUMENT;
   if (!n) return YDC_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   HIP_TRY(c, c->d_upd_idx.reserve(n));
   // Through a pinned staging buffer, stream-ordered: no wait here (the next batch follows on
   // the same stream). The buffer is reused only after its previous copy has run.
@@ -1029,6 +1052,7 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
 int ydc_set_running(ydc_context* c, const uint32_t* running, uint32_t n) {
   if (!c || n != c->n_servants || (n && !running)) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   if (n) HIP_TRY(c, hipMemcpy(c->d_running.p, running, n * 4, hipMemcpyHostToDevice));
   return YDC_OK;
@@ -1037,6 +1061,7 @@ int ydc_set_running(ydc_context* c, const uint32_t* running, uint32_t n) {
 int ydc_get_running(ydc_context* c, uint32_t* out, uint32_t n) {
   if (!c || n != c->n_servants || (n && !out)) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // (released slots may still be on their way)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (n) HIP_TRY(c, hipMemcpy(out, c->d_running.p, n * 4, hipMemcpyDeviceToHost));
@@ -1941,6 +1966,86 @@ bool row_is_structural(const ydc_context* c, uint32_t s, const ydc_servant_row& 
          std::min(c->h_max_tasks[s], c->h_nproc[s]) != std::min(r.max_tasks, r.num_processors);
 }
 
+// ---- the resident kernel (tick_kernel.h: TickBox) ----
+// Contexts whose resident kernel may still be polling its mailbox: told to leave when the process
+// exits without destroying them (the kernel reads page-locked memory the runtime is about to unmap).
+std::mutex g_resident_mu;
+std::vector<ydc_context*> g_resident;
+bool g_resident_atexit = false;
+
+inline unsigned long long box_load(const unsigned long long* p) {
+  return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+}
+
+// Waits until granule `g` of the reply carries command number `seq`; false when the kernel has left
+// instead (idle exit racing with the command) or does not answer for a very long time.
+bool box_wait(ydc_context* c, int g, uint32_t seq, uint32_t* word) {
+  const unsigned long long* p = &c->h_box->reply[g];
+  for (uint32_t spins = 0;; ++spins) {
+    const unsigned long long v = box_load(p);
+    if ((uint32_t)(v >> 32) == seq) {
+      *word = (uint32_t)v;
+      return true;
+    }
+    if ((spins & 0x3FFF) == 0x3FFF) {
+      if (__atomic_load_n(&c->h_box->alive, __ATOMIC_ACQUIRE) == 0) {
+        // (it may have answered right before leaving)
+        const unsigned long long w = box_load(p);
+        if ((uint32_t)(w >> 32) == seq) {
+          *word = (uint32_t)w;
+          return true;
+        }
+        return false;
+      }
+      if (spins > (1u << 30)) return false;
+    }
+  }
+}
+
+void resident_forget(ydc_context* c) {
+  c->res_live = false;
+  std::lock_guard<std::mutex> lk(g_resident_mu);
+  g_resident.erase(std::remove(g_resident.begin(), g_resident.end(), c), g_resident.end());
+}
+
+// Ends the context's resident kernel (if any): QUIT through the mailbox, then its stream. After
+// this the registry columns in HBM are what every other path expects (the kernel writes
+// running_tasks and heartbeat rows through after every command).
+void resident_stop(ydc_context* c) {
+  if (!c->res_live) return;
+  if (__atomic_load_n(&c->h_box->alive, __ATOMIC_ACQUIRE) != 0) {
+    if (++c->tick_seq == 0) c->tick_seq = 1;
+    const uint32_t seq = c->tick_seq;
+    for (int g = 7; g >= 0; --g)
+      __atomic_store_n(&c->h_box->head[g], ((unsigned long long)seq << 32) | (g == 0 ? kTickCmdQuit : 0u),
+                       __ATOMIC_RELEASE);
+    uint32_t word;
+    (void)box_wait(c, 0, seq, &word);
+  }
+  (void)hipStreamSynchronize(c->res_stream);
+  resident_forget(c);
+}
+
+void resident_atexit() {
+  std::vector<ydc_context*> live;
+  {
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    live = g_resident;
+  }
+  for (auto* c : live) resident_stop(c);
+}
+
+int resident_prepare(ydc_context* c) {
+  if (!c->h_box) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_box, sizeof(TickBox), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(c->h_box, 0, sizeof(TickBox));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_box, c->h_box, 0));
+  }
+  if (!c->res_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+  if (!c->res_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->res_ev, hipEventDisableTiming));
+  return YDC_OK;
+}
+
 struct TickCall {
   const ydc_task_soa* tasks = nullptr;  // host columns, or device addresses (tasks_on_device)
   bool tasks_on_device = false;
@@ -1958,13 +2063,94 @@ struct TickCall {
 };
 
 template <int THREADS, int K, bool COLD>
-void tick_launch(ydc_context* c, const TickArgs& a, size_t lds) {
-  YDC_LAUNCH(c, "k_tick", (k_tick<THREADS, K, COLD>), dim3(1), dim3(THREADS), lds, c->stream, a);
+void tick_launch(ydc_context* c, const TickArgs& a, size_t lds, hipStream_t stream) {
+  YDC_LAUNCH(c, "k_tick", (k_tick<THREADS, K, COLD>), dim3(1), dim3(THREADS), lds, stream, a);
+}
+
+// Fills the context's stats after a tick.
+void tick_stats(ydc_context* c, uint32_t N, uint32_t granted, uint32_t timeouts, uint32_t env_not_found) {
+  ++c->tick_batches;
+  ydc_stats& st = c->stats;
+  std::memset(&st, 0, sizeof(st));
+  st.n_tasks = N;
+  st.n_servants = c->n_servants;
+  st.n_classes = c->tables.n_classes();
+  st.key_bits = c->kf.key_bits;
+  st.n_chunks = 1;
+  st.rounds = 1;
+  st.chunk_sims = 1;
+  st.small_batch = 1;
+  st.granted = granted;
+  st.timeouts = timeouts;
+  st.env_not_found = env_not_found;
+}
+
+// The answer of a resident kernel to command `seq`: counters, placements (tick_kernel.h: TickBox).
+// false: the kernel left without taking the command.
+bool resident_receive(ydc_context* c, const TickCall& io, uint32_t seq) {
+  const uint32_t N = io.n_tasks;
+  uint32_t counters;
+  if (!box_wait(c, 0, seq, &counters)) return false;
+  if (N <= 7 && !io.out_util) {
+    for (uint32_t i = 0; i < N; ++i)
+      if (!box_wait(c, 1 + (int)i, seq, &io.out_idx[i])) return false;
+  } else {
+    // (the arrays were stored, and fenced, ahead of the granules)
+    for (uint32_t i = 0; i < N; ++i) io.out_idx[i] = __atomic_load_n(&c->h_box->out_idx[i], __ATOMIC_RELAXED);
+    if (io.out_util) std::memcpy(io.out_util, c->h_box->out_util, (size_t)N * 8);
+  }
+  // granted: the requests that are neither of the two (the counters are bytes; N <= 64 fits)
+  const uint32_t timeouts = (counters >> 8) & 0xFF, envnf = (counters >> 16) & 0xFF;
+  tick_stats(c, N, N - timeouts - envnf, timeouts, envnf);
+  return true;
 }
 
 int tick_run(ydc_context* c, const TickCall& io) {
   const uint32_t S = c->n_servants, C = c->tables.n_classes(), N = io.n_tasks;
   const uint32_t W = std::max<uint32_t>(1, ceil_div(C, 64));
+  const bool commit0 = (io.flags & YDC_DISPATCH_COMMIT) != 0;
+  // The resident form takes what a scheduler's turn looks like: COMMIT, host buffers, everything
+  // within what travels as arguments.
+  const bool resident = c->opt_resident && commit0 && !io.tasks_on_device && !io.out_on_device && !io.out_running &&
+                        N <= kTickInlineTasks && io.n_upd <= kTickInlineUpd && io.n_rel <= kTickInlineRel &&
+                        !c->profiling;
+  if (c->res_live && !resident) resident_stop(c);
+  if (c->res_live) {
+    TickBox* b = c->h_box;
+    if (__atomic_load_n(&b->alive, __ATOMIC_ACQUIRE) != 0) {
+      if (++c->tick_seq == 0) c->tick_seq = 1;
+      const uint32_t seq = c->tick_seq;
+      // Payload beyond the head first, the head's eight granules last.
+      if (N > 1)
+        for (uint32_t i = 0; i < N; ++i) {
+          b->env[i] = io.tasks->env_id[i];
+          b->minv[i] = io.tasks->min_version[i];
+          b->rip[i] = io.tasks->requestor_ip[i];
+        }
+      if (io.n_rel > 4) std::memcpy(b->rel, io.rel, (size_t)io.n_rel * 4);
+      for (uint32_t i = 0; i < io.n_upd; ++i) {
+        b->upd_idx[i] = io.upd_idx[i];
+        b->upd[i] = TickRow{io.upd_rows[i].num_processors, io.upd_rows[i].current_load, io.upd_rows[i].max_tasks,
+                            io.upd_rows[i].flags};
+      }
+      uint32_t words[8] = {kTickCmdTick | (N << 8) | (io.n_upd << 16) | (io.n_rel << 24),
+                           N ? io.tasks->env_id[0] : 0u, N ? io.tasks->min_version[0] : 0u,
+                           N ? io.tasks->requestor_ip[0] : 0u, 0u, 0u, 0u, 0u};
+      for (uint32_t j = 0; j < 4 && j < io.n_rel; ++j) words[4 + j] = io.rel[j];
+      for (int g = 7; g >= 0; --g)
+        __atomic_store_n(&b->head[g], ((unsigned long long)seq << 32) | words[g], __ATOMIC_RELEASE);
+      if (resident_receive(c, io, seq)) {
+        ++c->tick_resident;
+        return YDC_OK;
+      }
+    }
+    // The kernel has left (nobody asked for a while): its stream is drained, a new one is launched
+    // with this very command.
+    HIP_TRY(c, hipStreamSynchronize(c->res_stream));
+    resident_forget(c);
+  }
+  if (resident)
+    if (int rc = resident_prepare(c)) return rc;
   if (!c->h_tick_done) {
     HIP_TRY(c, hipHostMalloc((void**)&c->h_tick_done, sizeof(TickDone), hipHostMallocCoherent | hipHostMallocMapped));
     std::memset(c->h_tick_done, 0, sizeof(TickDone));
@@ -2056,8 +2242,23 @@ int tick_run(ydc_context* c, const TickCall& io) {
   a.out_idx = io.out_on_device ? io.out_idx : (uint32_t*)(c->d_tick_io + o_idx);
   a.out_util = io.out_util ? (io.out_on_device ? io.out_util : (double*)(c->d_tick_io + o_util)) : nullptr;
   a.done = c->d_tick_done;
+  a.box = nullptr;
+  a.idle_ticks = 0;
   if (++c->tick_seq == 0) c->tick_seq = 1;
   a.seq = c->tick_seq;
+  hipStream_t launch_stream = c->stream;
+  if (resident) {
+    // This launch stays: it answers through the mailbox like every later command, on a stream of
+    // its own, behind whatever the context's stream still has in flight.
+    a.box = c->d_box;
+    a.idle_ticks = (unsigned long long)c->opt_resident_idle_ms * 100000ull;
+    a.out_idx = c->d_box->out_idx;
+    a.out_util = io.out_util ? c->d_box->out_util : nullptr;
+    __atomic_store_n(&c->h_box->alive, 1u, __ATOMIC_RELEASE);
+    HIP_TRY(c, hipEventRecord(c->res_ev, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->res_stream, c->res_ev, 0));
+    launch_stream = c->res_stream;
+  }
 
   if (c->profiling) {
     c->ksamples_used = 0;
@@ -2067,15 +2268,33 @@ int tick_run(ydc_context* c, const TickCall& io) {
   // (tick_kernel.h): 256 threads up to 4096 servants, 512 up to 8192, 1024 beyond.
   const size_t lds = (size_t)W * 8;
   const uint32_t per_thread = std::max(1u, ceil_div(S, 256u));
-  if (per_thread <= 1) tick_launch<256, 1, true>(c, a, lds);
-  else if (per_thread <= 2) tick_launch<256, 2, true>(c, a, lds);
-  else if (per_thread <= 4) tick_launch<256, 4, true>(c, a, lds);
-  else if (per_thread <= 8) tick_launch<256, 8, true>(c, a, lds);
-  else if (per_thread <= 16) tick_launch<256, 16, true>(c, a, lds);
-  else if (per_thread <= 32) tick_launch<512, 16, true>(c, a, lds);
-  else tick_launch<1024, 16, false>(c, a, lds);
+  if (per_thread <= 1) tick_launch<256, 1, true>(c, a, lds, launch_stream);
+  else if (per_thread <= 2) tick_launch<256, 2, true>(c, a, lds, launch_stream);
+  else if (per_thread <= 4) tick_launch<256, 4, true>(c, a, lds, launch_stream);
+  else if (per_thread <= 8) tick_launch<256, 8, true>(c, a, lds, launch_stream);
+  else if (per_thread <= 16) tick_launch<256, 16, true>(c, a, lds, launch_stream);
+  else if (per_thread <= 32) tick_launch<512, 16, true>(c, a, lds, launch_stream);
+  else tick_launch<1024, 16, false>(c, a, lds, launch_stream);
   HIP_TRY(c, hipGetLastError());
   mark(c, 7);
+  ++c->tick_launches;
+  if (resident) {
+    c->res_live = true;
+    {
+      std::lock_guard<std::mutex> lk(g_resident_mu);
+      g_resident.push_back(c);
+      if (!g_resident_atexit) {
+        g_resident_atexit = true;
+        std::atexit(resident_atexit);
+      }
+    }
+    if (!resident_receive(c, io, a.seq)) {
+      (void)hipStreamSynchronize(c->res_stream);
+      resident_forget(c);
+      return fail(c, YDC_ERR_HIP, "the resident small-batch kernel left without answering its first command");
+    }
+    return YDC_OK;
+  }
 
   // The kernel's last store is the stamp; spin on it (a launch-to-stamp round trip is a third
   // shorter than launch + hipStreamSynchronize). Never forever: the stream is asked now and then.
@@ -2102,20 +2321,8 @@ int tick_run(ydc_context* c, const TickCall& io) {
     if (io.out_running && S)
       HIP_TRY(c, hipMemcpy(io.out_running, dev_run_out, (size_t)S * 4, hipMemcpyDeviceToHost));
   }
-  ++c->tick_batches;
+  tick_stats(c, N, c->h_tick_done->granted, c->h_tick_done->timeouts, c->h_tick_done->env_not_found);
   ydc_stats& st = c->stats;
-  std::memset(&st, 0, sizeof(st));
-  st.n_tasks = N;
-  st.n_servants = S;
-  st.n_classes = C;
-  st.key_bits = c->kf.key_bits;
-  st.n_chunks = 1;
-  st.rounds = 1;
-  st.chunk_sims = 1;
-  st.small_batch = 1;
-  st.granted = c->h_tick_done->granted;
-  st.timeouts = c->h_tick_done->timeouts;
-  st.env_not_found = c->h_tick_done->env_not_found;
   if (c->profiling) {
     for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&st.stage_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&st.stage_ms[YDC_STAGE_TOTAL], c->ev[0], c->ev[7]);
@@ -2153,6 +2360,7 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
       return tick_run(c, io);
     }
   }
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   BatchPlan p;
   if (int rc = plan_batch(c, N, &p)) return rc;
   uint32_t rounds = 0;
@@ -2186,6 +2394,7 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
   if (c->max_tasks && N > c->max_tasks)
     return fail(c, YDC_ERR_CAPACITY, "%u tasks > max_tasks %u", N, c->max_tasks);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   auto& pd = c->pend[(c->pend_head + c->pend_count) & 1];
   if (!pd.h_outcome) HIP_TRY(c, hipHostMalloc((void**)&pd.h_outcome, sizeof(DeviceParams)));
   if (!pd.ev) HIP_TRY(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
@@ -2742,6 +2951,7 @@ int ydc_group_unique_id(void* out_id128) {
 int ydc_group_init(ydc_context* c, const void* id128, int rank, int n_ranks) {
   if (!c || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   group_release(c);
   auto& g = c->group;
   std::string err;
@@ -2775,6 +2985,7 @@ int ydc_group_init_local(ydc_context** ctxs, int n) {
   hub->refs = n;
   for (int r = 0; r < n; ++r) {
     if (!ctxs[r]) return YDC_ERR_INVALID_ARGUMENT;
+    resident_stop(ctxs[r]);
     group_release(ctxs[r]);
     ctxs[r]->group.hub = hub;
     ctxs[r]->group.rank = r;
@@ -2787,6 +2998,7 @@ int ydc_group_ipc_export(ydc_context* c, int rank, int n_ranks, void* out_handle
   if (!c || !out_handle || n_ranks < 1 || n_ranks > (int)kMailboxMaxRanks || rank < 0 || rank >= n_ranks)
     return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
   group_release(c);
   auto& b = c->group.box;
@@ -2882,6 +3094,7 @@ int ydc_group_init_ipc(ydc_context* c, const void* handles, int rank, int n_rank
   if (b.exported_ranks != n_ranks || b.exported_rank != rank)
     return fail(c, YDC_ERR_INVALID_ARGUMENT, "ydc_group_ipc_export(rank %d of %d) first", rank, n_ranks);
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   const bool host = transport == YDC_TRANSPORT_IPC_HOST;
   // (a second attempt with the other flavour: drop what the first one mapped)
   for (uint32_t q = 0; q < kMailboxMaxRanks; ++q) {
@@ -2987,6 +3200,7 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   auto& g = c->group;
   if (g.n_ranks < 1) return fail(c, YDC_ERR_INVALID_ARGUMENT, "ydc_group_init first");
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   BatchPlan full_plan;
   if (int rc = plan_batch(c, N, &full_plan)) return rc;
   BatchPlan p = full_plan;
@@ -3368,6 +3582,7 @@ int ydc_stream_begin(ydc_context* c, uint32_t max_updates, uint32_t max_releases
                      uint32_t max_tasks) {
   if (!c || !max_tasks) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
   stream_release(c);
   auto& sm = c->stream_mode;
   sm.max_upd = max_updates;
