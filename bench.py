@@ -263,6 +263,37 @@ def td_surface(with_reference=True):
                 "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": str(e)}
+    # The reference's real call shape: one WaitForStartingTask RPC = waiters + 1 grants
+    # (daemon/local/task_grant_keeper.cc:145-146) — latency per CALL for 1 .. 256 requests, a
+    # FreeTask of the grants between two calls, a heartbeat before every fourth; the one-launch /
+    # resident path (ydc_dispatch_tick) and, for the crossover, the batch pipeline alone
+    # (YDC_TUNE=small_batch=0) and the launch-per-call form (resident=0).
+    out["latency"] = {"unit": "us per call, one caller thread; p50 / p99 over 1000 calls",
+                      "what": "ydc_td_wait_for_starting_new_task (single_1) / ..._tasks (batch_n), registry warm, "
+                              "grants freed between calls, a heartbeat before every fourth call"}
+    for S in (2000, 16000):
+        rec = {}
+        for name, tune in (("tick", None), ("tick_launch_per_call", "resident=0"), ("batch_pipeline_only", "small_batch=0")):
+            env = dict(os.environ)
+            if tune:
+                env["YDC_TUNE"] = ",".join(x for x in (tune, env.get("YDC_TUNE", "")) if x)
+            try:
+                r = subprocess.run([tool, "latency", str(S), "1000" if name == "tick" else "300"], capture_output=True,
+                                   text=True, timeout=300, cwd=ROOT, env=env)
+                rec[name] = json.loads(r.stdout.strip().splitlines()[-1])["per_call_us"] if r.returncode == 0 else {
+                    "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+            except Exception as e:  # noqa: BLE001
+                rec[name] = {"error": str(e)}
+        t, b = rec.get("tick", {}), rec.get("batch_pipeline_only", {})
+        cross = [int(k.split("_")[1]) for k in t if k.startswith("batch_") and k in b and
+                 isinstance(t[k], dict) and b[k]["p50"] < t[k]["p50"]]
+        rec["crossover_batch"] = min(cross) if cross else None
+        if with_reference:
+            try:
+                rec["reference"] = reference_latency(S)
+            except Exception as e:  # noqa: BLE001
+                rec["reference"] = {"error": str(e)}
+        out["latency"]["servants_%d" % S] = rec
     if with_reference:
         try:
             out["reference"] = reference_td_surface()
@@ -276,6 +307,34 @@ def td_surface(with_reference=True):
                 ours["get_running_tasks_per_s"] * ours["running_tasks_listed"] /
                 (ref["get_running_tasks_per_s"] * max(ref["running_tasks_listed"], 1)))
     return out
+
+
+def reference_latency(n_servants, calls=None):
+    """Per-call latency of the verbatim reference's WaitForStartingNewTask (oracle/_ref, one
+    thread) on the pool of tools/td_native_bench; a batch of n = n consecutive calls, as
+    SchedulerServiceImpl::WaitForStartingTask makes them (scheduler_service_impl.cc:234-264).
+    cpu_baseline leg: the oracle is the thing timed, never the product."""
+    from oracle import refbind as R
+    from yadcc_amd import synth
+    if not R.available():
+        return {"error": "oracle/_ref is not built"}
+    calls = calls or (2048 if n_servants <= 4000 else 512)
+    sv = synth.make_servants(n_servants, n_tasks_hint=70 * n_servants, n_envs=4, seed=42)
+    tk = synth.make_tasks(calls, sv, n_envs=4, self_frac=0.0)
+    d = R.RefDispatcher()
+    d.load_servants(sv)
+    d.dispatch_batch({k: v[:64] for k, v in tk.items()})  # warm
+    _, _, _, lat = d.dispatch_batch(tk, want_latency=True)
+    d.close()
+    us = lat.astype(np.float64) / 1e3
+    rec = {"kind": "reference", "cores": 1, "calls": int(calls),
+           "single_1": {"p50": percentile(us, 0.5), "p99": percentile(us, 0.99), "mean": float(us.mean())}}
+    for n in (2, 4, 8, 16, 32, 64, 128, 256):
+        if calls // n < 4:
+            break
+        g = us[:calls // n * n].reshape(-1, n).sum(axis=1)
+        rec["batch_%d" % n] = {"p50": percentile(g, 0.5), "p99": percentile(g, 0.99), "mean": float(g.mean())}
+    return rec
 
 
 def reference_td_surface(n_servants=2000, n_leases=100_000, heartbeats=150):

@@ -186,12 +186,16 @@ int ydc_dispatch(ydc_context* ctx, const ydc_task_soa* tasks, uint32_t n_tasks, 
  * n_rel released grants (FreeTask's --running_tasks, :181) and places n_tasks requests
  * (n x WaitForStartingNewTask with timeout == now, :93-140). Same answers as
  * ydc_update_servants_wide + ydc_release_slots + ydc_dispatch — which is what it does when the
- * batch is large (more than 64 requests), a heartbeat changes structure (a new servant, other
- * environments / version / host / capacity bound) or the registry is beyond 16384 servants /
- * 2048 classes. Otherwise ONE launch: a single workgroup reads the registry once, applies the
- * deltas, and makes the picks one after another (the reference's own arg-min,
- * :362-451, as a workgroup-wide min-reduction per pick); requests, deltas and results travel as
- * kernel arguments and stores to page-locked memory — no sort, no copy command, one wait.
+ * batch is large (more than 64 requests; 48 / 32 on registries beyond 4096 / 8192 servants), a
+ * heartbeat changes structure (a new servant, other environments / version / host / capacity
+ * bound) or the registry is beyond 16384 servants / 4096 classes. Otherwise ONE workgroup: it
+ * reads the registry once into registers, applies the deltas, and makes the picks one after
+ * another (the reference's own arg-min, :362-451, as a workgroup-wide min-reduction per pick;
+ * the identical requests of one RPC as one merge); requests, deltas and results travel as kernel
+ * arguments and stores to page-locked memory — no sort, no copy command, one wait. With
+ * YDC_DISPATCH_COMMIT the kernel then STAYS on its CU and takes the following calls from a
+ * page-locked mailbox (no launch, no column loads: a call is two PCIe round trips) until another
+ * entry point of the context needs the registry or nobody has called for 50 ms.
  * upd_env_masks (nullable): env_words words per heartbeat row, as ydc_update_servants_wide.
  * Host buffers in and out, synchronous. out_utilization is nullable. */
 int ydc_dispatch_tick(ydc_context* ctx, const uint32_t* upd_idx, const ydc_servant_row* upd_rows,

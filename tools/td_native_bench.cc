@@ -281,9 +281,9 @@ static int LatencyMode(int n_servants, int samples) {
   std::vector<std::vector<const char*>> envs;
   Register(td, n_servants, rng, 1, &sv, &locations, &envs);
   std::printf("{\"mode\": \"latency\", \"servants\": %d, \"samples\": %d, \"per_call_us\": {", n_servants, samples);
-  const std::size_t batches[] = {1, 1, 2, 16, 64, 256};  // (the first 1: single-request entry point)
+  const std::size_t batches[] = {1, 1, 2, 4, 8, 16, 32, 64, 128, 256};  // (the first 1: single-request entry point)
   bool first = true;
-  for (int bi = 0; bi < 6; ++bi) {
+  for (int bi = 0; bi < 10; ++bi) {
     const std::size_t batch = batches[bi];
     const bool single_entry = bi == 0;
     std::vector<const char*> ip_ptrs(batch), digest_ptrs(batch);

@@ -53,17 +53,21 @@ def main():
     print("k_tick on %d servants, %d requests of one signature, %d released grants per call; %d calls; "
           "microseconds after the kernel's entry (p50)" % (S, n, n_rel, reps))
     rel = (T - T[:, :1]) / 100.0
-    order = [0, 1, 2, 3, 4, 5] + list(range(8, 8 + min(n, 16))) + [6, 7]
+    order = [0, 1, 2, 3, 4] + ([5] + list(range(8, 8 + min(n, 16))) if not T[:, 27].any() else []) + [6, 7]
     prev = 0.0
     for s in order:
         v = np.median(rel[:, s])
         print("  %-40s %8.2f  (+%.2f)" % (NAMES.get(s, "pick %d done" % (s - 8)), v, v - prev))
         prev = v
-    if n > 2:
+    if n > 2 and not T[:, 27].any():
         for a, b, what in ((9, 24, "pick 2: candidates rescanned (the thread whose servant won pick 1)"),
                            (24, 25, "pick 2: workgroup reduction"), (25, 26, "pick 2: own-host flag (+ second reduction)"),
                            (26, 10, "pick 2: winner's state, key, results")):
             print("  %-70s %6.2f" % (what, np.median((T[:, b] - T[:, a]) / 100.0)))
+    if T[:, 27].any():
+        print("  merge: %d round(s), %d placed in the first; first round: lists built + visible at %.2f, merged at %.2f, "
+              "applied at %.2f us" % (np.median(T[:, 30]), np.median(T[:, 31]), np.median(rel[:, 27]),
+                                      np.median(rel[:, 28]), np.median(rel[:, 29])))
     print("host: python call p50 %.1f us (ctypes + numpy marshalling included)" % np.median(wall))
 
 

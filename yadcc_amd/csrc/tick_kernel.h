@@ -1,32 +1,44 @@
-// tick_kernel.h — the small-batch path: ONE launch places a handful of requests.
+// tick_kernel.h — the small-batch path: ONE workgroup places a handful of requests.
 //
 // The reference's real call shape is one WaitForStartingTask RPC asking for `waiters + 1` grants
 // (daemon/local/task_grant_keeper.cc:145-146; the loop at scheduler_service_impl.cc:234-264): one
 // to a few dozen requests against the whole registry. The batch pipeline (slot generation, sort,
 // speculative merge: four launches and more) costs 70-150 us whatever the batch holds; for a
 // handful of requests the reference's own arg-min loop (task_dispatcher.cc:362-451) is the right
-// algorithm — run by one workgroup:
+// algorithm — run by one workgroup, and, between calls, KEPT on its CU:
 //
-//   * the registry's columns are read ONCE, coalesced, servant s by thread s mod 1024, and turned
+//   * the registry's columns are read ONCE, coalesced, servant s by thread s mod THREADS, and turned
 //     into one 64-bit key per servant in registers: (tier << 63) | bits(double(running) / capacity)
 //     — the reference's own double (task_dispatcher.cc:440-441), positive doubles order like their
 //     bit patterns, tier 0 while DEDICATED and 2 * running < nproc (:399-410); ~0 = not free
-//     (GetCapacityAvailable, :283-313, in the closed form of dispatch_core.h);
+//     (GetCapacityAvailable, :283-313, in the closed form of dispatch_core.h). As few waves as hold
+//     the registry (256 threads up to 4096 servants): a pick costs a reduction, and every wave of a
+//     SIMD pays for it again;
 //   * eligibility (:316-344) comes from the servant's class — (environment set, version), as in
-//     the batch pipeline — through one bit mask per request, built by the workgroup in LDS for 64
-//     requests at a time (ballot per 64 classes);
+//     the batch pipeline — through a bit mask of the eligible classes per (digest, version
+//     threshold), built by the workgroup in LDS (ballot per 64 classes) when that pair changes;
+//     the servants' classes and hosts lie in LDS, read only then;
 //   * a pick is a min-reduction of (key, registry index) over the eligible free servants — first
 //     wins on ties, the reference's strict `<` (:440-447) — six DPP steps per wave, one LDS hop
-//     across the 16 waves, one barrier; the requestor's own servant (`self` = the first eligible
-//     free servant on its host, :372-379) is left out of it and is the last resort (:392-396);
-//     the winner's thread does `++running_tasks` (:123) and recomputes that one key;
+//     across the waves, one LDS-only barrier. Every thread CACHES its best candidate: only the
+//     thread whose servant was picked (or was touched by a heartbeat / a released grant) looks at
+//     its servants again. The requestor's own servant (`self` = the first eligible free servant
+//     on its host, :372-379) is left out and is the last resort (:392-396): a flag says whether
+//     any thread holds such a candidate at all, and only then a second reduction finds it;
+//   * the requests of one RPC are copies of one another: their n picks are ONE merge — every
+//     thread offers its next two candidates, wave 0 merges the sorted lists (a wave-wide reduction
+//     per pick, no workgroup barrier), rounds until all are placed;
 //   * heartbeat rows that change no structure (load, capacities) and released grants (FreeTask's
-//     `--running_tasks`, :181) ride in the same launch and are applied first; requests, deltas and
-//     results of a typical call travel as kernel arguments / plain stores to page-locked host
-//     memory — no copy command, no second launch, the host spins on a stamp the kernel stores last.
+//     `--running_tasks`, :181) ride with the requests: the thread that holds the servant patches
+//     its registers; running_tasks and the rows go back to the columns after the answer;
+//   * RESIDENT: the kernel of a COMMITting call does not end. It polls a page-locked mailbox
+//     (TickBox: eight self-validating 8-byte granules = one 64-byte PCIe read per poll), takes the
+//     next call's requests and deltas from it and answers the same way — no launch (7 us launch
+//     to first store on this box), no column loads. It leaves when told (every other entry point
+//     of the context ends it first) or when nobody has asked for 50 ms.
 //
 // Bit-exact with the batch pipeline and the oracle by construction (it IS the per-request scan);
-// tests/test_tick_gpu.py forces whole test pools through it.
+// tests/test_tick_gpu.py forces whole test pools through it, launched and resident.
 #ifndef YADCC_AMD_TICK_KERNEL_H_
 #define YADCC_AMD_TICK_KERNEL_H_
 
@@ -39,9 +51,10 @@ constexpr uint32_t kTickBlock = 64;          // results are flushed 64 requests 
 constexpr uint32_t kTickInlineTasks = 64;    // requests that travel as kernel arguments
 constexpr uint32_t kTickInlineUpd = 16;      // heartbeat rows ...
 constexpr uint32_t kTickInlineRel = 64;      // released grants ...
-constexpr uint32_t kTickMaxServants = 16384;  // 1024 threads x 16 servants in registers
+constexpr uint32_t kTickMaxServants = 16384;  // 512 threads x 32 servants in registers
 constexpr uint32_t kTickMaxClasses = 4096;    // eligible-class mask of a request: 64 words of LDS
 constexpr uint64_t kTickNoKey = ~0ull;
+constexpr uint32_t kTickMergeMin = 3;  // identical requests from which a command is placed as one merge
 
 // The columns of a heartbeat that changes no structure (KeepServantAlive, task_dispatcher.cc:195-201).
 struct TickRow {
@@ -60,6 +73,7 @@ struct TickDone {
 // heartbeat rows — lies in the arrays, stored before the head and read after it. The answer comes
 // back the same way (`reply`, then the arrays for more than seven placements / utilisations).
 constexpr uint32_t kTickCmdTick = 1, kTickCmdQuit = 2;
+constexpr uint32_t kTickCmdSame = 0x80;  // flag on kTickCmdTick: every request is a copy of the first (one RPC's requests)
 struct TickBox {
   unsigned long long head[8];  // {cmd | n_tasks << 8 | n_upd << 16 | n_rel << 24}, env, minv, rip, rel[0 .. 3]
   unsigned long long reply[8];  // {granted | timeouts << 8 | env_not_found << 16}, placement 0 .. 6
@@ -319,8 +333,12 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   }
 
   // ---- the registry into registers: G servants' columns in flight at a time ----
+  // Per servant in registers: the key and running_tasks (and, COLD, the columns a key is made
+  // of). Its class and its host are only looked at when the request signature changes: LDS.
   uint64_t key[K];
-  uint32_t cls[K], ip[K], c_run[K];
+  uint32_t c_run[K];
+  uint32_t* const s_ip = (uint32_t*)(s_mask + W + (THREADS <= 256 ? 4 * THREADS : 0));  // [K * THREADS], behind the merge's lists
+  uint16_t* const s_cls = (uint16_t*)(s_ip + K * THREADS);                              // [K * THREADS]
   uint32_t c_nproc[COLD ? K : 1], c_load[COLD ? K : 1], c_maxt[COLD ? K : 1], c_flags[COLD ? K : 1];
   uint32_t in_cls = 0;   // bit k: servant k of this thread accepts tasks at all (max_tasks != 0)
   uint32_t changed = 0;  // bit k: running_tasks of servant k is to be written back
@@ -348,8 +366,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       const int k = g + j;
       const uint32_t s = (uint32_t)k * THREADS + t;
       const bool live = s < S, inc = live && l_co[j] != kNone;
-      ip[k] = live ? l_ip[j] : 0u;
-      cls[k] = inc ? l_co[j] : 0u;
+      s_ip[s] = live ? l_ip[j] : 0u;
+      s_cls[s] = (uint16_t)(inc ? l_co[j] : 0u);
       in_cls |= (inc ? 1u : 0u) << k;
       c_run[k] = l_r[j];
       key[k] = tick_key(l_np[j], l_ld[j], l_mt[j], l_fl[j], l_r[j], inc);
@@ -364,6 +382,10 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   }
   YDC_TICK_STAMP(2);
 
+  // (the thread index as the command loop sees it: opaque to the compiler once per turn, or it
+  // hoists every per-servant index, address and mask out of the loop and spills them — 1.2 KB of
+  // scratch per lane in the 16-servants-per-thread kernels)
+  uint32_t tl = t;
   // What survives from one command of a resident kernel to the next: the eligible-class mask of
   // the last (digest, version threshold), the host the own-host bits belong to, and every
   // thread's cached candidates — a thread whose servants no command touches never rescans.
@@ -374,7 +396,112 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   TickBest mine{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
   TickOwn mine_own{kNone, kNone};
 
+  // The request signature the cached values belong to: one RPC's requests share it
+  // (scheduler_service_impl.cc:228-264), and digests and version thresholds are few.
+  auto set_signature = [&](uint32_t env, uint32_t minv, uint32_t rip) {
+    if (!have_sig || env != p_env || minv != p_minv) {
+      // Eligible classes: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
+      for (uint32_t c = t; c < W * 64; c += THREADS) {  // (whole waves)
+        bool bit = false;
+        if (c < C && env < 64 * EW)
+          bit = ((p_cls_env[(size_t)c * EW + (env >> 6)] >> (env & 63)) & 1u) && p_cls_ver[c] >= minv;
+        const uint64_t word = __ballot(bit);
+        if (lane == 0) s_mask[c >> 6] = word;
+      }
+      tick_lds_barrier();
+      uint64_t any_w = 0;
+      for (uint32_t w = 0; w < W; ++w) any_w |= s_mask[w];
+      any = any_w != 0;
+      elig = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t cl = s_cls[(uint32_t)k * THREADS + tl];
+        const uint64_t m = s_mask[cl >> 6];
+        elig |= (uint32_t)((m >> (cl & 63)) & ((in_cls >> k) & 1u)) << k;
+      }
+      dirty = true;
+      tick_lds_barrier();  // (s_mask is rewritten at the next change)
+    }
+    if (!have_sig || rip != p_rip) {
+      uint32_t nb = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) nb |= (s_ip[(uint32_t)k * THREADS + tl] == rip ? 1u : 0u) << k;
+      // (another requestor only matters to the threads that hold a servant of the old or the new host)
+      if (nb | ownb) dirty = true;
+      ownb = nb;
+    }
+    have_sig = true;
+    p_env = env;
+    p_minv = minv;
+    p_rip = rip;
+  };
+  // A thread's next TWO candidates (the merge below): the best of its servants and what would be
+  // its best once that one is taken — the runner-up, or the same servant at running + 1 (nk0).
+  TickBest e1{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+  uint64_t nk0 = kTickNoKey;
+  uint32_t k0 = 0, k1 = 0;
+  bool e1_same = false, list_valid = false;
+  auto build_list = [&]() {
+    uint64_t b0 = kTickNoKey, b1 = kTickNoKey;
+    uint32_t i0 = kNone, i1 = kNone;
+    k0 = k1 = 0;
+    mine_own.own1 = mine_own.own2 = kNone;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+      const uint32_t s = (uint32_t)k * THREADS + tl;
+      if ((ownb >> k) & 1u) {
+        if (mine_own.own1 == kNone) mine_own.own1 = s;
+        else if (mine_own.own2 == kNone) mine_own.own2 = s;
+      } else if (key[k] < b0) {  // (ascending s: the first of equal keys stays in front)
+        b1 = b0;
+        i1 = i0;
+        k1 = k0;
+        b0 = key[k];
+        i0 = s;
+        k0 = (uint32_t)k;
+      } else if (key[k] < b1) {
+        b1 = key[k];
+        i1 = s;
+        k1 = (uint32_t)k;
+      }
+    }
+    mine.khi = (uint32_t)(b0 >> 32);
+    mine.klo = (uint32_t)b0;
+    mine.idx = i0;
+    nk0 = kTickNoKey;
+    if (i0 != kNone) {
+      uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
+      if (!COLD) {
+        np = p_nproc[i0];
+        ld = p_load[i0];
+        mt = p_maxt[i0];
+        fl = p_flags[i0];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool me = (uint32_t)k == k0;
+        run = me ? c_run[k] : run;
+        if (COLD) {
+          np = me ? c_nproc[k] : np;
+          ld = me ? c_load[k] : ld;
+          mt = me ? c_maxt[k] : mt;
+          fl = me ? c_flags[k] : fl;
+        }
+      }
+      nk0 = tick_key(np, ld, mt, fl, run + 1, true);
+    }
+    e1_same = nk0 < b1 || (nk0 == b1 && i0 < i1);  // (both none: no second candidate either way)
+    const uint64_t kk = e1_same ? nk0 : b1;
+    e1.khi = (uint32_t)(kk >> 32);
+    e1.klo = (uint32_t)kk;
+    e1.idx = kk == kTickNoKey ? kNone : (e1_same ? i0 : i1);
+    dirty = false;
+    list_valid = true;
+  };
+
   for (;;) {  // one command per turn (a kernel that is not resident takes one turn)
+    asm volatile("" : "+v"(tl));
     tick_lds_barrier();  // (the staged command)
     YDC_TICK_STAMP(3);
     // ---- short delta lists: the owner patches its registers ----
@@ -382,7 +509,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     if (!p_upd_idx && n_upd) {
       for (uint32_t u = 0; u < n_upd; ++u) {
         const uint32_t s = s_uidx[u];
-        if (s < S && s % THREADS == t) {
+        if (s < S && s % THREADS == tl) {
           const TickRow r = s_urow[u];
           p_nproc[s] = r.nproc;
           p_load[s] = r.load;
@@ -392,7 +519,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       }
       for (uint32_t u = 0; u < n_upd; ++u) {
         const uint32_t s = s_uidx[u];
-        if (s < S && s % THREADS == t) {
+        if (s < S && s % THREADS == tl) {
           const TickRow r = s_urow[u];
           const uint32_t wk = s / THREADS;
           uint32_t run = 0;
@@ -419,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       uint32_t touched = 0;
       for (uint32_t j = 0; j < n_rel; ++j) {
         const uint32_t s = s_rel[j];
-        if (s < S && s % THREADS == t) {
+        if (s < S && s % THREADS == tl) {
           const uint32_t wk = s / THREADS;
 #pragma unroll
           for (int k = 0; k < K; ++k) c_run[k] -= (uint32_t)k == wk ? 1u : 0u;
@@ -431,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           if (!((touched >> k) & 1u)) continue;
-          const uint32_t s = (uint32_t)k * THREADS + t;
+          const uint32_t s = (uint32_t)k * THREADS + tl;
           uint32_t np, ld, mt, fl;
           if (COLD) {
             np = c_nproc[k];
@@ -453,7 +580,190 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     YDC_TICK_STAMP(4);
 
     uint32_t n_granted = 0, n_timeout = 0, n_envnf = 0;  // (thread 0's are reported)
-    for (uint32_t i = 0; i < n_tasks; ++i) {
+    uint32_t i_start = 0;
+    // ---- the requests of one RPC are copies of one another (scheduler_service_impl.cc:228-264):
+    // n picks as ONE merge. Every thread offers its next two candidates; the picks of the
+    // sequential process are the smallest (key, registry index) entries of the union of these
+    // sorted lists, in order — a thread's own servants are picked in the order of its list
+    // whatever the other threads do — so wave 0 alone merges them, a wave-wide reduction and no
+    // workgroup barrier per pick, until the requests are placed or a list runs dry (then the
+    // threads that were picked from make new lists: another round). Requests from a host that
+    // runs an eligible free servant (`self`, :372-396) take the pick-by-pick loop below.
+    // (256-thread kernels: the wider ones have no registers to spare for it)
+    if (THREADS <= 256 && !p_tenv && n_tasks >= kTickMergeMin && n_tasks <= kTickBlock) {
+      const bool differs = lane < n_tasks && (s_env[lane] != s_env[0] || s_minv[lane] != s_minv[0] || s_rip[lane] != s_rip[0]);
+      if (__ballot(differs) == 0) {
+        set_signature((uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[0]),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[0]),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[0]));
+        uint64_t* const s_lk = s_mask + W;                           // [2][THREADS] keys
+        uint32_t* const s_li = (uint32_t*)(s_lk + 2 * THREADS);      // [2][THREADS] registry indexes
+        uint32_t* const s_cnt = s_li + 2 * THREADS;                  // [THREADS] entries taken this round
+        if (!any) {  // :105-108, n times
+          if (t < n_tasks) {
+            s_out[t] = kIdxEnvNotFound;
+            s_util[t] = -1.0;
+          }
+          n_envnf += n_tasks;
+          i_start = n_tasks;
+        } else {
+          uint32_t placed = 0;
+          bool own_seen = false;
+          for (uint32_t round = 0; placed < n_tasks; ++round) {
+            if (dirty || !list_valid) build_list();
+            s_lk[t] = ((uint64_t)mine.khi << 32) | mine.klo;
+            s_lk[THREADS + t] = ((uint64_t)e1.khi << 32) | e1.klo;
+            s_li[t] = mine.idx;
+            s_li[THREADS + t] = e1.idx;
+            const uint32_t fl_i = pk % 3;
+            if (round == 0 && __ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
+            tick_lds_barrier();
+            if (round == 0) YDC_TICK_STAMP(27);
+            if (round == 0) {
+              own_seen = s_own_flag[fl_i] != 0;
+              if (t == 0) s_own_flag[(pk + 2) % 3] = 0;
+              ++pk;
+              if (own_seen) break;  // (nothing has been placed: the loop below takes all of them)
+            }
+            if (t < 64) {
+              constexpr int T = THREADS / 64;  // lists per lane: threads lane + 64 q
+              uint32_t pos = 0;                // 2 bits per list: entries taken
+              TickBest lb{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+              auto local_best = [&]() {
+                uint64_t bk = kTickNoKey;
+                uint32_t bi = kNone;
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                  const uint32_t pq = (pos >> (2 * q)) & 3u;
+                  if (pq < 2) {
+                    const uint64_t kq = s_lk[pq * THREADS + lane + 64 * q];
+                    const uint32_t iq = s_li[pq * THREADS + lane + 64 * q];
+                    if (kq < bk || (kq == bk && iq < bi)) {
+                      bk = kq;
+                      bi = iq;
+                    }
+                  }
+                }
+                lb.khi = (uint32_t)(bk >> 32);
+                lb.klo = (uint32_t)bk;
+                lb.idx = bk == kTickNoKey ? kNone : bi;
+              };
+              local_best();
+              uint32_t stop = 0;  // 1: a list ran dry, 2: nothing is free any more
+              while (placed < n_tasks && !stop) {
+                TickBest b = lb;
+                tick_row_reduce<16>(b);
+                tick_dpp_step<0x142, 0xa>(b);
+                tick_dpp_step<0x143, 0xc>(b);
+                const uint32_t bhi = tick_rl(b.khi, 63), blo = tick_rl(b.klo, 63), bidx = tick_rl(b.idx, 63);
+                if (bidx == kNone) {
+                  stop = 2;
+                  break;
+                }
+                if (lane == 0) {
+                  s_out[placed] = bidx;
+                  s_util[placed] = __longlong_as_double((long long)((((uint64_t)bhi << 32) | blo) & 0x7FFFFFFFFFFFFFFFull));
+                }
+                ++placed;
+                const uint32_t tw = bidx % THREADS;
+                bool dry = false;
+                if (lane == (tw & 63u)) {
+                  const uint32_t q2 = 2 * (tw >> 6);
+                  pos += 1u << q2;
+                  dry = ((pos >> q2) & 3u) == 2u;
+                  local_best();
+                }
+                if (__ballot(dry) != 0) stop = 1;
+              }
+#pragma unroll
+              for (int q = 0; q < T; ++q) s_cnt[lane + 64 * q] = (pos >> (2 * q)) & 3u;
+              if (lane == 0) {
+                s_cmd[2] = placed;
+                s_cmd[3] = stop;
+              }
+            }
+            tick_lds_barrier();
+            if (round == 0) YDC_TICK_STAMP(28);
+            const uint32_t took = s_cnt[t], stop = s_cmd[3];
+            placed = s_cmd[2];
+#ifdef YDC_PHASE_PROBE
+            if (t == 0) {
+              ydc_phase_probe[30] = round + 1;
+              if (round == 0) ydc_phase_probe[31] = placed;
+            }
+#endif
+            if (took) {
+              // ++running_tasks (:123) of what was taken from this thread: its first candidate, and
+              // with two its second — the same servant again, or the runner-up.
+              const uint32_t add0 = 1u + (took == 2 && e1_same ? 1u : 0u), add1 = took == 2 && !e1_same ? 1u : 0u;
+              uint32_t np0 = 0, ld0 = 0, mt0 = 0, fl0 = 0, r0 = 0, np1 = 0, ld1 = 0, mt1 = 0, fl1 = 0, r1 = 0;
+              if (!COLD) {
+                np0 = p_nproc[mine.idx];
+                ld0 = p_load[mine.idx];
+                mt0 = p_maxt[mine.idx];
+                fl0 = p_flags[mine.idx];
+                if (add1) {
+                  np1 = p_nproc[e1.idx];
+                  ld1 = p_load[e1.idx];
+                  mt1 = p_maxt[e1.idx];
+                  fl1 = p_flags[e1.idx];
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const bool m0 = (uint32_t)k == k0, m1 = add1 && (uint32_t)k == k1;
+                c_run[k] += m0 ? add0 : (m1 ? 1u : 0u);
+                r0 = m0 ? c_run[k] : r0;
+                r1 = m1 ? c_run[k] : r1;
+                if (COLD) {
+                  np0 = m0 ? c_nproc[k] : np0;
+                  ld0 = m0 ? c_load[k] : ld0;
+                  mt0 = m0 ? c_maxt[k] : mt0;
+                  fl0 = m0 ? c_flags[k] : fl0;
+                  np1 = m1 ? c_nproc[k] : np1;
+                  ld1 = m1 ? c_load[k] : ld1;
+                  mt1 = m1 ? c_maxt[k] : mt1;
+                  fl1 = m1 ? c_flags[k] : fl1;
+                }
+              }
+              const uint64_t nka = add0 == 1 ? nk0 : tick_key(np0, ld0, mt0, fl0, r0, true);
+              const uint64_t nkb = add1 ? tick_key(np1, ld1, mt1, fl1, r1, true) : 0;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const bool m0 = (uint32_t)k == k0, m1 = add1 && (uint32_t)k == k1;
+                key[k] = m0 ? nka : (m1 ? nkb : key[k]);
+              }
+              changed |= (1u << k0) | (add1 ? 1u << k1 : 0u);
+              dirty = true;
+            }
+            if (round == 0) YDC_TICK_STAMP(29);
+            if (stop == 2) {  // Timeout (:116-118) for every request that is left
+              if (t >= placed && t < n_tasks) {
+                s_out[t] = kIdxTimeout;
+                s_util[t] = -1.0;
+              }
+              n_timeout += n_tasks - placed;
+              n_granted += placed;
+              placed = n_tasks;
+              i_start = n_tasks;
+              break;
+            }
+            if (placed == n_tasks) {
+              n_granted += placed;
+              i_start = n_tasks;
+            }
+          }
+        }
+        if (i_start == n_tasks) {  // the results of a merged command (the loop below does not run)
+          tick_lds_barrier();
+          if (t < n_tasks) {
+            p_out_idx[t] = s_out[t];
+            if (p_out_util) p_out_util[t] = s_util[t];
+          }
+        }
+      }
+    }
+    for (uint32_t i = i_start; i < n_tasks; ++i) {
       const uint32_t oi = i & (kTickBlock - 1);
       if (p_tenv && oi == 0) {  // the next 64 requests' columns (device or mapped host memory)
         if (t < kTickBlock && i + t < n_tasks) {
@@ -467,43 +777,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       const uint32_t env = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[oi]),
                      minv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[oi]),
                      rip = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[oi]);
-      // The request signature the cached values belong to: one RPC's requests share it
-      // (scheduler_service_impl.cc:228-264), and digests and version thresholds are few.
-      if (!have_sig || env != p_env || minv != p_minv) {
-        // Eligible classes: UnsafeEnumerateEligibleServants per class (task_dispatcher.cc:324-338).
-        for (uint32_t c = t; c < W * 64; c += THREADS) {  // (whole waves)
-          bool bit = false;
-          if (c < C && env < 64 * EW)
-            bit = ((p_cls_env[(size_t)c * EW + (env >> 6)] >> (env & 63)) & 1u) && p_cls_ver[c] >= minv;
-          const uint64_t word = __ballot(bit);
-          if (lane == 0) s_mask[c >> 6] = word;
-        }
-        tick_lds_barrier();
-        uint64_t any_w = 0;
-        for (uint32_t w = 0; w < W; ++w) any_w |= s_mask[w];
-        any = any_w != 0;
-        elig = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const uint64_t m = s_mask[cls[k] >> 6];
-          elig |= (uint32_t)((m >> (cls[k] & 63)) & ((in_cls >> k) & 1u)) << k;
-        }
-        dirty = true;
-        tick_lds_barrier();  // (s_mask is rewritten at the next change)
-        if (i == 0) YDC_TICK_STAMP(5);
-      }
-      if (!have_sig || rip != p_rip) {
-        uint32_t nb = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) nb |= (ip[k] == rip ? 1u : 0u) << k;
-        // (another requestor only matters to the threads that hold a servant of the old or the new host)
-        if (nb | ownb) dirty = true;
-        ownb = nb;
-      }
-      have_sig = true;
-      p_env = env;
-      p_minv = minv;
-      p_rip = rip;
+      set_signature(env, minv, rip);
       if (!any) {  // nobody advertises the environment at that version: :105-108
         if (t == 0) {
           s_out[oi] = kIdxEnvNotFound;
@@ -517,7 +791,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
-            const uint32_t s = (uint32_t)k * THREADS + t;
+            const uint32_t s = (uint32_t)k * THREADS + tl;
             if ((ownb >> k) & 1u) {  // on the requestor's own host (ascending s: first, second)
               if (mine_own.own1 == kNone) mine_own.own1 = s;
               else if (mine_own.own2 == kNone) mine_own.own2 = s;
@@ -529,6 +803,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           mine.khi = (uint32_t)(bk >> 32);
           mine.klo = (uint32_t)bk;
           dirty = false;
+          list_valid = false;
         }
         if (i == 2) YDC_TICK_STAMP(24);
         // Own-host candidates are rare: a flag says whether the second reduction is needed at all.
@@ -550,7 +825,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
-              const uint32_t s = (uint32_t)k * THREADS + t;
+              const uint32_t s = (uint32_t)k * THREADS + tl;
               if (s != own.own1 && key[k] < bk) {
                 bk = key[k];
                 again.idx = s;
@@ -571,7 +846,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           ++n_timeout;
         } else {
           ++n_granted;
-          if (winner % THREADS == t) {
+          if (winner % THREADS == tl) {
             const uint32_t wk = winner / THREADS;
             uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
             uint64_t kw = 0;
@@ -637,7 +912,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     // running_tasks goes back: the servants this command touched (released grants, picks).
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t s = (uint32_t)k * THREADS + t;
+      const uint32_t s = (uint32_t)k * THREADS + tl;
       if ((changed >> k) & 1u) p_rw[s] = c_run[k];
       if (p_run_out && s < S) p_run_out[s] = c_run[k];
     }
@@ -686,7 +961,16 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         if (lane >= 4 && lane < 8) s_rel[lane - 4] = word;
         const uint32_t nt = (w0 >> 8) & 0xFF, nu = (w0 >> 16) & 0xFF, nr = w0 >> 24;
         // (what does not fit the head was stored before it; this read follows the head's)
-        if (nt > 1 && lane < nt) {
+        if (nt > 1 && (w0 & kTickCmdSame)) {  // copies of the first request: nothing more to fetch
+          const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 1),
+                         m0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 2),
+                         r0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 3);
+          if (lane < nt) {
+            s_env[lane] = e0;
+            s_minv[lane] = m0;
+            s_rip[lane] = r0;
+          }
+        } else if (nt > 1 && lane < nt) {
           s_env[lane] = __hip_atomic_load(&box->env[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           s_minv[lane] = __hip_atomic_load(&box->minv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           s_rip[lane] = __hip_atomic_load(&box->rip[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -704,7 +988,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       }
       if (lane == 0) {
         s_cmd[0] = w0;
-        s_cmd[1] = leave ? 2u : ((w0 & 0xFF) == kTickCmdQuit ? 1u : 0u);
+        s_cmd[1] = leave ? 2u : ((w0 & 0x7F) == kTickCmdQuit ? 1u : 0u);
       }
     }
     tick_lds_barrier();  // (s_cmd; the barrier at the top of the next turn covers the staged payload again)

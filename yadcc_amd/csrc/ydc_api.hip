@@ -280,7 +280,15 @@ struct ydc_context {
   uint8_t *h_tick_io = nullptr, *d_tick_io = nullptr;  // page-locked arena: columns / deltas in, results out
   size_t tick_io_cap = 0;
   uint32_t tick_seq = 0;
-  uint32_t opt_small_batch = 64;  // batches up to this many requests take it (small_batch=0: none does)
+  // Batches up to this many requests take it (small_batch=0: none does). kSmallBatchAuto: by
+  // registry size — a pick costs ~1 us at 2k servants and ~4 us at 16k, the batch pipeline
+  // ~90 / ~165 us whatever the batch holds (profiles/r05_td_latency_*.json).
+  static constexpr uint32_t kSmallBatchAuto = 0xFFFFFFFFu;
+  uint32_t opt_small_batch = kSmallBatchAuto;
+  uint32_t small_batch() const {
+    if (opt_small_batch != kSmallBatchAuto) return opt_small_batch;
+    return n_servants <= 4096 ? 64u : n_servants <= 8192 ? 48u : 32u;
+  }
   uint64_t tick_batches = 0;
   // The resident form: the kernel of a COMMITting tick stays on its CU, the registry in its
   // registers, and takes the following ticks from a page-locked mailbox (tick_kernel.h: TickBox) —
@@ -1944,7 +1952,7 @@ namespace {
 
 // Registries and batches the one-workgroup kernel takes (tables must be current).
 bool tick_takes(const ydc_context* c, uint32_t n_tasks) {
-  return c->opt_small_batch && n_tasks <= c->opt_small_batch && c->n_servants <= kTickMaxServants &&
+  return n_tasks <= c->small_batch() && c->small_batch() && c->n_servants <= kTickMaxServants &&
          c->tables.n_classes() <= kTickMaxClasses && c->h_alias_ip.empty() && c->group.n_ranks == 0 &&
          !c->stream_mode.active && c->pend_count == 0 && !c->debug_sim && !c->debug_verify_binsort;
 }
@@ -2062,10 +2070,6 @@ struct TickCall {
   bool out_on_device = false;
 };
 
-template <int THREADS, int K, bool COLD>
-void tick_launch(ydc_context* c, const TickArgs& a, size_t lds, hipStream_t stream) {
-  YDC_LAUNCH(c, "k_tick", (k_tick<THREADS, K, COLD>), dim3(1), dim3(THREADS), lds, stream, a);
-}
 
 // Fills the context's stats after a tick.
 void tick_stats(ydc_context* c, uint32_t N, uint32_t granted, uint32_t timeouts, uint32_t env_not_found) {
@@ -2120,8 +2124,13 @@ int tick_run(ydc_context* c, const TickCall& io) {
     if (__atomic_load_n(&b->alive, __ATOMIC_ACQUIRE) != 0) {
       if (++c->tick_seq == 0) c->tick_seq = 1;
       const uint32_t seq = c->tick_seq;
-      // Payload beyond the head first, the head's eight granules last.
-      if (N > 1)
+      // Payload beyond the head first, the head's eight granules last. (One RPC's requests are
+      // copies of one another, scheduler_service_impl.cc:228-264: then the head says so and holds all.)
+      bool same = N > 1;
+      for (uint32_t i = 1; i < N && same; ++i)
+        same = io.tasks->env_id[i] == io.tasks->env_id[0] && io.tasks->min_version[i] == io.tasks->min_version[0] &&
+               io.tasks->requestor_ip[i] == io.tasks->requestor_ip[0];
+      if (N > 1 && !same)
         for (uint32_t i = 0; i < N; ++i) {
           b->env[i] = io.tasks->env_id[i];
           b->minv[i] = io.tasks->min_version[i];
@@ -2133,7 +2142,7 @@ int tick_run(ydc_context* c, const TickCall& io) {
         b->upd[i] = TickRow{io.upd_rows[i].num_processors, io.upd_rows[i].current_load, io.upd_rows[i].max_tasks,
                             io.upd_rows[i].flags};
       }
-      uint32_t words[8] = {kTickCmdTick | (N << 8) | (io.n_upd << 16) | (io.n_rel << 24),
+      uint32_t words[8] = {kTickCmdTick | (same ? kTickCmdSame : 0u) | (N << 8) | (io.n_upd << 16) | (io.n_rel << 24),
                            N ? io.tasks->env_id[0] : 0u, N ? io.tasks->min_version[0] : 0u,
                            N ? io.tasks->requestor_ip[0] : 0u, 0u, 0u, 0u, 0u};
       for (uint32_t j = 0; j < 4 && j < io.n_rel; ++j) words[4 + j] = io.rel[j];
@@ -2265,16 +2274,28 @@ int tick_run(ydc_context* c, const TickCall& io) {
     for (int s = 0; s <= 6; ++s) mark(c, s);
   }
   // As few waves as hold the registry in registers, at most 16 servants per thread
-  // (tick_kernel.h): 256 threads up to 4096 servants, 512 up to 8192, 1024 beyond.
-  const size_t lds = (size_t)W * 8;
+  // (tick_kernel.h): 256 threads up to 4096 servants, 512 beyond (32 per thread above 8192).
   const uint32_t per_thread = std::max(1u, ceil_div(S, 256u));
-  if (per_thread <= 1) tick_launch<256, 1, true>(c, a, lds, launch_stream);
-  else if (per_thread <= 2) tick_launch<256, 2, true>(c, a, lds, launch_stream);
-  else if (per_thread <= 4) tick_launch<256, 4, true>(c, a, lds, launch_stream);
-  else if (per_thread <= 8) tick_launch<256, 8, true>(c, a, lds, launch_stream);
-  else if (per_thread <= 16) tick_launch<256, 16, true>(c, a, lds, launch_stream);
-  else if (per_thread <= 32) tick_launch<512, 16, true>(c, a, lds, launch_stream);
-  else tick_launch<1024, 16, false>(c, a, lds, launch_stream);
+  // As few waves as hold the registry in registers, at most 16 servants per thread
+  // (tick_kernel.h): 256 threads up to 4096 servants, 512 beyond (32 per thread above 8192).
+  // LDS: the eligible-class mask, the candidate lists of the merge (256-thread kernels, 32 B per
+  // thread), the servants' hosts and classes (6 B per servant slot).
+  auto launch = [&](auto kernel, uint32_t threads, uint32_t k) -> int {
+    const size_t lds = (size_t)W * 8 + (threads <= 256 ? (size_t)32 * threads : 0) + (size_t)6 * threads * k;
+    if (lds > 48 * 1024)
+      HIP_TRY(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    YDC_LAUNCH(c, "k_tick", kernel, dim3(1), dim3(threads), lds, launch_stream, a);
+    return YDC_OK;
+  };
+  int lrc;
+  if (per_thread <= 1) lrc = launch(k_tick<256, 1, true>, 256, 1);
+  else if (per_thread <= 2) lrc = launch(k_tick<256, 2, true>, 256, 2);
+  else if (per_thread <= 4) lrc = launch(k_tick<256, 4, true>, 256, 4);
+  else if (per_thread <= 8) lrc = launch(k_tick<256, 8, true>, 256, 8);
+  else if (per_thread <= 16) lrc = launch(k_tick<256, 16, true>, 256, 16);
+  else if (per_thread <= 32) lrc = launch(k_tick<512, 16, true>, 512, 16);
+  else lrc = launch(k_tick<512, 32, false>, 512, 32);
+  if (lrc) return lrc;
   HIP_TRY(c, hipGetLastError());
   mark(c, 7);
   ++c->tick_launches;
@@ -2343,7 +2364,7 @@ int ydc_dispatch_device(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint
   if (c->pend_count && !c->pend[c->pend_head].rerun && c->pend[c->pend_head].active)
     return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (N && N <= c->opt_small_batch && d_out_idx && !c->host_in.active && !c->post_copy.bytes) {
+  if (N && N <= c->small_batch() && d_out_idx && !c->host_in.active && !c->post_copy.bytes) {
     // A handful of requests: one launch of the one-workgroup kernel (tick_kernel.h).
     if (c->tables_dirty)
       if (int rc = rebuild_tables(c)) return rc;
@@ -2503,7 +2524,7 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
   if (!c || (N && (!tk || !out_idx))) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (N && N <= c->opt_small_batch) {
+  if (N && N <= c->small_batch()) {
     // A handful of requests: one launch of the one-workgroup kernel, the requests as kernel
     // arguments, the results stored to page-locked memory (tick_kernel.h).
     if (c->max_tasks && N > c->max_tasks)
