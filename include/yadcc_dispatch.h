@@ -409,6 +409,21 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
                                  uint64_t* out_grant_ids, char* out_locations,
                                  size_t location_stride, char* out_digests, size_t digest_stride,
                                  size_t cap);
+/* The same list without the copy: a view into the dispatcher's shared, immutable snapshot of it
+ * (RunningTaskBookkeeper::GetRunningTasks, running_task_bookkeeper.cc:36-43 — every daemon polls it
+ * once a second, daemon/local/running_task_keeper.cc:31-33, while it changes only with a servant's
+ * report). Ids as arrays, strings as (offset, length) into one pool, NUL-terminated there. The view
+ * stays valid — and unchanged — until the handle is released, whatever reports arrive meanwhile. */
+typedef struct ydc_td_running_view {
+  size_t n;
+  const uint64_t* servant_task_ids;
+  const uint64_t* task_grant_ids;
+  const uint32_t *location_off, *location_len; /* servant_location of task i: strings + location_off[i] */
+  const uint32_t *digest_off, *digest_len;     /* task_digest */
+  const char* strings;
+} ydc_td_running_view;
+int ydc_td_running_tasks_acquire(ydc_td* td, void** out_handle, ydc_td_running_view* out_view);
+int ydc_td_running_tasks_release(void* handle);
 /* Where the host class spent its time so far (cumulative, nanoseconds of the steady clock):
  * device_ns inside the device API (registry deltas + ydc_dispatch), host_ns in the class itself
  * (string lookups, lease records, results), both over `requests` placed requests in `batches`

@@ -163,6 +163,12 @@ static void Storm() {
         } else if (ev < 97) {
           (void)td.NotifyServantRunningTasks("10.1.0." + std::to_string(rnd() % kServants) + ":8335", {});
           (void)td.GetRunningTasks();
+          // the copy-free column snapshot, held across other threads' reports
+          auto cols = td.GetRunningTasksColumns();
+          std::size_t sum = 0;
+          for (std::size_t i = 0; i != cols->task_grant_ids.size(); ++i)
+            sum += cols->strings[cols->location_off[i]] + cols->digest_len[i];
+          CHECK(cols->location_off.size() == cols->task_grant_ids.size() && sum + 1 != 0);
         } else {
           td.OnExpirationTimer();
           (void)td.DumpInternals();

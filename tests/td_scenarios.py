@@ -466,6 +466,11 @@ def event_stream_matches_reference(make, seed, n_digests=3, n_pool=60, steps=400
             b = td.notify_servant_running_tasks(loc, ids)
             assert a == b, (seed, step)
             assert sorted(ref.get_running_tasks()) == sorted(td.get_running_tasks())
+            # the copy-free view of the same snapshot (ydc_td_running_tasks_acquire): same entries,
+            # every entry of a servant carrying that servant's location
+            view = td.running_tasks_view()
+            assert sorted((a_, b_) for a_, b_, _, _ in view) == sorted(td.get_running_tasks())
+            assert sorted((a_, b_, l_) for a_, b_, l_, _ in view) == sorted(td.get_running_tasks(with_strings=True))
         else:
             ms = int(rng.integers(200, 2500))
             R.clock_advance_ms(ms)

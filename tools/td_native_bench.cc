@@ -249,17 +249,29 @@ static int HeartbeatMode(int n_servants, std::size_t leases, int rounds) {
   auto p1 = Clk::now();
   for (int i = 0; i < polls; ++i) total = ydc_td_get_running_tasks(td, st.data(), gr.data(), locs.data(), 32, nullptr, 0, leases);
   auto p2 = Clk::now();
+  // ... and without the copy: a view into the shared snapshot (ydc_td_running_tasks_acquire / _release).
+  const int views = 200000;
+  std::uint64_t seen = 0;
+  for (int i = 0; i < views; ++i) {
+    void* h = nullptr;
+    ydc_td_running_view v{};
+    if (ydc_td_running_tasks_acquire(td, &h, &v) != YDC_OK) return 1;
+    seen += v.n ? v.task_grant_ids[(std::size_t)i % v.n] != 0 : 0;
+    ydc_td_running_tasks_release(h);
+  }
+  auto p3 = Clk::now();
   ydc_td_stats hs{};
   ydc_td_host_stats(td, &hs);
   std::printf("{\"mode\": \"heartbeat\", \"servants\": %d, \"leases\": %zu, \"rounds\": %d, "
               "\"heartbeats_per_s\": %.0f, \"us_per_heartbeat\": %.3f, \"first_round_heartbeats_per_s\": %.0f, "
               "\"reported_tasks_per_heartbeat\": %.1f, \"unknown_reported\": %zu, "
               "\"get_running_tasks_per_s\": %.1f, \"get_running_tasks_with_locations_per_s\": %.1f, "
+              "\"running_tasks_views_per_s\": %.0f, "
               "\"running_tasks_listed\": %lld, \"bookkeeper_rebuilds\": %llu}\n",
               n_servants, leases, rounds, (double)n_servants * rounds / steady_s,
               1e6 * steady_s / ((double)n_servants * rounds), n_servants / first_s,
               (double)leases / n_servants, unknown_total, polls / Secs(p0, p1), polls / Secs(p1, p2),
-              (long long)total, (unsigned long long)hs.bookkeeper_rebuilds);
+              views / Secs(p2, p3) + 0.0 * seen, (long long)total, (unsigned long long)hs.bookkeeper_rebuilds);
   ydc_td_destroy(td);
   return 0;
 }

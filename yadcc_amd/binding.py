@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
-    "ydc_td_free_tasks", "ydc_td_host_stats",
+    "ydc_td_free_tasks", "ydc_td_host_stats", "ydc_td_running_tasks_acquire", "ydc_td_running_tasks_release",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
     "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
 )
@@ -177,7 +177,7 @@ _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GU
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
-              "ROUNDS_PER_CHECK", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+              "ROUNDS_PER_CHECK", "WALK_AFTER", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
 _tune_injected = ""
 
 

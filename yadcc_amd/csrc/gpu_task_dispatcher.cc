@@ -146,6 +146,7 @@ void RunningTaskBookkeeper::SetServantRunningTasks(std::string_view servant_loca
     h.task_digest.assign(t.task_digest.data(), t.task_digest.size());
   }
   flattened_.reset();
+  columns_.reset();
 }
 
 void RunningTaskBookkeeper::DropServant(std::string_view servant_location) {
@@ -154,7 +155,10 @@ void RunningTaskBookkeeper::DropServant(std::string_view servant_location) {
   if (!have) return;
   const bool had_tasks = !have->empty();
   running_tasks_.erase(servant_location);
-  if (had_tasks) flattened_.reset();
+  if (had_tasks) {
+    flattened_.reset();
+    columns_.reset();
+  }
 }
 
 RunningTaskBookkeeper::Snapshot RunningTaskBookkeeper::GetRunningTasksShared() const {
@@ -176,6 +180,50 @@ RunningTaskBookkeeper::Snapshot RunningTaskBookkeeper::GetRunningTasksShared() c
 }
 
 std::vector<RunningTask> RunningTaskBookkeeper::GetRunningTasks() const { return *GetRunningTasksShared(); }
+
+RunningTaskBookkeeper::ColumnsSnapshot RunningTaskBookkeeper::GetRunningTasksColumns() const {
+  std::scoped_lock _(lock_);
+  if (!columns_) {
+    auto cols = std::make_shared<RunningTaskColumns>();
+    std::size_t total = 0;
+    running_tasks_.for_each([&](const std::string&, const std::vector<RunningTask>& v) { total += v.size(); });
+    cols->servant_task_ids.reserve(total);
+    cols->task_grant_ids.reserve(total);
+    cols->location_off.reserve(total);
+    cols->digest_off.reserve(total);
+    cols->location_len.reserve(total);
+    cols->digest_len.reserve(total);
+    FlatStringMap<std::uint32_t> pooled;  // string -> offset in the pool
+    auto intern = [&](const std::string& str) {
+      if (const std::uint32_t* at = pooled.find(str)) return *at;
+      const std::uint32_t at = (std::uint32_t)cols->strings.size();
+      cols->strings.append(str);
+      cols->strings.push_back('\0');
+      pooled.emplace(str, at);
+      return at;
+    };
+    running_tasks_.for_each([&](const std::string&, const std::vector<RunningTask>& v) {
+      const std::string* last_loc = nullptr;
+      std::uint32_t last_at = 0;
+      for (const RunningTask& t : v) {
+        cols->servant_task_ids.push_back(t.servant_task_id);
+        cols->task_grant_ids.push_back(t.task_grant_id);
+        // (a servant's tasks carry its own location: asked once)
+        if (!last_loc || *last_loc != t.servant_location) {
+          last_at = intern(t.servant_location);
+          last_loc = &t.servant_location;
+        }
+        cols->location_off.push_back(last_at);
+        cols->location_len.push_back((std::uint32_t)t.servant_location.size());
+        cols->digest_off.push_back(intern(t.task_digest));
+        cols->digest_len.push_back((std::uint32_t)t.task_digest.size());
+      }
+    });
+    columns_ = std::move(cols);
+    ++rebuilds_;
+  }
+  return columns_;
+}
 
 // ---------------------------------------------------------------------------
 // Task records

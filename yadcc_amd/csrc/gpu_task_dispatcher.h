@@ -124,9 +124,21 @@ struct RunningTaskView {
 // only with its own heartbeat — and most heartbeats report the list they
 // reported a second ago, so a report is compared with what is stored before
 // anything is replaced or invalidated.
+// The flattened running-task list as columns (what the C-ABI hands out without a copy,
+// ydc_td_running_tasks_acquire): ids as arrays, strings as offsets into one pool — every string
+// NUL-terminated there, a servant's location stored once for all its tasks, a digest once per
+// distinct value.
+struct RunningTaskColumns {
+  std::vector<std::uint64_t> servant_task_ids, task_grant_ids;
+  std::vector<std::uint32_t> location_off, digest_off;  // per task: where its string starts in `strings`
+  std::vector<std::uint32_t> location_len, digest_len;
+  std::string strings;
+};
+
 class RunningTaskBookkeeper {
  public:
   using Snapshot = std::shared_ptr<const std::vector<RunningTask>>;
+  using ColumnsSnapshot = std::shared_ptr<const RunningTaskColumns>;
   void SetServantRunningTasks(const std::string& servant_location, std::vector<RunningTask> tasks);
   // The entries `keep[0..n_keep)` of `tasks` (report order).
   void SetServantRunningTasks(std::string_view servant_location, const RunningTaskView* tasks,
@@ -135,12 +147,15 @@ class RunningTaskBookkeeper {
   std::vector<RunningTask> GetRunningTasks() const;
   // The flattened list without the copy: shared with later callers until a report changes it.
   Snapshot GetRunningTasksShared() const;
+  // ... and as columns: built once per change of the list, shared by every caller until the next.
+  ColumnsSnapshot GetRunningTasksColumns() const;
   std::uint64_t rebuilds() const { return rebuilds_; }
 
  private:
   mutable std::mutex lock_;
   FlatStringMap<std::vector<RunningTask>> running_tasks_;
   mutable Snapshot flattened_;
+  mutable ColumnsSnapshot columns_;
   mutable std::uint64_t rebuilds_ = 0;
 };
 
@@ -209,6 +224,9 @@ class GpuTaskDispatcher {
                                                        const RunningTaskView* tasks, std::size_t n);
   RunningTaskBookkeeper::Snapshot GetRunningTasksShared() const {
     return running_task_bookkeeper_.GetRunningTasksShared();
+  }
+  RunningTaskBookkeeper::ColumnsSnapshot GetRunningTasksColumns() const {
+    return running_task_bookkeeper_.GetRunningTasksColumns();
   }
   void FreeTasks(const std::uint64_t* task_ids, std::size_t n);  // n FreeTask calls, one lock
 

@@ -688,6 +688,12 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   uint32_t pass = pass_arg;  // (becomes 1 when the launch of pass 0 goes on with pass 1)
   const bool device_check = flags & 1u;  // an earlier consistent pass ends the work
   const bool count_sims = flags & 2u;   // debug: count replays (a same-address atomic each)
+  // The host has given up on parallel repair (32 passes and the end states still change: every
+  // chunk's true start state differs from any guess — e.g. a hole at every boundary).
+  // Two launches replace the rest: a scout — every inconsistent chunk reports its index, the
+  // lowest is the frontier (everything below it is final) — and the walk: the frontier's wave
+  // replays its chunk from the true state and carries on through every chunk behind it.
+  const bool walk_scout = flags & 8u, walk_run = flags & 16u;
   uint32_t kc = blockIdx.x;  // chunk
   const uint32_t probe_kc = blockIdx.x;
   [[maybe_unused]] uint64_t probe_topup = 0, probe_loop = 0;  // (measurement builds only)
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
   const uint32_t batch_seq = prm->batch_seq;
   const uint32_t n_slots_all = prm->n_slots;
+  const uint32_t walk_frontier = prm->reserved0;
   const uint32_t prev_changed = device_check && pass > 0 ? B.flags[(pass - 1) & B.flag_mask] : 1u;
   const bool own_guess = W == 1 && pass == 0 && B.before != nullptr;
   const bool warm_mode = own_guess && B.hand != nullptr && B.tail != nullptr && B.n_parts <= 1 &&
@@ -1005,7 +1012,15 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
     }
     if (pass != 0) {
       if (__ballot(differs) == 0) return;  // consistent
-      if (pass >= 2 && kc >= 1 && B.sampled[(pass - 1) & B.flag_mask] < 4) {
+      if (walk_scout) {
+        if (lane == 0) {
+          atomicMin(&prm->reserved0, kc);
+          B.flags[pass & B.flag_mask] = 1;  // (not final)
+        }
+        return;
+      }
+      if (walk_run && kc != walk_frontier) return;
+      if (!walk_run && pass >= 2 && kc >= 1 && B.sampled[(pass - 1) & B.flag_mask] < 4) {
         // Few end states changed in the previous pass (sampled estimate < ~64): what is left
         // are chains — chunks whose predecessor's end state keeps changing. A chunk whose
         // predecessor is itself inconsistent would replay from a stale state; it leaves the
@@ -1032,7 +1047,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       // Inconsistent: this pass has work. One wave per chunk and pass.
       uint32_t taken = 0;
       if (lane == 0) taken = atomicMax(&B.claim[kc], stamp) == stamp;
-      if (readlane_u32(taken, 0)) return;  // a wave following its chain got here first
+      if (readlane_u32(taken, 0) && !walk_run) return;  // a wave following its chain got here first
     }
   }
 
@@ -1578,6 +1593,12 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       ring_ready = false;
       warm = false;
       continue;  // replay chunk kc from the predecessor's end state, with pass 1's early stops
+    }
+    if (walk_run) {  // the walk: on to the next chunk, whatever this one's end state did
+      if (kc + 1 >= n_chunks) return;
+      ++kc;
+      if (lane == 0) (void)atomicMax(&B.claim[kc], stamp);
+      continue;
     }
     if (!changed) return;  // nothing downstream is affected
     // (Within the launch of pass 0 every chunk belongs to its own wave: no following.)

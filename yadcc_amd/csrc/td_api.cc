@@ -221,6 +221,27 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
   return (int64_t)tasks.size();
 }
 
+int ydc_td_running_tasks_acquire(ydc_td* td, void** out_handle, ydc_td_running_view* out_view) {
+  if (!td || !out_handle || !out_view) return YDC_ERR_INVALID_ARGUMENT;
+  auto* held = new ydc::RunningTaskBookkeeper::ColumnsSnapshot(td->impl->GetRunningTasksColumns());
+  const ydc::RunningTaskColumns& c = **held;
+  out_view->n = c.task_grant_ids.size();
+  out_view->servant_task_ids = c.servant_task_ids.data();
+  out_view->task_grant_ids = c.task_grant_ids.data();
+  out_view->location_off = c.location_off.data();
+  out_view->location_len = c.location_len.data();
+  out_view->digest_off = c.digest_off.data();
+  out_view->digest_len = c.digest_len.data();
+  out_view->strings = c.strings.c_str();
+  *out_handle = held;
+  return YDC_OK;
+}
+
+int ydc_td_running_tasks_release(void* handle) {
+  delete (ydc::RunningTaskBookkeeper::ColumnsSnapshot*)handle;
+  return YDC_OK;
+}
+
 int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out) {
   if (!td || !out) return YDC_ERR_INVALID_ARGUMENT;
   const auto s = td->impl->host_stats();

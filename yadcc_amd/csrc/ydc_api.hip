@@ -344,6 +344,13 @@ struct ydc_context {
   uint64_t binsort_misses = 0;
   int64_t opt_shard_margin = -1;  // >= 0: margin of the key windows in slots (tests)
   uint32_t opt_rounds_per_check = 2;
+  // Passes after which the matching stops repairing chunks in parallel and lets one wave walk
+  // each chain to its end (match_kernel.h: walk): registries whose every chunk boundary carries a
+  // state no guess predicts (a handful of servants with tens of thousands of slots and requests
+  // from their own hosts: 554 passes, 1.2 s; healthy batches need 2 - 4) — `walk_after` passes, then
+  // a scout and the walk.
+  uint32_t opt_walk_after = 12;
+  uint32_t walk_flag = 0;
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
   ydc_stats stats{};
@@ -751,6 +758,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
   if (const char* s = tune_value("resident")) c->opt_resident = atoi(s) != 0;
   if (const char* s = tune_value("resident_idle_ms")) c->opt_resident_idle_ms = (uint32_t)std::max(1, atoi(s));
+  if (const char* s = tune_value("walk_after")) c->opt_walk_after = (uint32_t)std::max(2, atoi(s));
   if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
   *out = c;
@@ -1582,6 +1590,7 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   const size_t lds = (size_t)p.ring_total * 8;
   device_check |= c->debug_sim ? 2u : 0u;
   device_check |= c->opt_pair ? 4u : 0u;
+  device_check |= c->walk_flag;  // (8: the walk's scout, 16: the walk itself — match_kernel.h)
   device_check |= p.ring_total << 8;
   DeviceParams* prm = c->d_prm.p;
   // (rings of 32 entries are watched by the fast loop itself: match_kernel.h, CHECKED)
@@ -1720,6 +1729,7 @@ void collect_kernel_profile(ydc_context* c) {
 int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t launched, uint32_t flags,
                                 uint32_t* d_out_idx, double* d_out_util, uint32_t* d_out_running,
                                 uint32_t* rounds) {
+  bool walked = false;
   for (;;) {
     const uint32_t group = launched == 0 ? std::max(2u, std::min(c->round_hint, 16u)) : 4u;
     if (launched) {
@@ -1731,7 +1741,20 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
       }
     }
     const uint32_t first = launched;
-    for (uint32_t r = launched; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
+    if (launched >= c->opt_walk_after && !walked && group >= 4) {
+      // Parallel repair is not getting anywhere (one chunk per pass): scout + walk, then two
+      // ordinary passes that find everything consistent (match_kernel.h: walk_scout / walk_run).
+      walked = true;
+      HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->reserved0, 0xFF, 4, c->stream));
+      c->walk_flag = 8u;
+      enqueue_pass(c, p, launched, 1u);
+      c->walk_flag = 16u;
+      enqueue_pass(c, p, launched + 1, 1u);
+      c->walk_flag = 0;
+      for (uint32_t r = launched + 2; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
+    } else {
+      for (uint32_t r = launched; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
+    }
     launched += group;
     if (int rc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running,
                                   (launched - 1) & 63))

@@ -18,7 +18,7 @@ TD_SYMBOLS = (
     "ydc_td_create", "ydc_td_destroy", "ydc_td_device_status", "ydc_td_set_clock_ns",
     "ydc_td_keep_servant_alive", "ydc_td_wait_for_starting_new_task",
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
-    "ydc_td_free_tasks", "ydc_td_host_stats",
+    "ydc_td_free_tasks", "ydc_td_host_stats", "ydc_td_running_tasks_acquire", "ydc_td_running_tasks_release",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
     "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
 )
@@ -36,6 +36,13 @@ class _Servant(C.Structure):
 class _RunningTask(C.Structure):
     _fields_ = [("servant_task_id", C.c_uint64), ("task_grant_id", C.c_uint64),
                 ("servant_location", C.c_char_p), ("task_digest", C.c_char_p)]
+
+
+class _RunningView(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("servant_task_ids", C.POINTER(C.c_uint64)),
+                ("task_grant_ids", C.POINTER(C.c_uint64)), ("location_off", C.POINTER(C.c_uint32)),
+                ("location_len", C.POINTER(C.c_uint32)), ("digest_off", C.POINTER(C.c_uint32)),
+                ("digest_len", C.POINTER(C.c_uint32)), ("strings", C.c_void_p)]
 
 
 class _TdStats(C.Structure):
@@ -64,6 +71,8 @@ def type_td_functions(L):
         L.ydc_td_free_task.argtypes = [C.c_void_p, C.c_uint64]
         L.ydc_td_free_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ydc_td_host_stats.argtypes = [C.c_void_p, C.POINTER(_TdStats)]
+        L.ydc_td_running_tasks_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(_RunningView)]
+        L.ydc_td_running_tasks_release.argtypes = [C.c_void_p]
         L.ydc_td_notify_servant_running_tasks.argtypes = [
             C.c_void_p, C.c_char_p, C.POINTER(_RunningTask), C.c_size_t, C.c_void_p, C.c_size_t]
         L.ydc_td_notify_servant_running_tasks.restype = C.c_int64
@@ -216,6 +225,22 @@ class GpuTaskDispatcher:
         raw = locs.raw
         return [(a, b, raw[i * self.LOC:(i + 1) * self.LOC].split(b"\0", 1)[0].decode())
                 for i, (a, b) in enumerate(pairs)]
+
+    def running_tasks_view(self):
+        """The shared snapshot behind GetRunningTasks without the copy (ydc_td_running_tasks_acquire
+        / _release): [(servant_task_id, task_grant_id, servant_location, task_digest), ...]."""
+        h, v = C.c_void_p(), _RunningView()
+        assert self._L.ydc_td_running_tasks_acquire(self._h, C.byref(h), C.byref(v)) == 0
+        try:
+            out = []
+            for i in range(v.n):
+                loc = C.string_at(v.strings + v.location_off[i], v.location_len[i]).decode()
+                dig = C.string_at(v.strings + v.digest_off[i], v.digest_len[i]).decode()
+                assert C.string_at(v.strings + v.location_off[i]) == loc.encode()  # NUL-terminated in the pool
+                out.append((int(v.servant_task_ids[i]), int(v.task_grant_ids[i]), loc, dig))
+            return out
+        finally:
+            self._L.ydc_td_running_tasks_release(h)
 
     def on_expiration_timer(self):
         self._L.ydc_td_on_expiration_timer(self._h)
