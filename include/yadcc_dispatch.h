@@ -262,6 +262,19 @@ int ydc_stream_tick_wide(ydc_context* ctx, const uint32_t* upd_idx, const ydc_se
                          const uint64_t* upd_env_masks, uint32_t env_words, uint32_t n_upd,
                          const uint32_t* release_servant_idx, uint32_t n_rel,
                          const ydc_task_soa* tasks, uint32_t n_tasks, uint32_t* out_servant_idx);
+/* The page-locked arrays a tick is staged in (capacities as given to ydc_stream_begin; valid until
+ * ydc_stream_end). A caller that assembles its tick right there and passes these very pointers to
+ * ydc_stream_tick / _wide (requests as a ydc_task_soa of env_id / min_version / requestor_ip,
+ * out_servant_idx for the answers) is not copied on either side: the captured step reads and
+ * writes them in place. */
+typedef struct ydc_stream_buffers {
+  uint32_t* upd_idx;
+  ydc_servant_row* upd_rows;
+  uint32_t* release_servant_idx;
+  uint32_t *env_id, *min_version, *requestor_ip;
+  uint32_t* out_servant_idx;
+} ydc_stream_buffers;
+int ydc_stream_buffers_get(ydc_context* ctx, ydc_stream_buffers* out);
 int ydc_stream_end(ydc_context* ctx);
 
 /* ---- multi-GPU group: one batch sharded by rank range (BASELINE.json configs[3]) ------

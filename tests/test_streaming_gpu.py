@@ -11,19 +11,28 @@ pytestmark = pytest.mark.gpu
 
 
 def run_stream(n_servants, tasks_per_tick, frees_per_tick, ticks, n_envs=1, varying=False,
-               capacity=None):
+               capacity=None, in_place=False):
     sv = synth.make_servants(n_servants, n_tasks_hint=tasks_per_tick * 6, n_envs=n_envs, seed=42)
     es = streaming.EventStream(sv, tasks_per_tick, frees_per_tick, n_envs=n_envs)
     ctx = binding.Context(device=0)
     ctx.upload_servants(pack.to_abi_columns(sv))
     cap = capacity or tasks_per_tick
     ctx.stream_begin(es.hb + 8, max(frees_per_tick, 1), cap)
+    views = ctx.stream_buffers(es.hb + 8, max(frees_per_tick, 1), cap) if in_place else None
     for t in range(ticks):
         who, rows, rel, tk = es.next_tick()
         if varying and t % 3 == 1:  # fewer requests than the captured capacity
             tk = {k: v[: len(v) // 3] for k, v in tk.items()}
         want, _, wrun = O.dispatch(es.registry_snapshot(), tk, "sorted")
-        got = ctx.stream_tick(who, rows, rel, tk)
+        if in_place:  # the tick assembled in the library's page-locked arena: nothing is copied
+            views["upd_idx"][:len(who)] = who
+            views["upd_rows"][:len(who)] = np.asarray(rows, dtype=binding.ROW_DTYPE)
+            views["release_idx"][:len(rel)] = rel
+            for k in ("env_id", "min_version", "requestor_ip"):
+                views[k][:len(tk[k])] = tk[k]
+            got = ctx.stream_tick_inplace(len(who), len(rel), len(tk["env_id"])).copy()
+        else:
+            got = ctx.stream_tick(who, rows, rel, tk)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "tick %d: first mismatch at request %d (gpu %d oracle %d), %d total" % (
             t, bad[0], got[bad[0]], want[bad[0]], bad.size)
@@ -41,8 +50,18 @@ def test_stream_cfg5_shape():
     assert es.tick_no == 12 and len(es.live) > 0
 
 
-def test_stream_multi_env_varying_counts():
+@pytest.mark.parametrize("zero_copy", ["1", "0"])
+def test_stream_multi_env_varying_counts(zero_copy, monkeypatch):
+    """zero_copy = 1: the captured step reads the tick's page-locked arena in place and k_finalize
+    stores placement and outcome to page-locked memory (no copy node); 0: three copy nodes."""
+    monkeypatch.setenv("YDC_STREAM_ZERO_COPY", zero_copy)
+    monkeypatch.setenv("YDC_OUTCOME_STORE", zero_copy)
     run_stream(600, 3000, 2500, ticks=15, n_envs=3, varying=True)
+
+
+def test_stream_assembled_in_place():
+    """ydc_stream_buffers_get: the caller fills the page-locked arena itself and passes its pointers."""
+    run_stream(800, 4000, 3000, ticks=12, n_envs=2, varying=True, in_place=True)
 
 
 def test_stream_saturated_pool_times_out():

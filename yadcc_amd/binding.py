@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
     "ydc_device_malloc", "ydc_device_free", "ydc_memcpy_h2d", "ydc_memcpy_d2h",
     "ydc_host_register", "ydc_host_unregister", "ydc_host_alloc", "ydc_host_free",
-    "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_tick_wide", "ydc_stream_end",
+    "ydc_stream_begin", "ydc_stream_tick", "ydc_stream_tick_wide", "ydc_stream_buffers_get", "ydc_stream_end",
     "ydc_group_unique_id", "ydc_group_init", "ydc_group_init_local", "ydc_group_destroy",
     "ydc_group_size", "ydc_group_ipc_export", "ydc_group_init_ipc", "ydc_group_transport",
     "ydc_dispatch_sharded",
@@ -129,6 +129,7 @@ def lib():
         L.ydc_stream_tick_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                            C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(TaskSoA),
                                            C.c_uint32, C.c_void_p]
+        L.ydc_stream_buffers_get.argtypes = [C.c_void_p, C.c_void_p]
         L.ydc_stream_end.argtypes = [C.c_void_p]
         L.ydc_group_unique_id.argtypes = [C.c_void_p]
         L.ydc_group_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -177,7 +178,7 @@ _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GU
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
-              "ROUNDS_PER_CHECK", "WALK_AFTER", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+              "ROUNDS_PER_CHECK", "WALK_AFTER", "OUTCOME_STORE", "STREAM_ZERO_COPY", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
 _tune_injected = ""
 
 
@@ -545,6 +546,34 @@ class Context:
                                                    rel.ctypes.data, len(rel), C.byref(soa), n,
                                                    out.ctypes.data), "ydc_stream_tick_wide")
         return out
+
+    def stream_buffers(self, max_updates, max_releases, max_tasks):
+        """numpy views of the page-locked arrays a tick is staged in (ydc_stream_buffers_get): fill
+        them in place and call stream_tick_inplace — nothing is copied on either side."""
+        class _B(C.Structure):
+            _fields_ = [(k, C.c_void_p) for k in ("upd_idx", "upd_rows", "release_servant_idx", "env_id",
+                                                   "min_version", "requestor_ip", "out_servant_idx")]
+        b = _B()
+        self._check(lib().ydc_stream_buffers_get(self._h, C.byref(b)), "ydc_stream_buffers_get")
+
+        def view(p, n, dt):
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p)
+            return np.frombuffer(buf, dtype=dt, count=n)
+        self._stream_views = {
+            "upd_idx": view(b.upd_idx, max_updates, np.uint32), "upd_rows": view(b.upd_rows, max_updates, ROW_DTYPE),
+            "release_idx": view(b.release_servant_idx, max_releases, np.uint32),
+            "env_id": view(b.env_id, max_tasks, np.uint32), "min_version": view(b.min_version, max_tasks, np.uint32),
+            "requestor_ip": view(b.requestor_ip, max_tasks, np.uint32), "out": view(b.out_servant_idx, max_tasks, np.uint32)}
+        return self._stream_views
+
+    def stream_tick_inplace(self, n_upd, n_rel, n_tasks):
+        """One tick whose data already lies in stream_buffers(); the answers are in views["out"][:n_tasks]."""
+        v = self._stream_views
+        soa = TaskSoA(v["env_id"].ctypes.data, v["min_version"].ctypes.data, v["requestor_ip"].ctypes.data)
+        self._check(lib().ydc_stream_tick(self._h, v["upd_idx"].ctypes.data, v["upd_rows"].ctypes.data, n_upd,
+                                          v["release_idx"].ctypes.data, n_rel, C.byref(soa), n_tasks,
+                                          v["out"].ctypes.data), "ydc_stream_tick")
+        return v["out"][:n_tasks]
 
     def stream_end(self):
         self._check(lib().ydc_stream_end(self._h), "ydc_stream_end")

@@ -77,6 +77,9 @@ struct DeviceParams {
   // become final within its pre-launched passes — the batches enqueued behind it take no effect
   // (their finalise is gated on this) and the host replays from there. Cleared by the host.
   uint32_t pipeline_broken;
+  // k_finalize's servant workgroups that have reported (the last one hands the outcome to the
+  // host and clears it).
+  uint32_t fin_reports;
 };
 
 // Measurement builds only (`make probe`): wall-clock stamps the kernels leave behind
@@ -1291,6 +1294,11 @@ struct RunningArgs {
   // Pipelined batches: a batch that is not final latches DeviceParams::pipeline_broken, and no
   // batch takes effect while it is set.
   uint32_t pipelined;
+  // Non-NULL: the device address of a page-locked DeviceParams — the launch's last servant
+  // workgroup stores the batch's outcome there itself (the 560-byte read-back was a blit kernel
+  // of its own: 3.9 us of a 60 us step).
+  DeviceParams* host_outcome;
+  uint32_t srv_blocks;
 };
 
 // Slots of servant s (class c) that sort before what `st` has not consumed yet.
@@ -1326,7 +1334,8 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
   // with a sharded sort, only if every rank's key window covered what its requests reached).
   const bool final = (check_slot == kNone || prm->n_changed[check_slot] == 0) && !prm->window_miss &&
                      !(ra.pipelined && (prm->pipeline_broken || prm->overflow));
-  if (ra.pipelined && !final && blockIdx.x == req_blocks && threadIdx.x == 0) prm->pipeline_broken = 1;
+  if (ra.pipelined && !final && blockIdx.x == req_blocks && threadIdx.x == 0)
+    __hip_atomic_store(&prm->pipeline_broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x < req_blocks) {
     if (!final) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1372,6 +1381,24 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
   uint32_t total;
   (void)block_exclusive_scan(taken, lds, &total);
   if (threadIdx.x == 0 && total) atomicAdd(&prm->granted, total);
+  if (ra.host_outcome) {
+    // The servant workgroup that reports last has everybody's grants behind it: it hands the
+    // counters to the host (plain stores to page-locked memory; the host waits for the launch).
+    __shared__ uint32_t last;
+    if (threadIdx.x == 0) {
+      __threadfence();
+      last = atomicAdd(&prm->fin_reports, 1u) == ra.srv_blocks - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      const uint32_t* src = (const uint32_t*)prm;
+      uint32_t* dst = (uint32_t*)ra.host_outcome;
+      for (uint32_t i = threadIdx.x; i < sizeof(DeviceParams) / 4; i += blockDim.x)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(&prm->fin_reports, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // Registry maintenance.

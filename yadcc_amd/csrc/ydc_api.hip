@@ -156,6 +156,7 @@ struct ydc_context {
     double* out_util = nullptr;
     uint32_t* out_running = nullptr;
     DeviceParams* h_outcome = nullptr;  // pinned
+    DeviceParams* d_h_outcome = nullptr;  // ... its device address
     hipEvent_t ev = nullptr;
   } pend[2];
   uint32_t pend_head = 0, pend_count = 0;
@@ -226,6 +227,12 @@ struct ydc_context {
     uint32_t *d_upd_idx = nullptr, *d_rel = nullptr, *d_env = nullptr, *d_minv = nullptr,
              *d_ip = nullptr;
     ServantRowDev* d_upd_rows = nullptr;
+    // The same sections as the kernels of the captured step see them when they read the
+    // page-locked arena in place (no H2D copy node), and the result array likewise.
+    uint32_t *z_upd_idx = nullptr, *z_rel = nullptr, *z_env = nullptr, *z_minv = nullptr, *z_ip = nullptr,
+             *z_out = nullptr;
+    ServantRowDev* z_upd_rows = nullptr;
+    bool zero_copy = false;  // the captured step in use reads / writes the arenas in place
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     BatchPlan plan;
@@ -241,6 +248,12 @@ struct ydc_context {
   bool debug_sim = false;
   DevBuf<DeviceParams> d_prm;
   DeviceParams* h_prm = nullptr;  // pinned
+  DeviceParams* d_h_prm = nullptr;  // ... its device address
+  // Where the finalise being enqueued hands the batch's outcome to the host itself (NULL: the
+  // caller reads d_prm back with a copy) — kernels.h: RunningArgs::host_outcome.
+  DeviceParams* finalize_outcome = nullptr;
+  bool opt_outcome_store = true;  // (outcome_store=0: always the copy)
+  bool opt_stream_zero_copy = true;  // streaming: the captured step reads / writes the page-locked arenas in place
 
   // Staging for the host-pointer entry point (ydc_dispatch): the three request columns in
   // one pinned arena and its device mirror (one H2D copy), the results (indexes |
@@ -711,7 +724,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
     c->own_stream = true;
   }
   if (c->d_prm.reserve(1) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_prm, sizeof(DeviceParams)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_prm, sizeof(DeviceParams), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_h_prm, c->h_prm, 0) != hipSuccess ||
       c->d_row_total.reserve(1u << kMaxRadixBits) != hipSuccess) {
     ydc_destroy(c);
     return YDC_ERR_HIP;
@@ -758,6 +772,8 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
   if (const char* s = tune_value("resident")) c->opt_resident = atoi(s) != 0;
   if (const char* s = tune_value("resident_idle_ms")) c->opt_resident_idle_ms = (uint32_t)std::max(1, atoi(s));
+  if (const char* s = tune_value("outcome_store")) c->opt_outcome_store = atoi(s) != 0;
+  if (const char* s = tune_value("stream_zero_copy")) c->opt_stream_zero_copy = atoi(s) != 0;
   if (const char* s = tune_value("walk_after")) c->opt_walk_after = (uint32_t)std::max(2, atoi(s));
   if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
@@ -1640,6 +1656,8 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
   ra.out_b = nullptr;
   ra.taken_out = d_taken;
   ra.pipelined = c->enqueue_pipelined ? 1u : 0u;
+  ra.host_outcome = srv_blocks && c->opt_outcome_store ? c->finalize_outcome : nullptr;
+  ra.srv_blocks = srv_blocks;
   YDC_LAUNCH(c, "k_finalize", k_finalize, dim3(req_blocks + srv_blocks), dim3(256), 0, c->stream, p.sv,
              c->d_slot_base.p, c->d_owner.p, p.rank_to_g, c->d_slot_of.p, N, p.wave_path ? 1u : 0u,
              d_out_idx, d_out_util, check_slot, c->d_prm.p, p.gbits ? (1u << p.gbits) - 1 : 0xFFFFFFFFu,
@@ -1659,9 +1677,10 @@ constexpr int kRetryRadix = 1 << 20;
 // Reads the batch counters back and decides: 1 converged (rounds set), 0 more passes needed,
 // 2 the batch has to be repeated with the radix sort.
 int read_outcome(ydc_context* c, const BatchPlan& p, uint32_t first, uint32_t launched,
-                 uint32_t* rounds) {
-  HIP_TRY(c, hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost,
-                            c->stream));
+                 uint32_t* rounds, bool stored_by_finalize = false) {
+  if (!stored_by_finalize)
+    HIP_TRY(c, hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost,
+                              c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   if (c->h_prm->overflow)
@@ -1741,6 +1760,9 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
       }
     }
     const uint32_t first = launched;
+    // (k_finalize stores the outcome to the page-locked block itself where it has servant workgroups)
+    const bool outcome_stored = c->opt_outcome_store && p.S != 0;
+    c->finalize_outcome = outcome_stored ? c->d_h_prm : nullptr;
     if (launched >= c->opt_walk_after && !walked && group >= 4) {
       // Parallel repair is not getting anywhere (one chunk per pass): scout + walk, then two
       // ordinary passes that find everything consistent (match_kernel.h: walk_scout / walk_run).
@@ -1756,14 +1778,14 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
       for (uint32_t r = launched; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
     }
     launched += group;
-    if (int rc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running,
-                                  (launched - 1) & 63))
-      return rc;
+    const int frc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running, (launched - 1) & 63);
+    c->finalize_outcome = nullptr;
+    if (frc) return frc;
     mark(c, 7);
     if (c->post_copy.bytes)  // a finalise that was gated out is repeated, and so is the copy
       HIP_TRY(c, hipMemcpyAsync(c->post_copy.dst, c->post_copy.src, c->post_copy.bytes,
                                 hipMemcpyDeviceToHost, c->stream));
-    int done = read_outcome(c, p, first, launched, rounds);
+    int done = read_outcome(c, p, first, launched, rounds, outcome_stored);
     if (done < 0) return done;
     if (done == 2) return kRetryRadix;
     if (done) {
@@ -2440,7 +2462,10 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
   HIP_TRY(c, hipSetDevice(c->device));
   resident_stop(c);  // (the registry leaves the resident kernel's registers)
   auto& pd = c->pend[(c->pend_head + c->pend_count) & 1];
-  if (!pd.h_outcome) HIP_TRY(c, hipHostMalloc((void**)&pd.h_outcome, sizeof(DeviceParams)));
+  if (!pd.h_outcome) {
+    HIP_TRY(c, hipHostMalloc((void**)&pd.h_outcome, sizeof(DeviceParams), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&pd.d_h_outcome, pd.h_outcome, 0));
+  }
   if (!pd.ev) HIP_TRY(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
   pd.active = true;
   pd.rerun = false;
@@ -2469,13 +2494,18 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
     for (uint32_t r = 0; r < group; ++r) enqueue_pass(c, pd.plan, r, 1u);
     pd.launched = group;
     c->enqueue_pipelined = true;
+    // (the outcome block: stored by k_finalize's last servant workgroup; a registry without
+    // servants has none, then it is read back with a copy)
+    const bool outcome_stored = c->opt_outcome_store && pd.plan.S != 0;
+    c->finalize_outcome = outcome_stored ? pd.d_h_outcome : nullptr;
     int rc = enqueue_finalize(c, pd.plan, flags, d_out_idx, d_out_util, d_out_running, (group - 1) & 63);
+    c->finalize_outcome = nullptr;
     c->enqueue_pipelined = false;
     if (rc) return give_up(rc);
     // (from here on the batch may take effect: a failing copy / event leaves it to be waited for
     // the slow way — a stream synchronise instead of the event)
-    if (hipMemcpyAsync(pd.h_outcome, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, c->stream) !=
-            hipSuccess ||
+    if ((!outcome_stored &&
+         hipMemcpyAsync(pd.h_outcome, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
         hipEventRecord(pd.ev, c->stream) != hipSuccess) {
       (void)hipStreamSynchronize(c->stream);
       return give_up(fail(c, YDC_ERR_HIP, "could not enqueue the outcome read-back of a pipelined batch"));
@@ -3586,23 +3616,33 @@ int stream_capture(ydc_context* c) {
       rc = fail(c, YDC_ERR_HIP, "capture: %s", hipGetErrorString(e));
   };
   const size_t T = sm.max_tasks;
-  cap(hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, st));
+  // Round 5: no copy node. The tick's inputs are read where the host put them (k_apply_tick and
+  // the request classification read every word once), the placement is stored to the page-locked
+  // result array by k_finalize, and so is the outcome block (stream_zero_copy=0: three copies).
+  const bool zc = c->opt_stream_zero_copy;
+  sm.zero_copy = zc;
+  if (!zc) cap(hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, st));
   if (sm.max_upd + sm.max_rel) {
     const uint32_t upd_blocks = ceil_div(sm.max_upd, 256);
     hipLaunchKernelGGL(k_apply_tick, dim3(upd_blocks + ceil_div(sm.max_rel, 256)), dim3(256), 0, st,
-                       sm.d_upd_idx, sm.d_upd_rows, sm.max_upd, upd_blocks, sm.d_rel, sm.max_rel,
+                       zc ? sm.z_upd_idx : sm.d_upd_idx, zc ? sm.z_upd_rows : sm.d_upd_rows, sm.max_upd, upd_blocks,
+                       zc ? sm.z_rel : sm.d_rel, sm.max_rel,
                        c->n_servants, c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p,
                        c->d_flags.p, c->d_running.p);
   }
-  ydc_task_soa d{sm.d_env, sm.d_minv, sm.d_ip};
+  ydc_task_soa d{zc ? sm.z_env : sm.d_env, zc ? sm.z_minv : sm.d_minv, zc ? sm.z_ip : sm.d_ip};
   if (rc == YDC_OK) rc = enqueue_front(c, sm.plan, &d);
   if (rc == YDC_OK && sm.plan.wave_path)
     for (uint32_t r = 0; r < sm.passes; ++r) enqueue_pass(c, sm.plan, r, 1u);
-  if (rc == YDC_OK)
-    rc = enqueue_finalize(c, sm.plan, YDC_DISPATCH_COMMIT, c->d_out_idx.p, nullptr, nullptr,
+  const bool outcome_stored = zc && c->opt_outcome_store && sm.plan.S != 0;
+  if (rc == YDC_OK) {
+    c->finalize_outcome = outcome_stored ? c->d_h_prm : nullptr;
+    rc = enqueue_finalize(c, sm.plan, YDC_DISPATCH_COMMIT, zc ? sm.z_out : c->d_out_idx.p, nullptr, nullptr,
                           sm.plan.wave_path ? (sm.passes - 1) & 63 : kNone);
-  cap(hipMemcpyAsync(sm.h_out, c->d_out_idx.p, T * 4, hipMemcpyDeviceToHost, st));
-  cap(hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+    c->finalize_outcome = nullptr;
+  }
+  if (!zc) cap(hipMemcpyAsync(sm.h_out, c->d_out_idx.p, T * 4, hipMemcpyDeviceToHost, st));
+  if (!outcome_stored) cap(hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
   hipGraph_t g = nullptr;
   hipError_t ee = hipStreamEndCapture(st, &g);
   c->profiling = was_profiling;
@@ -3646,8 +3686,20 @@ int ydc_stream_begin(ydc_context* c, uint32_t max_updates, uint32_t max_releases
   const size_t o_minv = section((size_t)max_tasks * 4);
   const size_t o_ip = section((size_t)max_tasks * 4);
   sm.in_bytes = off;
-  HIP_TRY(c, hipHostMalloc((void**)&sm.h_in, sm.in_bytes));
-  HIP_TRY(c, hipHostMalloc((void**)&sm.h_out, std::max<size_t>((size_t)max_tasks * 4, 16)));
+  HIP_TRY(c, hipHostMalloc((void**)&sm.h_in, sm.in_bytes, hipHostMallocCoherent | hipHostMallocMapped));
+  HIP_TRY(c, hipHostMalloc((void**)&sm.h_out, std::max<size_t>((size_t)max_tasks * 4, 16),
+                           hipHostMallocCoherent | hipHostMallocMapped));
+  {
+    uint8_t* z_in = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&z_in, sm.h_in, 0));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&sm.z_out, sm.h_out, 0));
+    sm.z_upd_idx = (uint32_t*)(z_in + o_idx);
+    sm.z_upd_rows = (ServantRowDev*)(z_in + o_rows);
+    sm.z_rel = (uint32_t*)(z_in + o_rel);
+    sm.z_env = (uint32_t*)(z_in + o_env);
+    sm.z_minv = (uint32_t*)(z_in + o_minv);
+    sm.z_ip = (uint32_t*)(z_in + o_ip);
+  }
   HIP_TRY(c, sm.d_in.reserve(sm.in_bytes));
   sm.h_upd_idx = (uint32_t*)(sm.h_in + o_idx);
   sm.h_upd_rows = (ydc_servant_row*)(sm.h_in + o_rows);
@@ -3665,6 +3717,19 @@ int ydc_stream_begin(ydc_context* c, uint32_t max_updates, uint32_t max_releases
   sm.want_passes = sm.window_max = sm.window_ticks = 0;
   sm.active = true;
   sm.stale = true;
+  return YDC_OK;
+}
+
+int ydc_stream_buffers_get(ydc_context* c, ydc_stream_buffers* out) {
+  if (!c || !out || !c->stream_mode.active) return YDC_ERR_INVALID_ARGUMENT;
+  auto& sm = c->stream_mode;
+  out->upd_idx = sm.h_upd_idx;
+  out->upd_rows = sm.h_upd_rows;
+  out->release_servant_idx = sm.h_rel;
+  out->env_id = sm.h_env;
+  out->min_version = sm.h_minv;
+  out->requestor_ip = sm.h_ip;
+  out->out_servant_idx = sm.h_out;
   return YDC_OK;
 }
 
@@ -3759,17 +3824,18 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
   if (sm.stale || c->tables_dirty)
     if (int rc = stream_capture(c)) return rc;
   // Stage the tick (padding = no-ops).
+  // (a caller that filled the arena itself — ydc_stream_buffers_get — has nothing to copy)
   if (graph_upd) {
-    std::memcpy(sm.h_upd_idx, upd_idx, (size_t)graph_upd * 4);
-    std::memcpy(sm.h_upd_rows, upd_rows, (size_t)graph_upd * sizeof(ydc_servant_row));
+    if (upd_idx != sm.h_upd_idx) std::memcpy(sm.h_upd_idx, upd_idx, (size_t)graph_upd * 4);
+    if (upd_rows != sm.h_upd_rows) std::memcpy(sm.h_upd_rows, upd_rows, (size_t)graph_upd * sizeof(ydc_servant_row));
   }
   for (uint32_t i = graph_upd; i < sm.max_upd; ++i) sm.h_upd_idx[i] = 0xFFFFFFFFu;
-  if (n_rel) std::memcpy(sm.h_rel, release_servant_idx, (size_t)n_rel * 4);
+  if (n_rel && release_servant_idx != sm.h_rel) std::memcpy(sm.h_rel, release_servant_idx, (size_t)n_rel * 4);
   for (uint32_t i = n_rel; i < sm.max_rel; ++i) sm.h_rel[i] = 0xFFFFFFFFu;
   if (n_tasks) {
-    std::memcpy(sm.h_env, tasks->env_id, (size_t)n_tasks * 4);
-    std::memcpy(sm.h_minv, tasks->min_version, (size_t)n_tasks * 4);
-    std::memcpy(sm.h_ip, tasks->requestor_ip, (size_t)n_tasks * 4);
+    if (tasks->env_id != sm.h_env) std::memcpy(sm.h_env, tasks->env_id, (size_t)n_tasks * 4);
+    if (tasks->min_version != sm.h_minv) std::memcpy(sm.h_minv, tasks->min_version, (size_t)n_tasks * 4);
+    if (tasks->requestor_ip != sm.h_ip) std::memcpy(sm.h_ip, tasks->requestor_ip, (size_t)n_tasks * 4);
   }
   for (uint32_t i = n_tasks; i < sm.max_tasks; ++i) {
     sm.h_env[i] = 0xFFFFFFFFu;  // a digest nobody has: EnvironmentNotFound, consumes nothing
@@ -3799,7 +3865,7 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
     fill_stats(c, pe, rounds_e);
     c->stats.n_tasks = n_tasks;
     c->stats.env_not_found -= std::min(c->stats.env_not_found, sm.max_tasks - n_tasks);  // padding
-    if (n_tasks) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
+    if (n_tasks && out_servant_idx != sm.h_out) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
     return YDC_OK;
   }
   HIP_TRY(c, hipGraphLaunch(sm.exec, c->stream));
@@ -3817,6 +3883,8 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
     ++sm.eager_fallbacks;
     BatchPlan p2;
     if (int rc = fall_back_to_radix(c, sm.max_tasks, &p2)) return rc;
+    if (sm.zero_copy)  // (the captured step read the arena in place: the device copy is stale)
+      HIP_TRY(c, hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, c->stream));
     ydc_task_soa d{sm.d_env, sm.d_minv, sm.d_ip};
     if (int rc = run_planned_batch(c, p2, &d, YDC_DISPATCH_COMMIT, c->d_out_idx.p, nullptr, nullptr, &rounds))
       return rc;
@@ -3824,7 +3892,7 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
     fill_stats(c, p2, rounds);
     c->stats.n_tasks = n_tasks;
     c->stats.env_not_found -= std::min(c->stats.env_not_found, sm.max_tasks - n_tasks);  // padding
-    if (n_tasks) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
+    if (n_tasks && out_servant_idx != sm.h_out) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
     return YDC_OK;
   }
   if (p.wave_path) {
@@ -3858,7 +3926,7 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
   fill_stats(c, p, rounds);
   c->stats.n_tasks = n_tasks;
   c->stats.env_not_found -= std::min(c->stats.env_not_found, sm.max_tasks - n_tasks);  // padding
-  if (n_tasks) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
+  if (n_tasks && out_servant_idx != sm.h_out) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
   return YDC_OK;
 }
 
