@@ -813,7 +813,20 @@ def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
             ctx.release_slots(granted_idx)
         ctx.synchronize()
         dt = time.perf_counter() - s0
+        # ... and with the grants given back from where the batch left them: the placement array in
+        # HBM (ydc_release_slots_device; entries that are no servant are skipped).
+        for _ in range(3):
+            step(commit=True)
+            ctx.release_slots_device(d_out)
+        ctx.synchronize()
+        s1 = time.perf_counter()
+        for _ in range(k_st):
+            step(commit=True)
+            ctx.release_slots_device(d_out)
+        ctx.synchronize()
+        dt_dev = time.perf_counter() - s1
         steady = {"ms_per_step": 1e3 * dt / k_st, "steps": k_st,
+                  "ms_per_step_released_from_hbm": 1e3 * dt_dev / k_st,
                   "assignments_per_s": len(granted_idx) * k_st / dt,
                   "registry_restored": bool(np.array_equal(ctx.get_running(), run0)),
                   "same_placement": bool(np.array_equal(

@@ -164,6 +164,10 @@ int ydc_remove_servants(ydc_context* ctx, const uint32_t* idx, uint32_t n);
 /* FreeTask / zombie / orphan sweeps: running_tasks[servant_idx[i]] -= 1
  * (task_dispatcher.cc:181). */
 int ydc_release_slots(ydc_context* ctx, const uint32_t* servant_idx, uint32_t n);
+/* The same with the indexes in device memory (or page-locked host memory the device can address) —
+ * e.g. the placement array of an earlier batch as it is: entries that are no servant index
+ * (YDC_IDX_*) are skipped. No staging copy; asynchronous on the context's stream. */
+int ydc_release_slots_device(ydc_context* ctx, const uint32_t* d_servant_idx, uint32_t n);
 /* Overwrite / read back the resident running_tasks column. */
 int ydc_set_running(ydc_context* ctx, const uint32_t* running, uint32_t n);
 int ydc_get_running(ydc_context* ctx, uint32_t* out_running, uint32_t n);

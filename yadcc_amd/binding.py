@@ -27,7 +27,7 @@ STAGES = ("servant_scan", "slot_gen", "sort", "class_lists", "task_classify", "m
 ABI_SYMBOLS = (
     "ydc_strerror", "ydc_last_error", "ydc_abi_version", "ydc_create", "ydc_destroy",
     "ydc_upload_servants", "ydc_update_servants", "ydc_update_servants_wide",
-    "ydc_set_host_aliases", "ydc_remove_servants", "ydc_release_slots", "ydc_set_running",
+    "ydc_set_host_aliases", "ydc_remove_servants", "ydc_release_slots", "ydc_release_slots_device", "ydc_set_running",
     "ydc_get_running", "ydc_dispatch", "ydc_dispatch_tick", "ydc_dispatch_device", "ydc_dispatch_device_async",
     "ydc_dispatch_wait", "ydc_synchronize",
     "ydc_set_profiling", "ydc_get_stats", "ydc_kernel_profile", "ydc_device_count",
@@ -112,6 +112,7 @@ def lib():
         L.ydc_set_host_aliases.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_remove_servants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_release_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ydc_release_slots_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_set_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_get_running.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ydc_dispatch.argtypes = [C.c_void_p, C.POINTER(TaskSoA), C.c_uint32, C.c_uint32,
@@ -178,7 +179,7 @@ _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GU
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
-              "ROUNDS_PER_CHECK", "WALK_AFTER", "OUTCOME_STORE", "STREAM_ZERO_COPY", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+              "ROUNDS_PER_CHECK", "WALK_AFTER", "OUTCOME_STORE", "STREAM_ZERO_COPY", "COMMIT_SWAP", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
 _tune_injected = ""
 
 
@@ -383,6 +384,12 @@ class Context:
     def release_slots(self, servant_idx):
         a = np.ascontiguousarray(servant_idx, dtype=np.uint32)
         self._check(lib().ydc_release_slots(self._h, a.ctypes.data, len(a)), "ydc_release_slots")
+
+    def release_slots_device(self, d_servant_idx):
+        """Indexes already in device memory (a DeviceArray / tensor, e.g. a batch's placement output):
+        entries that are no servant index are skipped; no staging copy."""
+        self._check(lib().ydc_release_slots_device(self._h, _ptr(d_servant_idx), int(d_servant_idx.numel())),
+                    "ydc_release_slots_device")
 
     def set_running(self, running):
         a = np.ascontiguousarray(running, dtype=np.uint32)

@@ -362,6 +362,11 @@ struct ydc_context {
   // state no guess predicts (a handful of servants with tens of thousands of slots and requests
   // from their own hosts: 554 passes, 1.2 s; healthy batches need 2 - 4) — `walk_after` passes, then
   // a scout and the walk.
+  // COMMIT by exchanging the resident running_tasks column with k_finalize's output instead of
+  // copying it back (set around enqueue_finalize by callers that do the exchange; never while a
+  // captured streaming step holds the two addresses).
+  bool commit_by_swap = false;
+  bool opt_commit_swap = true;  // (commit_swap=0: always the copy)
   uint32_t opt_walk_after = 12;
   uint32_t walk_flag = 0;
   bool profiling = false;
@@ -772,6 +777,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
   if (const char* s = tune_value("resident")) c->opt_resident = atoi(s) != 0;
   if (const char* s = tune_value("resident_idle_ms")) c->opt_resident_idle_ms = (uint32_t)std::max(1, atoi(s));
+  if (const char* s = tune_value("commit_swap")) c->opt_commit_swap = atoi(s) != 0;
   if (const char* s = tune_value("outcome_store")) c->opt_outcome_store = atoi(s) != 0;
   if (const char* s = tune_value("stream_zero_copy")) c->opt_stream_zero_copy = atoi(s) != 0;
   if (const char* s = tune_value("walk_after")) c->opt_walk_after = (uint32_t)std::max(2, atoi(s));
@@ -1077,6 +1083,17 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
   HIP_TRY(c, hipEventRecord(c->h_rel_ev, c->stream));
   hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream,
                      c->d_upd_idx.p, n, c->n_servants, c->d_running.p);
+  HIP_TRY(c, hipGetLastError());
+  return YDC_OK;
+}
+
+int ydc_release_slots_device(ydc_context* c, const uint32_t* d_servant_idx, uint32_t n) {
+  if (!c || (n && !d_servant_idx)) return YDC_ERR_INVALID_ARGUMENT;
+  if (!n) return YDC_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  resident_stop(c);  // (the registry leaves the resident kernel's registers)
+  hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, d_servant_idx, n,
+                     c->n_servants, c->d_running.p);
   HIP_TRY(c, hipGetLastError());
   return YDC_OK;
 }
@@ -1664,7 +1681,10 @@ int enqueue_finalize(ydc_context* c, const BatchPlan& p, uint32_t flags, uint32_
              req_blocks, ra, p.rank_stride);
   // COMMIT (`++pick->running_tasks`, task_dispatcher.cc:123): running_out -> the resident column.
   // When the passes have not converged yet running_out == running and the step is repeated.
-  if ((flags & YDC_DISPATCH_COMMIT) && S)
+  // Round 5: no copy where the caller can simply make running_out THE column afterwards
+  // (commit_by_swap; a 4 us blit kernel per committed batch otherwise — kept where pointers are
+  // baked into a captured step).
+  if ((flags & YDC_DISPATCH_COMMIT) && S && !c->commit_by_swap)
     HIP_TRY(c, hipMemcpyAsync(c->d_running.p, c->d_running_out.p, (size_t)S * 4, hipMemcpyDeviceToDevice,
                               c->stream));
   return YDC_OK;
@@ -1778,7 +1798,10 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
       for (uint32_t r = launched; r < launched + group; ++r) enqueue_pass(c, p, r, 1u);
     }
     launched += group;
+    const bool by_swap = c->opt_commit_swap && !c->stream_mode.active && (flags & YDC_DISPATCH_COMMIT) && p.S;
+    c->commit_by_swap = by_swap;
     const int frc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running, (launched - 1) & 63);
+    c->commit_by_swap = false;
     c->finalize_outcome = nullptr;
     if (frc) return frc;
     mark(c, 7);
@@ -1789,6 +1812,8 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
     if (done < 0) return done;
     if (done == 2) return kRetryRadix;
     if (done) {
+      // (the finalise just waited for was the final one: its output IS the column now)
+      if (by_swap) std::swap(c->d_running, c->d_running_out);
       if (c->debug_sim) {
         fprintf(stderr, "[ydc match] K=%u cs=%u R=%u fill=%u rounds=%u sims=%u pass changed ends:", p.K,
                 p.cs, 1u << p.rshift, p.init_fill, *rounds, c->h_prm->chunk_sims);
@@ -1961,7 +1986,11 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
           return fail(c, YDC_ERR_NOT_CONVERGED, "no fixpoint after %u rounds", rounds);
       }
     }
-    if (int rc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running, kNone)) return rc;
+    const bool by_swap = c->opt_commit_swap && !c->stream_mode.active && (flags & YDC_DISPATCH_COMMIT) && p.S;
+    c->commit_by_swap = by_swap;
+    const int frc = enqueue_finalize(c, p, flags, d_out_idx, d_out_util, d_out_running, kNone);
+    c->commit_by_swap = false;
+    if (frc) return frc;
     mark(c, 7);
     if (c->post_copy.bytes)
       HIP_TRY(c, hipMemcpyAsync(c->post_copy.dst, c->post_copy.src, c->post_copy.bytes,
@@ -1972,6 +2001,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
     if (c->h_prm->overflow)
       return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
     if (p.binsort && c->h_prm->window_miss) return kRetryRadix;
+    if (by_swap) std::swap(c->d_running, c->d_running_out);  // (an ungated finalise: always final here)
   }
   *rounds_out = rounds;
   return YDC_OK;
@@ -2498,10 +2528,16 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
     // servants has none, then it is read back with a copy)
     const bool outcome_stored = c->opt_outcome_store && pd.plan.S != 0;
     c->finalize_outcome = outcome_stored ? pd.d_h_outcome : nullptr;
+    const bool by_swap = c->opt_commit_swap && !c->stream_mode.active && (flags & YDC_DISPATCH_COMMIT) && pd.plan.S;
+    c->commit_by_swap = by_swap;
     int rc = enqueue_finalize(c, pd.plan, flags, d_out_idx, d_out_util, d_out_running, (group - 1) & 63);
+    c->commit_by_swap = false;
     c->finalize_outcome = nullptr;
     c->enqueue_pipelined = false;
     if (rc) return give_up(rc);
+    // (a batch that turns out not to be final wrote the column's own values: the exchange is
+    // harmless then, and the replay plans with the pointers as they are)
+    if (by_swap) std::swap(c->d_running, c->d_running_out);
     // (from here on the batch may take effect: a failing copy / event leaves it to be waited for
     // the slow way — a stream synchronise instead of the event)
     if ((!outcome_stored &&
