@@ -31,10 +31,13 @@ def check(ctx, sv, tk, method="scan", **kw):
     return st
 
 
-@pytest.fixture()
-def forced(monkeypatch):
-    """A context whose every batch takes the one-workgroup kernel, whatever its size."""
+@pytest.fixture(params=["packed", "fp64"])
+def forced(monkeypatch, request):
+    """A context whose every batch takes the one-workgroup kernel, whatever its size — with the
+    one-word candidate (integer key above the registry index, where capacities are below 2^10 and
+    both fit 32 bits) and with the reference's double as the key."""
     monkeypatch.setenv("YDC_SMALL_BATCH", "100000000")
+    monkeypatch.setenv("YDC_PACKED_TICK", "1" if request.param == "packed" else "0")
     c = binding.Context(device=0)
     yield c
     c.close()
@@ -146,10 +149,11 @@ def _rows_of(sv, idx, flags):
     return rows
 
 
+@pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("n_servants,n_envs,big", [(60, 1, False), (700, 3, False), (2500, 4, True), (9000, 2, True),
                                                    (400, 150, False)])
-def test_ticks_with_heartbeats_and_releases(n_servants, n_envs, big, resident, monkeypatch):
+def test_ticks_with_heartbeats_and_releases(n_servants, n_envs, big, resident, packed, monkeypatch):
     """Sequences of scheduler turns: heartbeats (new load / memory / capacity figures — and now and
     then another version or environment set, which changes structure and takes the general path),
     released grants, a handful of requests — COMMITted; the oracle replays every turn on its own
@@ -158,6 +162,7 @@ def test_ticks_with_heartbeats_and_releases(n_servants, n_envs, big, resident, m
     mailbox (until a turn it does not take — a structural heartbeat, a long list — ends it);
     resident = 0: every turn is a launch."""
     monkeypatch.setenv("YDC_RESIDENT", resident)
+    monkeypatch.setenv("YDC_PACKED_TICK", packed)
     rng = np.random.default_rng(77 + n_servants)
     sv, _ = cases.random_case(seed=5 + n_servants, n_tasks=3 * n_servants, n_servants=n_servants, n_envs=n_envs,
                               shared_ip_frac=0.1)

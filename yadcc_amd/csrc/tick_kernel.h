@@ -75,7 +75,10 @@ struct TickDone {
 constexpr uint32_t kTickCmdTick = 1, kTickCmdQuit = 2;
 constexpr uint32_t kTickCmdSame = 0x80;  // flag on kTickCmdTick: every request is a copy of the first (one RPC's requests)
 struct TickBox {
-  unsigned long long head[8];  // {cmd | n_tasks << 8 | n_upd << 16 | n_rel << 24}, env, minv, rip, rel[0 .. 3]
+  // {cmd | n_tasks << 8 | n_upd << 16 | n_rel << 24}, env, minv, rip, rel[0 .. 3],
+  // upd_idx[0], upd[0].{nproc, load, max_tasks, flags}, rel[4 .. 6]: two 64-byte lines — a request
+  // with up to seven released grants and one heartbeat row needs no second read
+  unsigned long long head[16];
   unsigned long long reply[8];  // {granted | timeouts << 8 | env_not_found << 16}, placement 0 .. 6
   uint32_t env[kTickInlineTasks], minv[kTickInlineTasks], rip[kTickInlineTasks];
   uint32_t rel[kTickInlineRel];
@@ -87,6 +90,7 @@ struct TickBox {
 };
 
 struct TickArgs {
+  uint32_t cap_bits, idx_bits;  // the one-word candidate: key format (dispatch_core.h), bits of a registry index
   // resident registry
   uint32_t *nproc, *load, *max_tasks, *flags;  // (written by the heartbeat rows of this tick)
   const uint32_t *class_of, *ip;
@@ -167,6 +171,47 @@ __device__ __forceinline__ void tick_row_reduce(T& c) {
   if (N > 8) tick_dpp_step<0x118, 0xf>(c);  // row_shr:8
 }
 
+// The one-word candidate (capacities below 2^10, which is every realistic pool): the exact integer
+// key of dispatch_core.h (slot_key_exact: tier and floor(running * 4^b / capacity), order-isomorphic
+// to the reference's double compare — DESIGN.md 2) above the registry index, 32 bits together.
+// The minimum of the words IS the pick, first-wins tie-break included: a reduction step is one
+// v_min_u32 with a DPP operand where the two-word key needs fourteen instructions.
+struct TickWord {
+  uint32_t w;
+};
+__device__ __forceinline__ void tick_merge(TickWord& a, const TickWord& b) { a.w = min(a.w, b.w); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void tick_dpp_step(TickWord& c) {
+  c.w = min(c.w, dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, c.w));
+}
+
+template <bool PK>
+struct TickTypes {
+  using Key = uint64_t;
+  using Cand = TickBest;
+};
+template <>
+struct TickTypes<true> {
+  using Key = uint32_t;
+  using Cand = TickWord;
+};
+__device__ __forceinline__ TickBest tick_cand(uint64_t key, uint32_t s, uint32_t) {
+  return TickBest{(uint32_t)(key >> 32), (uint32_t)key, key == kTickNoKey ? kNone : s};
+}
+__device__ __forceinline__ TickWord tick_cand(uint32_t key, uint32_t s, uint32_t ib) {
+  return TickWord{key == 0xFFFFFFFFu ? 0xFFFFFFFFu : (key << ib) | s};
+}
+__device__ __forceinline__ uint32_t tick_cand_idx(const TickBest& c, uint32_t) { return c.idx; }
+__device__ __forceinline__ uint32_t tick_cand_idx(const TickWord& c, uint32_t ib) {
+  return c.w == 0xFFFFFFFFu ? kNone : c.w & ((1u << ib) - 1);
+}
+// (key, registry index) order: is a before b?
+__device__ __forceinline__ bool tick_cand_less(const TickBest& a, const TickBest& b) {
+  const uint64_t ka = ((uint64_t)a.khi << 32) | a.klo, kb = ((uint64_t)b.khi << 32) | b.klo;
+  return ka < kb || (ka == kb && a.idx < b.idx);
+}
+__device__ __forceinline__ bool tick_cand_less(const TickWord& a, const TickWord& b) { return a.w < b.w; }
+
 // A workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every global
 // store in flight (vmcnt(0)) — the winner's `++running_tasks` store of the pick before would be
 // waited for by every pick (measured: 2 us per pick instead of 0.4).
@@ -202,6 +247,19 @@ __device__ __forceinline__ TickBest tick_block_reduce(TickBest c, uint32_t* part
   return TickBest{tick_rl(w.khi, WAVES - 1), tick_rl(w.klo, WAVES - 1), tick_rl(w.idx, WAVES - 1)};
 }
 template <int WAVES>
+__device__ __forceinline__ TickWord tick_block_reduce(TickWord c, uint32_t* part) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  tick_row_reduce<16>(c);
+  tick_dpp_step<0x142, 0xa>(c);
+  tick_dpp_step<0x143, 0xc>(c);
+  if (lane == 63) part[wave] = c.w;
+  tick_lds_barrier();
+  TickWord w{0xFFFFFFFFu};
+  if (lane < WAVES) w.w = part[lane];
+  tick_row_reduce<WAVES>(w);
+  return TickWord{tick_rl(w.w, WAVES - 1)};
+}
+template <int WAVES>
 __device__ __forceinline__ TickOwn tick_block_reduce(TickOwn c, uint32_t* part) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   tick_row_reduce<16>(c);
@@ -222,10 +280,15 @@ __device__ __forceinline__ TickOwn tick_block_reduce(TickOwn c, uint32_t* part) 
 }
 
 // Key of a servant's state (dispatch_core.h closed forms; the fp64 key is the reference's own compare).
-__device__ __forceinline__ uint64_t tick_key(uint32_t nproc, uint32_t load, uint32_t max_tasks,
-                                             uint32_t flags, uint32_t r, bool in_class) {
-  if (!in_class || servant_slot_count(nproc, load, max_tasks, r, flags) == 0) return kTickNoKey;
-  return slot_key_fp64(slot_tier(nproc, flags, r), r, slot_capacity(nproc, load, max_tasks, r));
+template <bool PK>
+__device__ __forceinline__ typename TickTypes<PK>::Key tick_key(uint32_t nproc, uint32_t load, uint32_t max_tasks,
+                                                                uint32_t flags, uint32_t r, bool in_class,
+                                                                uint32_t cap_bits) {
+  using Key = typename TickTypes<PK>::Key;
+  if (!in_class || servant_slot_count(nproc, load, max_tasks, r, flags) == 0) return (Key) ~(Key)0;
+  const uint32_t cap = slot_capacity(nproc, load, max_tasks, r), tier = slot_tier(nproc, flags, r);
+  if (PK) return (Key)slot_key_exact(tier, r, cap, cap_bits);  // (cap_bits <= 10: 32-bit arithmetic)
+  return (Key)slot_key_fp64(tier, r, cap);
 }
 
 // THREADS x K >= S: servant k * THREADS + t is slot k of thread t. As few waves as hold the
@@ -248,8 +311,11 @@ __device__ __forceinline__ uint64_t tick_key(uint32_t nproc, uint32_t load, uint
   } while (0)
 #endif
 
-template <int THREADS, int K, bool COLD>
+template <int THREADS, int K, bool COLD, bool PK>
 __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
+  using KeyT = typename TickTypes<PK>::Key;
+  using Cand = typename TickTypes<PK>::Cand;
+  constexpr KeyT kNo = (KeyT) ~(KeyT)0;
   constexpr int WAVES = THREADS / 64;
   constexpr int G = K < 8 ? K : 8;  // servants whose columns are in flight together
   extern __shared__ uint64_t s_mask[];  // [W]: eligible classes of the current (digest, version threshold)
@@ -279,7 +345,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   uint32_t* const p_run_out = a.run_out;
   const uint64_t* const p_cls_env = a.cls_env;
   const uint32_t* const p_cls_ver = a.cls_ver;
-  const uint32_t S = a.S, C = a.C, EW = a.EW, W = a.W;
+  const uint32_t S = a.S, C = a.C, EW = a.EW, W = a.W, cap_bits = a.cap_bits, ib = a.idx_bits;
   uint32_t n_tasks = a.n_tasks, n_upd = a.n_upd, n_rel = a.n_rel;
   const uint32_t *const p_tenv = a.t_env, *const p_tminv = a.t_minv, *const p_trip = a.t_rip;
   const uint32_t* const p_upd_idx = a.upd_idx;
@@ -293,6 +359,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   uint32_t seq = a.seq;
   asm volatile("" ::"s"(p_nproc), "s"(p_load), "s"(p_maxt), "s"(p_flags), "s"(p_class_of), "s"(p_ip),
                "s"(p_running), "s"(p_rw), "s"(p_run_out), "s"(p_cls_env), "s"(p_cls_ver), "s"(box), "s"(idle_ticks));
+  asm volatile("" ::"s"(cap_bits), "s"(ib));
   asm volatile("" ::"s"(S), "s"(C), "s"(EW), "s"(W), "s"(n_tasks), "s"(n_upd), "s"(n_rel), "s"(p_tenv),
                "s"(p_tminv), "s"(p_trip), "s"(p_upd_idx), "s"(p_upd_rows), "s"(p_rel), "s"(p_out_idx),
                "s"(p_out_util), "s"(p_done), "s"(seq));
@@ -335,7 +402,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   // ---- the registry into registers: G servants' columns in flight at a time ----
   // Per servant in registers: the key and running_tasks (and, COLD, the columns a key is made
   // of). Its class and its host are only looked at when the request signature changes: LDS.
-  uint64_t key[K];
+  KeyT key[K];
   uint32_t c_run[K];
   uint32_t* const s_ip = (uint32_t*)(s_mask + W + (THREADS <= 256 ? 4 * THREADS : 0));  // [K * THREADS], behind the merge's lists
   uint16_t* const s_cls = (uint16_t*)(s_ip + K * THREADS);                              // [K * THREADS]
@@ -370,7 +437,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       s_cls[s] = (uint16_t)(inc ? l_co[j] : 0u);
       in_cls |= (inc ? 1u : 0u) << k;
       c_run[k] = l_r[j];
-      key[k] = tick_key(l_np[j], l_ld[j], l_mt[j], l_fl[j], l_r[j], inc);
+      key[k] = tick_key<PK>(l_np[j], l_ld[j], l_mt[j], l_fl[j], l_r[j], inc, cap_bits);
       if (COLD) {
         c_nproc[k] = l_np[j];
         c_load[k] = l_ld[j];
@@ -393,7 +460,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   uint32_t p_env = 0, p_minv = 0, p_rip = 0;
   bool have_sig = false, any = false, dirty = true;
   uint32_t elig = 0, ownb = 0;  // bit k: servant k is eligible for / on the host of the signature
-  TickBest mine{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+  Cand mine = tick_cand(kNo, kNone, ib);
   TickOwn mine_own{kNone, kNone};
 
   // The request signature the cached values belong to: one RPC's requests share it
@@ -437,18 +504,18 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   };
   // A thread's next TWO candidates (the merge below): the best of its servants and what would be
   // its best once that one is taken — the runner-up, or the same servant at running + 1 (nk0).
-  TickBest e1{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
-  uint64_t nk0 = kTickNoKey;
+  Cand e1 = tick_cand(kNo, kNone, ib);
+  KeyT nk0 = kNo;
   uint32_t k0 = 0, k1 = 0;
   bool e1_same = false, list_valid = false;
   auto build_list = [&]() {
-    uint64_t b0 = kTickNoKey, b1 = kTickNoKey;
+    KeyT b0 = kNo, b1 = kNo;
     uint32_t i0 = kNone, i1 = kNone;
     k0 = k1 = 0;
     mine_own.own1 = mine_own.own2 = kNone;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+      if (!((elig >> k) & 1u) || key[k] == kNo) continue;
       const uint32_t s = (uint32_t)k * THREADS + tl;
       if ((ownb >> k) & 1u) {
         if (mine_own.own1 == kNone) mine_own.own1 = s;
@@ -466,10 +533,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         k1 = (uint32_t)k;
       }
     }
-    mine.khi = (uint32_t)(b0 >> 32);
-    mine.klo = (uint32_t)b0;
-    mine.idx = i0;
-    nk0 = kTickNoKey;
+    mine = tick_cand(b0, i0, ib);
+    nk0 = kNo;
     if (i0 != kNone) {
       uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
       if (!COLD) {
@@ -489,13 +554,10 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           fl = me ? c_flags[k] : fl;
         }
       }
-      nk0 = tick_key(np, ld, mt, fl, run + 1, true);
+      nk0 = tick_key<PK>(np, ld, mt, fl, run + 1, true, cap_bits);
     }
     e1_same = nk0 < b1 || (nk0 == b1 && i0 < i1);  // (both none: no second candidate either way)
-    const uint64_t kk = e1_same ? nk0 : b1;
-    e1.khi = (uint32_t)(kk >> 32);
-    e1.klo = (uint32_t)kk;
-    e1.idx = kk == kTickNoKey ? kNone : (e1_same ? i0 : i1);
+    e1 = tick_cand(e1_same ? nk0 : b1, e1_same ? i0 : i1, ib);
     dirty = false;
     list_valid = true;
   };
@@ -525,7 +587,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           uint32_t run = 0;
 #pragma unroll
           for (int k = 0; k < K; ++k) run = (uint32_t)k == wk ? c_run[k] : run;
-          const uint64_t nk = tick_key(r.nproc, r.load, r.max_tasks, r.flags, run, (in_cls >> wk) & 1u);
+          const KeyT nk = tick_key<PK>(r.nproc, r.load, r.max_tasks, r.flags, run, (in_cls >> wk) & 1u, cap_bits);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool me = (uint32_t)k == wk;
@@ -544,8 +606,10 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     // Released grants: FreeTask's --running_tasks (:181). This thread is the only one that knows servant s.
     if (!p_rel && n_rel) {
       uint32_t touched = 0;
+      // (one LDS read per lane, then a lane read per released grant: no LDS round trip in the loop)
+      const uint32_t rel_mine = lane < n_rel ? s_rel[lane] : kNone;
       for (uint32_t j = 0; j < n_rel; ++j) {
-        const uint32_t s = s_rel[j];
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)rel_mine, (int)j);
         if (s < S && s % THREADS == tl) {
           const uint32_t wk = s / THREADS;
 #pragma unroll
@@ -571,7 +635,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
             mt = p_maxt[s];
             fl = p_flags[s];
           }
-          key[k] = tick_key(np, ld, mt, fl, c_run[k], (in_cls >> k) & 1u);
+          key[k] = tick_key<PK>(np, ld, mt, fl, c_run[k], (in_cls >> k) & 1u, cap_bits);
         }
         changed |= touched;
         dirty = true;
@@ -590,15 +654,15 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     // threads that were picked from make new lists: another round). Requests from a host that
     // runs an eligible free servant (`self`, :372-396) take the pick-by-pick loop below.
     // (256-thread kernels: the wider ones have no registers to spare for it)
-    if (THREADS <= 256 && !p_tenv && n_tasks >= kTickMergeMin && n_tasks <= kTickBlock) {
+    // (the one-word candidate does not hold the utilisation: a caller that wants it gets the loop below)
+    if (THREADS <= 256 && !p_tenv && n_tasks >= kTickMergeMin && n_tasks <= kTickBlock && !(PK && p_out_util)) {
       const bool differs = lane < n_tasks && (s_env[lane] != s_env[0] || s_minv[lane] != s_minv[0] || s_rip[lane] != s_rip[0]);
       if (__ballot(differs) == 0) {
         set_signature((uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[0]),
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minv[0]),
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rip[0]));
-        uint64_t* const s_lk = s_mask + W;                           // [2][THREADS] keys
-        uint32_t* const s_li = (uint32_t*)(s_lk + 2 * THREADS);      // [2][THREADS] registry indexes
-        uint32_t* const s_cnt = s_li + 2 * THREADS;                  // [THREADS] entries taken this round
+        Cand* const s_lc = (Cand*)(s_mask + W);                      // [2][THREADS] candidates
+        uint32_t* const s_cnt = (uint32_t*)(s_mask + W) + 6 * THREADS;  // [THREADS] entries taken this round
         if (!any) {  // :105-108, n times
           if (t < n_tasks) {
             s_out[t] = kIdxEnvNotFound;
@@ -611,10 +675,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           bool own_seen = false;
           for (uint32_t round = 0; placed < n_tasks; ++round) {
             if (dirty || !list_valid) build_list();
-            s_lk[t] = ((uint64_t)mine.khi << 32) | mine.klo;
-            s_lk[THREADS + t] = ((uint64_t)e1.khi << 32) | e1.klo;
-            s_li[t] = mine.idx;
-            s_li[THREADS + t] = e1.idx;
+            s_lc[t] = mine;
+            s_lc[THREADS + t] = e1;
             const uint32_t fl_i = pk % 3;
             if (round == 0 && __ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
             tick_lds_barrier();
@@ -628,41 +690,41 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
             if (t < 64) {
               constexpr int T = THREADS / 64;  // lists per lane: threads lane + 64 q
               uint32_t pos = 0;                // 2 bits per list: entries taken
-              TickBest lb{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
+              Cand lb = tick_cand(kNo, kNone, ib);
               auto local_best = [&]() {
-                uint64_t bk = kTickNoKey;
-                uint32_t bi = kNone;
+                lb = tick_cand(kNo, kNone, ib);
 #pragma unroll
                 for (int q = 0; q < T; ++q) {
                   const uint32_t pq = (pos >> (2 * q)) & 3u;
                   if (pq < 2) {
-                    const uint64_t kq = s_lk[pq * THREADS + lane + 64 * q];
-                    const uint32_t iq = s_li[pq * THREADS + lane + 64 * q];
-                    if (kq < bk || (kq == bk && iq < bi)) {
-                      bk = kq;
-                      bi = iq;
-                    }
+                    const Cand cq = s_lc[pq * THREADS + lane + 64 * q];
+                    if (tick_cand_less(cq, lb)) lb = cq;
                   }
                 }
-                lb.khi = (uint32_t)(bk >> 32);
-                lb.klo = (uint32_t)bk;
-                lb.idx = bk == kTickNoKey ? kNone : bi;
               };
               local_best();
               uint32_t stop = 0;  // 1: a list ran dry, 2: nothing is free any more
               while (placed < n_tasks && !stop) {
-                TickBest b = lb;
+                Cand b = lb;
                 tick_row_reduce<16>(b);
                 tick_dpp_step<0x142, 0xa>(b);
                 tick_dpp_step<0x143, 0xc>(b);
-                const uint32_t bhi = tick_rl(b.khi, 63), blo = tick_rl(b.klo, 63), bidx = tick_rl(b.idx, 63);
+                uint32_t bidx;
+                double butil = -1.0;
+                if constexpr (PK) {
+                  bidx = tick_cand_idx(TickWord{tick_rl(b.w, 63)}, ib);
+                } else {
+                  bidx = tick_rl(b.idx, 63);
+                  butil = __longlong_as_double((long long)((((uint64_t)tick_rl(b.khi, 63) << 32) | tick_rl(b.klo, 63)) &
+                                                           0x7FFFFFFFFFFFFFFFull));
+                }
                 if (bidx == kNone) {
                   stop = 2;
                   break;
                 }
                 if (lane == 0) {
                   s_out[placed] = bidx;
-                  s_util[placed] = __longlong_as_double((long long)((((uint64_t)bhi << 32) | blo) & 0x7FFFFFFFFFFFFFFFull));
+                  s_util[placed] = butil;
                 }
                 ++placed;
                 const uint32_t tw = bidx % THREADS;
@@ -698,15 +760,16 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
               const uint32_t add0 = 1u + (took == 2 && e1_same ? 1u : 0u), add1 = took == 2 && !e1_same ? 1u : 0u;
               uint32_t np0 = 0, ld0 = 0, mt0 = 0, fl0 = 0, r0 = 0, np1 = 0, ld1 = 0, mt1 = 0, fl1 = 0, r1 = 0;
               if (!COLD) {
-                np0 = p_nproc[mine.idx];
-                ld0 = p_load[mine.idx];
-                mt0 = p_maxt[mine.idx];
-                fl0 = p_flags[mine.idx];
+                const uint32_t s0 = tick_cand_idx(mine, ib), s1 = tick_cand_idx(e1, ib);
+                np0 = p_nproc[s0];
+                ld0 = p_load[s0];
+                mt0 = p_maxt[s0];
+                fl0 = p_flags[s0];
                 if (add1) {
-                  np1 = p_nproc[e1.idx];
-                  ld1 = p_load[e1.idx];
-                  mt1 = p_maxt[e1.idx];
-                  fl1 = p_flags[e1.idx];
+                  np1 = p_nproc[s1];
+                  ld1 = p_load[s1];
+                  mt1 = p_maxt[s1];
+                  fl1 = p_flags[s1];
                 }
               }
 #pragma unroll
@@ -726,8 +789,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
                   fl1 = m1 ? c_flags[k] : fl1;
                 }
               }
-              const uint64_t nka = add0 == 1 ? nk0 : tick_key(np0, ld0, mt0, fl0, r0, true);
-              const uint64_t nkb = add1 ? tick_key(np1, ld1, mt1, fl1, r1, true) : 0;
+              const KeyT nka = add0 == 1 ? nk0 : tick_key<PK>(np0, ld0, mt0, fl0, r0, true, cap_bits);
+              const KeyT nkb = add1 ? tick_key<PK>(np1, ld1, mt1, fl1, r1, true, cap_bits) : (KeyT)0;
 #pragma unroll
               for (int k = 0; k < K; ++k) {
                 const bool m0 = (uint32_t)k == k0, m1 = add1 && (uint32_t)k == k1;
@@ -786,22 +849,22 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         ++n_envnf;
       } else {
         if (dirty) {  // this thread's candidates: its state (or the signature) changed
-          uint64_t bk = kTickNoKey;
-          mine.idx = mine_own.own1 = mine_own.own2 = kNone;
+          KeyT bk = kNo;
+          uint32_t bs = kNone;
+          mine_own.own1 = mine_own.own2 = kNone;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+            if (!((elig >> k) & 1u) || key[k] == kNo) continue;
             const uint32_t s = (uint32_t)k * THREADS + tl;
             if ((ownb >> k) & 1u) {  // on the requestor's own host (ascending s: first, second)
               if (mine_own.own1 == kNone) mine_own.own1 = s;
               else if (mine_own.own2 == kNone) mine_own.own2 = s;
             } else if (key[k] < bk) {
               bk = key[k];
-              mine.idx = s;
+              bs = s;
             }
           }
-          mine.khi = (uint32_t)(bk >> 32);
-          mine.klo = (uint32_t)bk;
+          mine = tick_cand(bk, bs, ib);
           dirty = false;
           list_valid = false;
         }
@@ -809,7 +872,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         // Own-host candidates are rare: a flag says whether the second reduction is needed at all.
         const uint32_t fl_i = pk % 3;
         if (__ballot(mine_own.own1 != kNone) != 0 && lane == 0) s_own_flag[fl_i] = 1;
-        TickBest best = tick_block_reduce<WAVES>(mine, s_part[red++ & 1]);
+        Cand best = tick_block_reduce<WAVES>(mine, s_part[red++ & 1]);
         if (i == 2) YDC_TICK_STAMP(25);
         const bool own_any = s_own_flag[fl_i] != 0;
         if (t == 0) s_own_flag[(pk + 2) % 3] = 0;
@@ -820,24 +883,23 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           if (own.own2 != kNone) {
             // Several eligible free servants on the requestor's host: only the first of them is
             // `self` (:372-379), the others compete like everybody else.
-            TickBest again{0xFFFFFFFFu, 0xFFFFFFFFu, kNone};
-            uint64_t bk = kTickNoKey;
+            KeyT bk = kNo;
+            uint32_t bs = kNone;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-              if (!((elig >> k) & 1u) || key[k] == kTickNoKey) continue;
+              if (!((elig >> k) & 1u) || key[k] == kNo) continue;
               const uint32_t s = (uint32_t)k * THREADS + tl;
               if (s != own.own1 && key[k] < bk) {
                 bk = key[k];
-                again.idx = s;
+                bs = s;
               }
             }
-            again.khi = (uint32_t)(bk >> 32);
-            again.klo = (uint32_t)bk;
-            best = tick_block_reduce<WAVES>(again, s_part[red++ & 1]);
+            best = tick_block_reduce<WAVES>(tick_cand(bk, bs, ib), s_part[red++ & 1]);
           }
         }
         if (i == 2) YDC_TICK_STAMP(26);
-        const uint32_t winner = best.idx != kNone ? best.idx : own.own1;  // :392-396
+        const uint32_t best_idx = tick_cand_idx(best, ib);
+        const uint32_t winner = best_idx != kNone ? best_idx : own.own1;  // :392-396
         if (winner == kNone) {  // eligible servants exist, none is free: Timeout with timeout == now (:116-118)
           if (t == 0) {
             s_out[oi] = kIdxTimeout;
@@ -849,7 +911,6 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           if (winner % THREADS == tl) {
             const uint32_t wk = winner / THREADS;
             uint32_t np = 0, ld = 0, mt = 0, fl = 0, run = 0;
-            uint64_t kw = 0;
             if (!COLD) {
               np = p_nproc[winner];
               ld = p_load[winner];
@@ -859,7 +920,6 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {  // (selects, not branches: the key is computed once below)
               const bool me = (uint32_t)k == wk;
-              kw = me ? key[k] : kw;
               run = me ? c_run[k] : run;
               if (COLD) {
                 np = me ? c_nproc[k] : np;
@@ -869,9 +929,10 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
               }
             }
             s_out[oi] = winner;
-            s_util[oi] = __longlong_as_double((long long)(kw & 0x7FFFFFFFFFFFFFFFull));
+            // (the double the reference compares, task_dispatcher.cc:440-441: the same division)
+            s_util[oi] = slot_utilization(run, slot_capacity(np, ld, mt, run));
             run += 1;  // ++pick->running_tasks (:123); written back at the end
-            const uint64_t nk = tick_key(np, ld, mt, fl, run, true);
+            const KeyT nk = tick_key<PK>(np, ld, mt, fl, run, true, cap_bits);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               const bool me = (uint32_t)k == wk;
@@ -940,9 +1001,9 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
       uint32_t word = 0, leave = 0;
       for (;;) {
         const unsigned long long g =
-            __hip_atomic_load(&box->head[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_load(&box->head[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const bool mine_ok = (uint32_t)(g >> 32) == seq;
-        if ((__ballot(mine_ok) & 0xFFull) == 0xFFull) {
+        if ((__ballot(mine_ok) & 0xFFFFull) == 0xFFFFull) {
           word = (uint32_t)g;
           break;
         }
@@ -959,6 +1020,12 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         if (lane == 2) s_minv[0] = word;
         if (lane == 3) s_rip[0] = word;
         if (lane >= 4 && lane < 8) s_rel[lane - 4] = word;
+        if (lane == 8) s_uidx[0] = word;
+        if (lane == 9) s_urow[0].nproc = word;
+        if (lane == 10) s_urow[0].load = word;
+        if (lane == 11) s_urow[0].max_tasks = word;
+        if (lane == 12) s_urow[0].flags = word;
+        if (lane >= 13 && lane < 16) s_rel[lane - 9] = word;
         const uint32_t nt = (w0 >> 8) & 0xFF, nu = (w0 >> 16) & 0xFF, nr = w0 >> 24;
         // (what does not fit the head was stored before it; this read follows the head's)
         if (nt > 1 && (w0 & kTickCmdSame)) {  // copies of the first request: nothing more to fetch
@@ -975,8 +1042,8 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
           s_minv[lane] = __hip_atomic_load(&box->minv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           s_rip[lane] = __hip_atomic_load(&box->rip[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (nr > 4 && lane < nr) s_rel[lane] = __hip_atomic_load(&box->rel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane < nu) {
+        if (nr > 7 && lane < nr) s_rel[lane] = __hip_atomic_load(&box->rel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (nu > 1 && lane < nu) {
           s_uidx[lane] = __hip_atomic_load(&box->upd_idx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           TickRow r;
           r.nproc = __hip_atomic_load(&box->upd[lane].nproc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

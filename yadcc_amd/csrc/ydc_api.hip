@@ -238,7 +238,7 @@ struct ydc_context {
     BatchPlan plan;
     uint64_t ticks = 0, recaptures = 0, eager_fallbacks = 0;
     bool eager_only = false;  // the registry's batches cannot be captured (> 256 classes): every tick runs eagerly
-    // Passes to capture: one more than the last eager batch needed, to begin with; after 256
+    // Passes to capture: one more than the last eager batch needed, to begin with; after 64
     // ticks that all needed fewer, exactly the most any of them needed (a pre-launched pass
     // that finds nothing to do still costs a launch); more again after a tick that ran out.
     uint32_t want_passes = 0, window_max = 0, window_ticks = 0;
@@ -307,6 +307,7 @@ struct ydc_context {
   // registers, and takes the following ticks from a page-locked mailbox (tick_kernel.h: TickBox) —
   // no launch, no column loads. Every other use of the context ends it first (resident_stop).
   bool opt_resident = true;        // (resident=0: every tick is a launch)
+  bool opt_tick_packed = true;     // (packed_tick=0: the two-word candidate everywhere)
   uint32_t opt_resident_idle_ms = 50;  // the kernel leaves by itself when nobody has asked for this long
   TickBox *h_box = nullptr, *d_box = nullptr;
   hipStream_t res_stream = nullptr;
@@ -776,6 +777,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("shard_margin")) c->opt_shard_margin = atoll(s);
   if (const char* s = tune_value("small_batch")) c->opt_small_batch = (uint32_t)std::max(0ll, atoll(s));
   if (const char* s = tune_value("resident")) c->opt_resident = atoi(s) != 0;
+  if (const char* s = tune_value("packed_tick")) c->opt_tick_packed = atoi(s) != 0;
   if (const char* s = tune_value("resident_idle_ms")) c->opt_resident_idle_ms = (uint32_t)std::max(1, atoi(s));
   if (const char* s = tune_value("commit_swap")) c->opt_commit_swap = atoi(s) != 0;
   if (const char* s = tune_value("outcome_store")) c->opt_outcome_store = atoi(s) != 0;
@@ -2099,7 +2101,7 @@ void resident_stop(ydc_context* c) {
   if (__atomic_load_n(&c->h_box->alive, __ATOMIC_ACQUIRE) != 0) {
     if (++c->tick_seq == 0) c->tick_seq = 1;
     const uint32_t seq = c->tick_seq;
-    for (int g = 7; g >= 0; --g)
+    for (int g = 15; g >= 0; --g)
       __atomic_store_n(&c->h_box->head[g], ((unsigned long long)seq << 32) | (g == 0 ? kTickCmdQuit : 0u),
                        __ATOMIC_RELEASE);
     uint32_t word;
@@ -2211,17 +2213,26 @@ int tick_run(ydc_context* c, const TickCall& io) {
           b->minv[i] = io.tasks->min_version[i];
           b->rip[i] = io.tasks->requestor_ip[i];
         }
-      if (io.n_rel > 4) std::memcpy(b->rel, io.rel, (size_t)io.n_rel * 4);
-      for (uint32_t i = 0; i < io.n_upd; ++i) {
-        b->upd_idx[i] = io.upd_idx[i];
-        b->upd[i] = TickRow{io.upd_rows[i].num_processors, io.upd_rows[i].current_load, io.upd_rows[i].max_tasks,
-                            io.upd_rows[i].flags};
-      }
-      uint32_t words[8] = {kTickCmdTick | (same ? kTickCmdSame : 0u) | (N << 8) | (io.n_upd << 16) | (io.n_rel << 24),
-                           N ? io.tasks->env_id[0] : 0u, N ? io.tasks->min_version[0] : 0u,
-                           N ? io.tasks->requestor_ip[0] : 0u, 0u, 0u, 0u, 0u};
+      if (io.n_rel > 7) std::memcpy(b->rel, io.rel, (size_t)io.n_rel * 4);
+      if (io.n_upd > 1)
+        for (uint32_t i = 0; i < io.n_upd; ++i) {
+          b->upd_idx[i] = io.upd_idx[i];
+          b->upd[i] = TickRow{io.upd_rows[i].num_processors, io.upd_rows[i].current_load, io.upd_rows[i].max_tasks,
+                              io.upd_rows[i].flags};
+        }
+      uint32_t words[16] = {kTickCmdTick | (same ? kTickCmdSame : 0u) | (N << 8) | (io.n_upd << 16) | (io.n_rel << 24),
+                            N ? io.tasks->env_id[0] : 0u, N ? io.tasks->min_version[0] : 0u,
+                            N ? io.tasks->requestor_ip[0] : 0u};
       for (uint32_t j = 0; j < 4 && j < io.n_rel; ++j) words[4 + j] = io.rel[j];
-      for (int g = 7; g >= 0; --g)
+      for (uint32_t j = 4; j < 7 && j < io.n_rel; ++j) words[9 + j] = io.rel[j];
+      if (io.n_upd) {
+        words[8] = io.upd_idx[0];
+        words[9] = io.upd_rows[0].num_processors;
+        words[10] = io.upd_rows[0].current_load;
+        words[11] = io.upd_rows[0].max_tasks;
+        words[12] = io.upd_rows[0].flags;
+      }
+      for (int g = 15; g >= 0; --g)
         __atomic_store_n(&b->head[g], ((unsigned long long)seq << 32) | words[g], __ATOMIC_RELEASE);
       if (resident_receive(c, io, seq)) {
         ++c->tick_resident;
@@ -2362,14 +2373,25 @@ int tick_run(ydc_context* c, const TickCall& io) {
     YDC_LAUNCH(c, "k_tick", kernel, dim3(1), dim3(threads), lds, launch_stream, a);
     return YDC_OK;
   };
+  // The one-word candidate where the integer key and a registry index share 32 bits (capacities
+  // below 2^10 and a registry that leaves room: every realistic pool); the reference's double as
+  // the key otherwise (packed_tick=0: always).
+  uint32_t idx_bits = 1;
+  while ((1u << idx_bits) < std::max(S, 2u)) ++idx_bits;
+  const bool packed = c->opt_tick_packed && c->tables.cap_bits <= 10 && 2 * c->tables.cap_bits + 1 + idx_bits <= 32;
+  a.cap_bits = c->tables.cap_bits;
+  a.idx_bits = idx_bits;
   int lrc;
-  if (per_thread <= 1) lrc = launch(k_tick<256, 1, true>, 256, 1);
-  else if (per_thread <= 2) lrc = launch(k_tick<256, 2, true>, 256, 2);
-  else if (per_thread <= 4) lrc = launch(k_tick<256, 4, true>, 256, 4);
-  else if (per_thread <= 8) lrc = launch(k_tick<256, 8, true>, 256, 8);
-  else if (per_thread <= 16) lrc = launch(k_tick<256, 16, true>, 256, 16);
-  else if (per_thread <= 32) lrc = launch(k_tick<512, 16, true>, 512, 16);
-  else lrc = launch(k_tick<512, 32, false>, 512, 32);
+#define YDC_TICK_LAUNCH(T, KK, COLD) \
+  lrc = packed ? launch(k_tick<T, KK, COLD, true>, T, KK) : launch(k_tick<T, KK, COLD, false>, T, KK)
+  if (per_thread <= 1) YDC_TICK_LAUNCH(256, 1, true);
+  else if (per_thread <= 2) YDC_TICK_LAUNCH(256, 2, true);
+  else if (per_thread <= 4) YDC_TICK_LAUNCH(256, 4, true);
+  else if (per_thread <= 8) YDC_TICK_LAUNCH(256, 8, true);
+  else if (per_thread <= 16) YDC_TICK_LAUNCH(256, 16, true);
+  else if (per_thread <= 32) YDC_TICK_LAUNCH(512, 16, true);
+  else YDC_TICK_LAUNCH(512, 32, false);
+#undef YDC_TICK_LAUNCH
   if (lrc) return lrc;
   HIP_TRY(c, hipGetLastError());
   mark(c, 7);
@@ -3950,7 +3972,7 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
           break;
         }
       sm.window_max = std::max(sm.window_max, rounds);
-      if (++sm.window_ticks >= 256) {
+      if (++sm.window_ticks >= 64) {
         if (sm.window_max < sm.passes && sm.passes > 2) {
           sm.want_passes = std::max(2u, sm.window_max);
           sm.stale = true;
