@@ -183,9 +183,15 @@ def test_pipelined_batches_commit_in_order(monkeypatch):
     want, _, wrun = O.dispatch(sv, tk, "sorted")
     n, S, nb = len(tk["env_id"]), len(sv["version"]), 6
     per = n // nb
-    for tries in (None, "0"):
+    for tries, swap in ((None, "1"), ("0", "1"), (None, "0")):
         if tries is not None:
             monkeypatch.setenv("YDC_HAND_TRIES", tries)
+        else:
+            monkeypatch.delenv("YDC_HAND_TRIES", raising=False)
+        # COMMIT by swapping the two running_tasks columns, and the copying COMMIT with the outcome
+        # fetched by a blit instead of k_finalize's store (the round-4 path)
+        monkeypatch.setenv("YDC_COMMIT_SWAP", swap)
+        monkeypatch.setenv("YDC_OUTCOME_STORE", swap)
         c = binding.Context(device=0)
         c.upload_servants(pack.to_abi_columns(sv))
         cols = [[DA.from_numpy(tk[k][b * per:(b + 1) * per]) for k in ("env_id", "min_version", "requestor_ip")]
@@ -199,7 +205,7 @@ def test_pipelined_batches_commit_in_order(monkeypatch):
         c.dispatch_wait()
         got = np.concatenate([o.numpy() for o in outs])
         bad = np.nonzero(got != want[:per * nb])[0]
-        assert bad.size == 0, (tries, bad[:5], got[bad[:5]], want[bad[:5]])
+        assert bad.size == 0, (tries, swap, bad[:5], got[bad[:5]], want[bad[:5]])
         wrun_b = O.dispatch(sv, {k: v[:per * nb] for k, v in tk.items()}, "sorted")[2]
         assert np.array_equal(runs[-1].numpy(), wrun_b) and np.array_equal(c.get_running(), wrun_b)
         with pytest.raises(binding.YdcError):
