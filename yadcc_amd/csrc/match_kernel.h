@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   const bool walk_scout = flags & 8u, walk_run = flags & 16u;
   uint32_t kc = blockIdx.x;  // chunk
   const uint32_t probe_kc = blockIdx.x;
-  [[maybe_unused]] uint64_t probe_topup = 0, probe_loop = 0;  // (measurement builds only)
+  [[maybe_unused]] uint64_t probe_topup = 0, probe_loop = 0, probe_gen = 0;  // (measurement builds only)
   if (pass_arg == 0) YDC_PROBE(probe_kc, 0);  // entry
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
   const uint32_t batch_seq = prm->batch_seq;
@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
         return;
       }
       if (walk_run && kc != walk_frontier) return;
+      if (walk_run) YDC_PROBE(0, 5);
       if (!walk_run && pass >= 2 && kc >= 1 && B.sampled[(pass - 1) & B.flag_mask] < 4) {
         // Few end states changed in the previous pass (sampled estimate < ~64): what is left
         // are chains — chunks whose predecessor's end state keeps changing. A chunk whose
@@ -1383,7 +1384,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
           // Classes without holes were advanced with lo == cursor.
           if (!((holes[0] >> lane) & 1)) q.lo = q.cursor;
           if (st == 1) {
-            general_step(i);
+            YDC_PROBE_ACC(probe_gen, general_step(i));
             YDC_PROBE_COUNT(probe_loop);
             ++i;
           }
@@ -1521,6 +1522,12 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       YDC_PROBE_PUT(probe_kc, 11, probe_loop);
     }
     if (pass_arg == 0 && fused_stage) YDC_PROBE(probe_kc, 9);   // second replay done
+    if (walk_run) {  // (tools/cliff_probe.py: running totals of the walking wave, row 0)
+      YDC_PROBE_PUT(0, 6, probe_topup);
+      YDC_PROBE_PUT(0, 7, probe_loop);
+      YDC_PROBE_PUT(0, 8, probe_gen);
+      YDC_PROBE(0, 9);
+    }
     if (pass == 0) {
       if (!fuse) return;
       // ---- pass 1 of this chunk, in the same launch. The end state of the pass-0 replay goes

@@ -370,6 +370,7 @@ struct ydc_context {
   bool opt_commit_swap = true;  // (commit_swap=0: always the copy)
   uint32_t opt_walk_after = 12;
   uint32_t walk_flag = 0;
+  uint32_t walked_at = 0;  // passes launched before the last batch's walk (0: it was not walked)
   bool profiling = false;
   hipEvent_t ev[YDC_STAGE_COUNT + 1] = {};
   ydc_stats stats{};
@@ -1789,6 +1790,7 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
       // Parallel repair is not getting anywhere (one chunk per pass): scout + walk, then two
       // ordinary passes that find everything consistent (match_kernel.h: walk_scout / walk_run).
       walked = true;
+      c->walked_at = launched;
       HIP_TRY(c, hipMemsetAsync(&c->d_prm.p->reserved0, 0xFF, 4, c->stream));
       c->walk_flag = 8u;
       enqueue_pass(c, p, launched, 1u);
@@ -1901,10 +1903,13 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
   uint32_t rounds = 0;
   mark(c, 6);
   if (p.wave_path) {
+    c->walked_at = 0;
     if (int rc = run_passes_until_consistent(c, p, 0, flags, d_out_idx, d_out_util, d_out_running,
                                              &rounds))
       return rc;
-    c->round_hint = rounds;
+    // (a batch that had to be walked says nothing about how many passes the next one wants —
+    // but if it is another of its kind, it should get to the walk as early)
+    c->round_hint = c->walked_at ? std::min(c->walked_at, 3u) : rounds;
   } else {
     if (N && p.C && p.use_generic) {
       // > kMaxWaveClasses classes: replay kernel + k_update per round, host-checked.
