@@ -108,6 +108,7 @@ typedef struct ydc_stats {
    * because a window turned out too small. */
   uint32_t shard_sort_batches, shard_sort_misses;
   uint32_t small_batch;    /* 1: the one-launch path placed the batch (ydc_dispatch_tick) */
+  uint32_t zone_rows;      /* chunks around the dedicated tier's end that started from a walked state (0: no walk) */
   float stage_ms[16];      /* per-stage GPU time when profiling is on (ydc_set_profiling) */
 } ydc_stats;
 

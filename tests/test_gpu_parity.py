@@ -594,3 +594,38 @@ def test_matching_loop_variants(n_envs, rings, monkeypatch):
         print("n_envs", n_envs, "classes", sa["n_classes"], "rings", rings, "rounds", sa["rounds"])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("lead", [None, "256", "off"])
+def test_walk_of_the_dedicated_tiers_end(lead, monkeypatch):
+    """zone_guess.h: workgroup 0 of the first matching launch walks the stretch where the dedicated
+    tier runs out and the chunks there start from its cursors instead of their level guesses
+    (cfg3's registry, a batch that reaches past the tier's end). Same placement as the oracle with
+    the walk, without it, and with a walk that starts too late to be of use (lead 256: the served
+    chunks replay again like any wrongly started chunk — and the next batch's walk starts earlier)."""
+    if lead == "off":
+        monkeypatch.setenv("YDC_ZONE_GUESS", "0")
+    elif lead:
+        monkeypatch.setenv("YDC_ZONE_LEAD", lead)
+    sv, tk = synth.make_config("cfg3")
+    n = 480_000
+    tk = {k: v[:n] for k, v in tk.items()}
+    want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+    c = binding.Context(device=0)
+    try:
+        c.upload_servants(pack.to_abi_columns(sv))
+        seen = []
+        for _ in range(4):
+            got, gutil, grun = c.dispatch(tk)
+            st = c.stats()
+            seen.append((st["zone_rows"], st["rounds"]))
+            assert np.array_equal(got, want) and np.array_equal(grun, wrun) and np.array_equal(gutil, wutil), seen
+        if lead == "off":
+            assert all(z == 0 for z, _ in seen), seen
+        else:
+            assert all(z >= 2 for z, _ in seen), seen   # the stretch spans several chunks
+            assert seen[-1][1] <= 2, seen                # ... which come out consistent in their first replay
+            if lead:
+                assert seen[0][1] > 2, seen              # (not with a walk that starts inside the transient)
+    finally:
+        c.close()

@@ -120,6 +120,28 @@ def hbmtable(specs):
     return "\n".join(out)
 
 
+def timeline(path, last=40):
+    """Start / duration / gap to the previous kernel's end of the last `last` dispatches (all queues)."""
+    db = sqlite3.connect(path)
+    try:
+        rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
+    except sqlite3.Error:
+        try:
+            rows = list(db.execute("select name, start, end, 0 from kernels order by start"))
+        except sqlite3.Error as e:
+            names = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+            return "no kernels view (%s); have: %s" % (e, ", ".join(names))
+    rows = rows[-last:]
+    t0 = rows[0][1]
+    out = ["%-44s %6s %12s %10s %10s" % ("kernel", "queue", "start_us", "dur_us", "gap_us")]
+    prev_end = None
+    for n, a, b, q in rows:
+        gap = (a - prev_end) / 1e3 if prev_end is not None else 0.0
+        out.append("%-44s %6s %12.2f %10.2f %10.2f" % (short(n)[:44], q, (a - t0) / 1e3, (b - a) / 1e3, gap))
+        prev_end = max(prev_end or b, b)
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "hbmjson":
@@ -130,5 +152,7 @@ if __name__ == "__main__":
         print(calib(sys.argv[2], sys.argv[3]))
     elif mode == "hbmtable":
         print(hbmtable(sys.argv[2:]))
+    elif mode == "timeline":
+        print(timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40))
     else:
         print(stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2]))

@@ -25,7 +25,7 @@ python tools/rocprof_summary.py hbmtable "cfg2 (100k requests x 2k servants)=pro
   "cfg4 (4M requests x 16k servants, 4 digests)=profiles/${R}_cfg4_pmc_hbm.json" > profiles/${R}_hbm_utilisation.txt
 # bench lines
 timeout 900 python bench.py --steps 20 --warmup 5 > $F/bench_driver_line.json 2> $F/bench_driver_line.err
-timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2000 --warmup 100 > $F/bench_cfg2.json 2> $F/bench_cfg2.err
+timeout 600 python bench.py --no-extra-configs --steps 2000 --warmup 100 > $F/bench_cfg2.json 2> $F/bench_cfg2.err
 timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --no-pipeline --steps 2000 --warmup 100 > $F/bench_cfg2_sync.json 2> $F/bench_cfg2_sync.err
 timeout 300 python bench.py --config cfg3 --no-cpu-baseline --no-extra-configs --steps 200 --warmup 10 > $F/bench_cfg3.json 2> $F/bench_cfg3.err
 timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-extra-configs --steps 100 --warmup 5 > $F/bench_cfg4.json 2> $F/bench_cfg4.err

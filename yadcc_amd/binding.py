@@ -72,7 +72,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "n_tasks", "n_servants", "n_classes", "n_slots", "key_bits", "radix_passes", "n_chunks",
         "rounds", "chunk_sims", "granted", "timeouts", "env_not_found", "shard_sort_batches",
-        "shard_sort_misses", "small_batch")] + [
+        "shard_sort_misses", "small_batch", "zone_rows")] + [
             ("stage_ms", C.c_float * 16)]
 
     def as_dict(self):
@@ -175,7 +175,7 @@ def _ptr(a):
 # into YDC_TUNE right before a context is created (and takes out again what it folded in last
 # time, so that a switch a test has dropped is gone). Not an interface of the package.
 _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GUESS", "PAIR", "RING_TOTAL",
-              "DENSE", "SPLIT_GEN", "XCD_TILES", "TILE_TAB", "GROUP_WALK", "WALK_PACKED", "SCAN_MULTI", "CLASSIFY_PER_THREAD",
+              "DENSE", "SPLIT_GEN", "XCD_TILES", "TILE_TAB", "GROUP_WALK", "WALK_PACKED", "ZONE_GUESS", "ZONE_LEAD", "ZONE_TRAIL", "ZONE_MAX_CHUNKS", "SCAN_MULTI", "CLASSIFY_PER_THREAD",
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",

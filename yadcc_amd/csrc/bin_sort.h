@@ -148,6 +148,7 @@ __device__ __forceinline__ void front_bin_boundary(const ServantTable& sv, uint3
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->reserved0 = 0;
+    prm->zone_rows = 0;
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;

@@ -80,6 +80,8 @@ struct DeviceParams {
   // k_finalize's servant workgroups that have reported (the last one hands the outcome to the
   // host and clears it).
   uint32_t fin_reports;
+  // zone_guess.h: chunks the walk of the dedicated tier's end left start cursors for (0: none).
+  uint32_t zone_rows;
 };
 
 // Measurement builds only (`make probe`): wall-clock stamps the kernels leave behind
@@ -108,6 +110,8 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (an LDS word named by its byte address)
 
 // Minimum over the 64 lanes (every lane gets it). Six v_min_u32_dpp.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -197,6 +201,7 @@ __device__ __forceinline__ void servant_scan_finish(const ServantTable& sv, uint
     prm->overflow = m > max_slots ? 1u : 0u;
     prm->n_slots = m > max_slots ? 0u : m;
     prm->reserved0 = 0;
+    prm->zone_rows = 0;
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;

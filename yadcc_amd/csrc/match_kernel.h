@@ -148,10 +148,20 @@ struct MatchBuffers {
   uint32_t tile_tab_tiles, tile_tab_elems;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
   uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
+  // Non-NULL (zone_guess.h): k_zone_guess walks the stretch where the dedicated tier runs out
+  // as workgroup 0 of the launch of pass 0 (the chunks are the workgroups behind it) and publishes, as granules {word, batch number}, which chunks
+  // that is ([0], [1]) and the class cursors their replays start from ([2 + row * C + class]);
+  // those chunks wait for their row instead of using their level guess.
+  unsigned long long* zone_box;
+  const uint2* zone_sorted;   // the key-sorted records {key, value}: where tier 1 begins
+  uint32_t zone_tier_shift;   // key >> zone_tier_shift != 0: tier 1
+  uint32_t zone_lead, zone_trail;  // the stretch: levels [T0 - lead, T0 + trail)
 };
 
 constexpr uint32_t kWarmUp = 16;
 
+constexpr uint32_t kZoneHeaderTries = 40;   // ~35 us
+constexpr uint32_t kZoneRowTries = 4000;    // ~5 ms: the walk is running once its header is there
 constexpr uint32_t kHandTries = 1500;  // polls for the predecessor's granules before giving up
 
 constexpr uint32_t kEarlyAt = 16;  // requests into a chunk at which MatchBuffers::early is taken
@@ -677,6 +687,10 @@ __device__ __forceinline__ uint32_t match_fast_loop(
 // SIMD to offer, a fourth resident wave is worth the two dozen registers spilled in the prologue
 // (OCC = 4: 128 VGPRs instead of 152).
 // CHECKED: rings of 32 entries, watched by the fast loop itself (match_fast_loop<true>).
+}  // namespace ydc
+#include "zone_guess.h"
+namespace ydc {
+
 template <int W, int OCC = 1, bool CHECKED = false>
 __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable T, uint32_t n_tasks,
                                                    uint32_t chunk_size, uint32_t n_chunks,
@@ -695,7 +709,16 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
   // replays its chunk from the true state and carries on through every chunk behind it.
   const bool walk_scout = flags & 8u, walk_run = flags & 16u;
   uint32_t kc = blockIdx.x;  // chunk
-  const uint32_t probe_kc = blockIdx.x;
+  if (W == 1 && B.zone_box != nullptr && pass_arg == 0) {
+    // (zone_guess.h: one workgroup more than chunks, the first walks the stretch around the end
+    // of the dedicated tier for the chunks there)
+    if (blockIdx.x == 0) {
+      zone_walk(L, T.mask, n_tasks, chunk_size, n_chunks, B, prm, lds_ring, flags >> 8);
+      return;
+    }
+    kc = blockIdx.x - 1;
+  }
+  const uint32_t probe_kc = kc;
   [[maybe_unused]] uint64_t probe_topup = 0, probe_loop = 0, probe_gen = 0;  // (measurement builds only)
   if (pass_arg == 0) YDC_PROBE(probe_kc, 0);  // entry
   // Everything the wave needs to decide whether it has work, fetched in one round trip.
@@ -983,6 +1006,36 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
         if (lane == ((uint32_t)q >> 1) && lane < C) {
           if (q & 1) next_guess.cursor = next_guess.lo = lo[q];
           else st.cursor = st.lo = next_guess.cursor = next_guess.lo = lo[q];
+        }
+      }
+    }
+    if (B.zone_box && kc > 0) {
+      // The header is there long before any wave gets here (the walk starts before this launch and
+      // finds its stretch in 5 us; the level guesses above took 15) — unless the walk's kernel has
+      // not been given a place on the chip: then nobody waits for it.
+      uint32_t z_lo = 0, z_hi = 0;
+      for (uint32_t tries = 0; tries < kZoneHeaderTries; ++tries) {
+        const unsigned long long h0 = __hip_atomic_load(B.zone_box + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long h1 = __hip_atomic_load(B.zone_box + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(h0 >> 32) == batch_seq && (uint32_t)(h1 >> 32) == batch_seq) {
+          z_lo = (uint32_t)h0;
+          z_hi = (uint32_t)h1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (kc > z_lo && kc < z_hi) {  // (row 0 is the level guess of chunk z_lo itself)
+        const unsigned long long* g = B.zone_box + 2 + (size_t)(kc - z_lo) * C + lane;
+        for (uint32_t tries = 0; tries < kZoneRowTries; ++tries) {
+          unsigned long long v = (unsigned long long)batch_seq << 32;
+          if (lane < C) v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__ballot((uint32_t)(v >> 32) != batch_seq) == 0) {
+            if (lane < C) st.cursor = st.lo = (uint32_t)v;
+            rings_from_windows = false;  // (filled around the level guess)
+            __builtin_amdgcn_s_setprio(2);  // (the launch ends with these chunks)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(32);
         }
       }
     }

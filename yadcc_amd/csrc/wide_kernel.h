@@ -85,7 +85,6 @@ struct WideState {
 // classes l, l + 64, ...); else this lane's class of the request's row of eligible classes (kNone:
 // none; rows are ascending and hold a class once) — one class per lane, no loop over the words.
 constexpr uint32_t kNoRow = 0xFFFFFFFEu;
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (an LDS word named by its byte address)
 // Head rank above the class id (k_walk_groups, ranks below 2^(32 - cbits) - 1): the lowest-ranked
 // head of a row of classes and the class it belongs to are one unsigned minimum.
 __device__ __forceinline__ uint32_t pack_head(uint32_t rank, uint32_t c, uint32_t cbits) {

@@ -89,6 +89,7 @@ struct BatchPlan {
   bool fuse01 = false;  // the launch of matching pass 0 is pass 1 as well (no launch for pass 1)
   bool wide_lists = false;  // > 256 classes with short eligible-class rows: k_sim_wide's list form
   bool binsort = false;
+  bool zone = false;            // workgroup 0 of the launch of pass 0 walks the tier's end (zone_guess.h)
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   uint32_t bin_group = 0, bin_tiles = 0;  // servants per slot tile, slot tiles (k_front_bins)
   ServantTable sv{};
@@ -134,6 +135,7 @@ struct ydc_context {
   DevBuf<uint16_t> d_cls_by_g;
   DevBuf<uint32_t> d_owner;     // servant of every slot (generation order)
   DevBuf<uint32_t> d_rank_to_g; // global rank -> slot when the class pass is fused into the sort
+  DevBuf<unsigned long long> d_zone_box;  // zone_walk's granules: header + a row of cursors per chunk
   DevBuf<uint32_t> d_binbase, d_binruns;  // bin sort: starts of the bins per class, run table of the slot tiles
   DevBuf<uint32_t> d_level_tab;           // bin sort: class-list positions at every 64th global rank
   DevBuf<uint32_t> d_elig_off, d_elig_cls, d_row_of;  // > 256 classes: eligible-class lists, the requests' rows
@@ -323,6 +325,15 @@ struct ydc_context {
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
   bool opt_scan_multi = true;  // (scan_multi=0: one workgroup loops over the slabs)
   bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
+  bool opt_zone_guess = true;  // start guesses around the dedicated tier's end from a walk of that stretch (zone_guess=0: level guesses)
+  // lead: where the walk starts, in levels before the tier's end (the first chunk boundary inside
+  // it: up to a chunk less). It has to be on the true track when the transient begins (cfg3: 840
+  // levels before the end; a start 1349 before it is too late, 1861 is not), and every request of
+  // the lead delays the stretch's last chunk by 54 ns: the default, and more after a batch whose
+  // served chunks did not come out consistent (zone_feedback).
+  uint32_t opt_zone_lead = 2304, opt_zone_trail = 1024, opt_zone_max_chunks = 2560;
+  uint32_t zone_lead_cur = 0;   // (0: opt_zone_lead) what zone_feedback has raised the lead to
+  uint32_t zone_fails = 0, zone_cooldown = 0;  // failures at the largest lead; batches without a walk
   bool opt_walk_packed = true; // ... with head rank and class id in one word where they fit (walk_packed=0: two arrays)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
@@ -757,6 +768,10 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
   if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
   if (const char* s = tune_value("walk_packed")) c->opt_walk_packed = atoi(s) != 0;
+  if (const char* s = tune_value("zone_guess")) c->opt_zone_guess = atoi(s) != 0;
+  if (const char* s = tune_value("zone_lead")) c->opt_zone_lead = (uint32_t)atoi(s);
+  if (const char* s = tune_value("zone_trail")) c->opt_zone_trail = (uint32_t)atoi(s);
+  if (const char* s = tune_value("zone_max_chunks")) c->opt_zone_max_chunks = (uint32_t)atoi(s);
   if (const char* s = tune_value("scan_multi")) c->opt_scan_multi = atoi(s) != 0;
   if (const char* s = tune_value("classify_per_thread")) c->opt_classify_multi = atoi(s) != 1;
   if (const char* s = tune_value("packed_class")) c->opt_packed_class = atoi(s) != 0;
@@ -812,6 +827,7 @@ int ydc_destroy(ydc_context* c) {
   c->d_cls_by_g.release();
   c->d_owner.release();
   c->d_rank_to_g.release();
+  c->d_zone_box.release();
   c->d_guess[0].release();
   c->d_endst.release();
   c->d_checkpoint.release();
@@ -1374,6 +1390,31 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     // enough for a whole block of 64 requests from one class.
     if (C <= 8) p.init_fill = std::min(128u, R);
     else if (C <= 16) p.init_fill = std::min(64u, R);
+    // The stretch where the dedicated tier runs out, walked by one wave beside the first pass
+    // (zone_guess.h: workgroup 0 of that launch). Where the passes are one round of
+    // latency-bound waves — a chain behind the first launch then costs its full serial time
+    // (cfg3: 224 of 384 us) —; a batch of more chunks hides its second replays behind the other
+    // waves' work. (The walk's rings — ranks only, 128 entries per class at least — live in the
+    // LDS a chunk's wave has.)
+    p.zone = c->opt_zone_guess && p.W == 1 && p.mb.before && p.fuse01 && p.mb.tail && c->n_parts <= 1 &&
+             !p.binsort && p.packed && c->kf.exact && p.key_passes >= 1 && C > 8 && C <= 64 && p.mb.tile_tab &&
+             K >= 64 && K <= c->opt_zone_max_chunks && !for_window && slot_bound && !c->stream_mode.active &&
+             ((size_t)C << 7) <= 2 * (size_t)p.ring_total;
+    if (p.zone && c->zone_cooldown) {
+      --c->zone_cooldown;
+      p.zone = false;
+    }
+    if (p.zone) {
+      const unsigned long long* had = c->d_zone_box.p;
+      HIP_TRY(c, c->d_zone_box.reserve(2 + (size_t)kZoneMaxChunks * C));
+      if (c->d_zone_box.p != had)  // (a granule is valid when it carries the batch's number: none does yet)
+        HIP_TRY(c, hipMemsetAsync(c->d_zone_box.p, 0, c->d_zone_box.cap * 8, c->stream));
+      p.mb.zone_box = c->d_zone_box.p;
+      p.mb.zone_sorted = (const uint2*)c->d_keys[key_sorted].p;
+      p.mb.zone_tier_shift = c->kf.key_bits - 1;
+      p.mb.zone_lead = std::max(c->opt_zone_lead, c->zone_lead_cur);
+      p.mb.zone_trail = c->opt_zone_trail;
+    }
   }
   return YDC_OK;
 }
@@ -1631,8 +1672,10 @@ void enqueue_pass(ydc_context* c, const BatchPlan& p, uint32_t pass, uint32_t de
   DeviceParams* prm = c->d_prm.p;
   // (rings of 32 entries are watched by the fast loop itself: match_kernel.h, CHECKED)
   const bool checked = p.W == 1 && p.rshift == 5;
+  // (pass 0 of a plan with a zone walk: one workgroup more, the walk is the first — zone_guess.h)
+  const uint32_t grid1 = p.K + (p.mb.zone_box && pass == 0 ? 1u : 0u);
 #define YDC_LAUNCH_MATCH1(OCC, CHECKED)                                                             \
-  YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1, OCC, CHECKED>), dim3(p.K), dim3(64), lds, c->stream, \
+  YDC_LAUNCH(c, "k_match_pass", (k_match_pass<1, OCC, CHECKED>), dim3(grid1), dim3(64), lds, c->stream, \
              p.L, p.T, p.N, p.cs, p.K, p.mb, pass, device_check, p.rshift, p.init_fill, p.shared, prm)
   if (p.W == 1) {
     if (p.dense && checked) YDC_LAUNCH_MATCH1(4, true);
@@ -1736,6 +1779,7 @@ void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   s.granted = c->h_prm->granted;
   s.shard_sort_batches = (uint32_t)c->group.windowed_batches;
   s.shard_sort_misses = (uint32_t)c->group.window_misses;
+  s.zone_rows = p.zone ? c->h_prm->zone_rows : 0u;
   s.env_not_found = p.N - std::min(p.N, c->h_prm->consuming);
   s.timeouts = p.N - s.env_not_found - std::min(p.N - s.env_not_found, s.granted);
 }
@@ -1764,6 +1808,24 @@ void collect_kernel_profile(ydc_context* c) {
     j += buf;
   }
   c->kprofile_json = j + "}";
+}
+
+// After a batch with a zone walk (zone_guess.h): the chunks it served should have come out
+// consistent in their first replay — two rounds. If not, the walk was not yet on the true track
+// where the transient began: the next one starts earlier. (rows: DeviceParams::zone_rows.)
+constexpr uint32_t kZoneLeadMax = 4096;
+void zone_feedback(ydc_context* c, const BatchPlan& p, uint32_t rows, uint32_t rounds) {
+  if (!p.zone || rows < 2) return;
+  if (rounds <= 2) {
+    c->zone_fails = 0;
+    return;
+  }
+  if (p.mb.zone_lead < kZoneLeadMax) {
+    c->zone_lead_cur = std::min(p.mb.zone_lead + 512, kZoneLeadMax);
+  } else if (++c->zone_fails >= 4) {  // this registry's transient is not one the walk tracks
+    c->zone_fails = 0;
+    c->zone_cooldown = 256;
+  }
 }
 
 // Passes [launched, ...) in groups until one finds every chunk consistent, each group
@@ -1910,6 +1972,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
     // (a batch that had to be walked says nothing about how many passes the next one wants —
     // but if it is another of its kind, it should get to the walk as early)
     c->round_hint = c->walked_at ? std::min(c->walked_at, 3u) : rounds;
+    zone_feedback(c, p, c->h_prm->zone_rows, rounds);
   } else {
     if (N && p.C && p.use_generic) {
       // > kMaxWaveClasses classes: replay kernel + k_update per round, host-checked.
@@ -2615,6 +2678,7 @@ int ydc_dispatch_wait(ydc_context* c) {
         }
       *c->h_prm = o;
       c->round_hint = rounds;
+      zone_feedback(c, pd.plan, o.zone_rows, rounds);
       fill_stats(c, pd.plan, rounds);
       pop();
       return YDC_OK;
@@ -3435,6 +3499,8 @@ int ydc_dispatch_sharded(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uin
   for (;;) {
     p = windowed ? win_plan : full_plan;
     p.mb.has_successor = g.rank + 1 < g.n_ranks ? 1u : 0u;
+    p.zone = false;  // (the walk of the tier's end is a single-context thing: zone_guess.h)
+    p.mb.zone_box = nullptr;
     if (windowed) {
       // Slots of the window: this rank's requests + a margin on both sides (classes run ahead
       // of or behind the global level) + the granularity of the thresholds.
