@@ -1043,7 +1043,9 @@ def main():
         out["configs"] = {}
         for cfg in ("cfg3", "cfg4"):
             k = max(5, min(args.steps, 20))
-            out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 3, "compact"))
+            # (ten untimed batches: the library decides from a shape's first seven whether the walk of
+            # the dedicated tier's end pays on this registry — DESIGN.md 9.3)
+            out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 10, "compact"))
         # Sparse eligibility: cfg2's batch on a pool with 150 digests, every servant advertising its
         # own handful (~one servant class per servant; the reference has no limit on them,
         # task_dispatcher.h:93-94) — the walk in groups of 64 requests (wide_kernel.h).

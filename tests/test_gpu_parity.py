@@ -596,16 +596,17 @@ def test_matching_loop_variants(n_envs, rings, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("lead", [None, "256", "off"])
+@pytest.mark.parametrize("lead", [None, "256", "off", "auto"])
 def test_walk_of_the_dedicated_tiers_end(lead, monkeypatch):
     """zone_guess.h: workgroup 0 of the first matching launch walks the stretch where the dedicated
     tier runs out and the chunks there start from its cursors instead of their level guesses
     (cfg3's registry, a batch that reaches past the tier's end). Same placement as the oracle with
     the walk, without it, and with a walk that starts too late to be of use (lead 256: the served
-    chunks replay again like any wrongly started chunk — and the next batch's walk starts earlier)."""
-    if lead == "off":
-        monkeypatch.setenv("YDC_ZONE_GUESS", "0")
-    elif lead:
+    chunks replay again like any wrongly started chunk — and the next batch's walk starts earlier).
+    "auto" (the default): no walk until a few batches have shown a chain behind the first launch,
+    then the walk as long as batches cost less on the device with it."""
+    monkeypatch.setenv("YDC_ZONE_GUESS", {"off": "0", "auto": "1"}.get(lead, "2"))
+    if lead == "256":
         monkeypatch.setenv("YDC_ZONE_LEAD", lead)
     sv, tk = synth.make_config("cfg3")
     n = 480_000
@@ -615,13 +616,17 @@ def test_walk_of_the_dedicated_tiers_end(lead, monkeypatch):
     try:
         c.upload_servants(pack.to_abi_columns(sv))
         seen = []
-        for _ in range(4):
+        for _ in range(12 if lead == "auto" else 4):
             got, gutil, grun = c.dispatch(tk)
             st = c.stats()
             seen.append((st["zone_rows"], st["rounds"]))
             assert np.array_equal(got, want) and np.array_equal(grun, wrun) and np.array_equal(gutil, wutil), seen
         if lead == "off":
             assert all(z == 0 for z, _ in seen), seen
+        elif lead == "auto":
+            assert all(x == (0, 4) for x in seen[:4]), seen           # the chain, seen three times behind a cold batch
+            assert all(z >= 2 for z, _ in seen[4:7]), seen            # ... the walk, tried three times
+            assert all(z >= 2 and r <= 2 for z, r in seen[7:]), seen  # ... and kept: it costs less
         else:
             assert all(z >= 2 for z, _ in seen), seen   # the stretch spans several chunks
             assert seen[-1][1] <= 2, seen                # ... which come out consistent in their first replay

@@ -82,6 +82,10 @@ struct DeviceParams {
   uint32_t fin_reports;
   // zone_guess.h: chunks the walk of the dedicated tier's end left start cursors for (0: none).
   uint32_t zone_rows;
+  // The 100 MHz wall clock when the batch's first kernel reset the counters and when its finalise
+  // handed over the outcome: what the batch cost on the device, queue gaps included (the host
+  // weighs optional steps against it: ydc_api.hip zone_decide).
+  uint32_t t_begin_lo, t_begin_hi, t_end_lo, t_end_hi;
 };
 
 // Measurement builds only (`make probe`): wall-clock stamps the kernels leave behind
@@ -202,6 +206,11 @@ __device__ __forceinline__ void servant_scan_finish(const ServantTable& sv, uint
     prm->n_slots = m > max_slots ? 0u : m;
     prm->reserved0 = 0;
     prm->zone_rows = 0;
+    {
+      const unsigned long long t = wall_clock64();
+      prm->t_begin_lo = (uint32_t)t;
+      prm->t_begin_hi = (uint32_t)(t >> 32);
+    }
     prm->chunk_sims = 0;
     prm->granted = 0;
     prm->consuming = 0;
@@ -1396,6 +1405,12 @@ __global__ __launch_bounds__(256) void k_finalize(ServantTable sv, const uint32_
     }
     __syncthreads();
     if (last) {
+      if (threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        prm->t_end_lo = (uint32_t)t;
+        prm->t_end_hi = (uint32_t)(t >> 32);
+      }
+      __syncthreads();
       __threadfence();
       const uint32_t* src = (const uint32_t*)prm;
       uint32_t* dst = (uint32_t*)ra.host_outcome;

@@ -90,6 +90,7 @@ struct BatchPlan {
   bool wide_lists = false;  // > 256 classes with short eligible-class rows: k_sim_wide's list form
   bool binsort = false;
   bool zone = false;            // workgroup 0 of the launch of pass 0 walks the tier's end (zone_guess.h)
+  bool zone_eligible = false;   // ... or would, if zone_decide had found it worth its while
   uint32_t n_bins = 0, bin_shift = 0, bin_slot_bits = 0, bin_cls_bits = 0;
   uint32_t bin_group = 0, bin_tiles = 0;  // servants per slot tile, slot tiles (k_front_bins)
   ServantTable sv{};
@@ -325,7 +326,7 @@ struct ydc_context {
   uint32_t opt_xcd = 3;  // XCD-contiguous tile order: 1 slot generation, 2 histograms, 4 scatters (YDC_XCD_TILES)
   bool opt_scan_multi = true;  // (scan_multi=0: one workgroup loops over the slabs)
   bool opt_group_walk = true;  // sparse eligibility: the walk in groups of 64 requests (YDC_GROUP_WALK=0: one at a time)
-  bool opt_zone_guess = true;  // start guesses around the dedicated tier's end from a walk of that stretch (zone_guess=0: level guesses)
+  uint32_t opt_zone_guess = 1;  // start guesses around the dedicated tier's end from a walk of that stretch: 1 where it pays, 2 always, 0 never
   // lead: where the walk starts, in levels before the tier's end (the first chunk boundary inside
   // it: up to a chunk less). It has to be on the true track when the transient begins (cfg3: 840
   // levels before the end; a start 1349 before it is too late, 1861 is not), and every request of
@@ -334,6 +335,18 @@ struct ydc_context {
   uint32_t opt_zone_lead = 2304, opt_zone_trail = 1024, opt_zone_max_chunks = 2560;
   uint32_t zone_lead_cur = 0;   // (0: opt_zone_lead) what zone_feedback has raised the lead to
   uint32_t zone_fails = 0, zone_cooldown = 0;  // failures at the largest lead; batches without a walk
+  // Whether the walk pays is the registry's business (three of four seeds of cfg3's pool have no
+  // chain at the tier's end: the chunks there would wait 200 us for cursors their level guesses
+  // already had): decided from what batches of this shape cost on the device with and without it
+  // (zone_decide / zone_feedback; zone_guess=2 forces the walk, 0 forbids it).
+  struct ZoneArm {
+    uint32_t n = 0;
+    float ticks = 0;  // (moving average, 100 MHz)
+  } zone_on, zone_off;
+  uint32_t zone_off_rounds = 0;  // rounds of the last batch without the walk
+  bool zone_cold = true;         // the shape's first batch has not been seen yet (not counted)
+  uint32_t zone_since_probe = 0;
+  uint64_t zone_shape = 0;       // the plans the figures above are about
   bool opt_walk_packed = true; // ... with head rank and class id in one word where they fit (walk_packed=0: two arrays)
   bool opt_tile_tab = true;  // level searches narrowed by the class pass's histogram table (YDC_TILE_TAB=0)
   bool opt_classify_multi = true;  // (YDC_CLASSIFY_PER_THREAD=1: one request per thread everywhere)
@@ -768,7 +781,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("tile_tab")) c->opt_tile_tab = atoi(s) != 0;
   if (const char* s = tune_value("group_walk")) c->opt_group_walk = atoi(s) != 0;
   if (const char* s = tune_value("walk_packed")) c->opt_walk_packed = atoi(s) != 0;
-  if (const char* s = tune_value("zone_guess")) c->opt_zone_guess = atoi(s) != 0;
+  if (const char* s = tune_value("zone_guess")) c->opt_zone_guess = (uint32_t)std::max(0, atoi(s));
   if (const char* s = tune_value("zone_lead")) c->opt_zone_lead = (uint32_t)atoi(s);
   if (const char* s = tune_value("zone_trail")) c->opt_zone_trail = (uint32_t)atoi(s);
   if (const char* s = tune_value("zone_max_chunks")) c->opt_zone_max_chunks = (uint32_t)atoi(s);
@@ -1148,6 +1161,8 @@ namespace {
 
 // for_window: the plan of a multi-GPU batch whose slot sort is sharded (k_window generates only a
 // key window of the slots: radix pipeline).
+bool zone_decide(ydc_context* c, uint32_t N, uint32_t K, uint32_t C);
+
 int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = false) {
   BatchPlan& p = *out;
   p = BatchPlan{};
@@ -1404,6 +1419,8 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
       --c->zone_cooldown;
       p.zone = false;
     }
+    p.zone_eligible = p.zone;
+    if (p.zone && c->opt_zone_guess == 1) p.zone = zone_decide(c, N, K, C);
     if (p.zone) {
       const unsigned long long* had = c->d_zone_box.p;
       HIP_TRY(c, c->d_zone_box.reserve(2 + (size_t)kZoneMaxChunks * C));
@@ -1810,11 +1827,46 @@ void collect_kernel_profile(ydc_context* c) {
   c->kprofile_json = j + "}";
 }
 
+// Walk or no walk for a batch of this shape? Without one until three batches (behind a first one
+// that is not counted: cold caches) have shown a chain (more than two rounds); then three with it; then whichever costs less on the device
+// (DeviceParams::t_begin .. t_end), the other one tried again every 64th batch.
+bool zone_decide(ydc_context* c, uint32_t N, uint32_t K, uint32_t C) {
+  const uint64_t shape = ((uint64_t)(N >> 12) << 40) | ((uint64_t)K << 16) | C;
+  if (shape != c->zone_shape) {
+    c->zone_shape = shape;
+    c->zone_on = c->zone_off = ydc_context::ZoneArm{};
+    c->zone_off_rounds = 0;
+    c->zone_since_probe = 0;
+    c->zone_cold = true;
+  }
+  if (c->zone_off.n < 3 || c->zone_off_rounds <= 2) return false;  // (no chain: nothing to cure)
+  if (c->zone_on.n < 3) return true;
+  const bool best = c->zone_on.ticks < c->zone_off.ticks;
+  if (++c->zone_since_probe >= 64) {
+    c->zone_since_probe = 0;
+    return !best;
+  }
+  return best;
+}
+
 // After a batch with a zone walk (zone_guess.h): the chunks it served should have come out
 // consistent in their first replay — two rounds. If not, the walk was not yet on the true track
 // where the transient began: the next one starts earlier. (rows: DeviceParams::zone_rows.)
 constexpr uint32_t kZoneLeadMax = 4096;
-void zone_feedback(ydc_context* c, const BatchPlan& p, uint32_t rows, uint32_t rounds) {
+void zone_feedback(ydc_context* c, const BatchPlan& p, const DeviceParams& o, uint32_t rounds) {
+  const uint32_t rows = o.zone_rows;
+  if (p.zone_eligible) {
+    const uint64_t t0 = ((uint64_t)o.t_begin_hi << 32) | o.t_begin_lo, t1 = ((uint64_t)o.t_end_hi << 32) | o.t_end_lo;
+    ydc_context::ZoneArm& arm = p.zone ? c->zone_on : c->zone_off;
+    if (c->zone_cold) {
+      c->zone_cold = false;
+    } else if (t1 > t0 && t1 - t0 < 100000000ull) {  // (stamped by this batch's first and last kernel)
+      const float x = (float)(t1 - t0);
+      arm.ticks = arm.n ? 0.75f * arm.ticks + 0.25f * x : x;
+      ++arm.n;
+    }
+    if (!p.zone) c->zone_off_rounds = rounds;
+  }
   if (!p.zone || rows < 2) return;
   if (rounds <= 2) {
     c->zone_fails = 0;
@@ -1828,6 +1880,15 @@ void zone_feedback(ydc_context* c, const BatchPlan& p, uint32_t rows, uint32_t r
   }
 }
 
+// Passes to launch before the first look at the outcome: what the last batch needed — and what
+// the last batch WITHOUT the walk of the tier's end needed when this is one of those again
+// (zone_decide tries the other arm now and then: it must not cost a pipeline miss).
+uint32_t first_group(const ydc_context* c, const BatchPlan& p) {
+  uint32_t hint = c->round_hint;
+  if (p.zone_eligible && !p.zone) hint = std::max(hint, c->zone_off_rounds);
+  return std::max(2u, std::min(hint, 16u));
+}
+
 // Passes [launched, ...) in groups until one finds every chunk consistent, each group
 // followed by the (gated) finalise and one look at the counters.
 int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t launched, uint32_t flags,
@@ -1835,7 +1896,7 @@ int run_passes_until_consistent(ydc_context* c, const BatchPlan& p, uint32_t lau
                                 uint32_t* rounds) {
   bool walked = false;
   for (;;) {
-    const uint32_t group = launched == 0 ? std::max(2u, std::min(c->round_hint, 16u)) : 4u;
+    const uint32_t group = launched == 0 ? first_group(c, p) : 4u;
     if (launched) {
       // Counter slots of the passes to come (the first group's were cleared by
       // k_servant_scan). The stream is idle here: the host has just synchronised.
@@ -1972,7 +2033,7 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
     // (a batch that had to be walked says nothing about how many passes the next one wants —
     // but if it is another of its kind, it should get to the walk as early)
     c->round_hint = c->walked_at ? std::min(c->walked_at, 3u) : rounds;
-    zone_feedback(c, p, c->h_prm->zone_rows, rounds);
+    zone_feedback(c, p, *c->h_prm, rounds);
   } else {
     if (N && p.C && p.use_generic) {
       // > kMaxWaveClasses classes: replay kernel + k_update per round, host-checked.
@@ -2610,7 +2671,7 @@ int ydc_dispatch_device_async(ydc_context* c, const ydc_task_soa* tk, uint32_t N
     pd.rerun = true;
   } else {
     if (int rc = enqueue_front(c, pd.plan, &pd.tk)) return give_up(rc);
-    const uint32_t group = std::max(2u, std::min(c->round_hint, 16u));
+    const uint32_t group = first_group(c, pd.plan);
     for (uint32_t r = 0; r < group; ++r) enqueue_pass(c, pd.plan, r, 1u);
     pd.launched = group;
     c->enqueue_pipelined = true;
@@ -2678,7 +2739,7 @@ int ydc_dispatch_wait(ydc_context* c) {
         }
       *c->h_prm = o;
       c->round_hint = rounds;
-      zone_feedback(c, pd.plan, o.zone_rows, rounds);
+      zone_feedback(c, pd.plan, o, rounds);
       fill_stats(c, pd.plan, rounds);
       pop();
       return YDC_OK;
