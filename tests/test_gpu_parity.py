@@ -634,3 +634,38 @@ def test_walk_of_the_dedicated_tiers_end(lead, monkeypatch):
                 assert seen[0][1] > 2, seen              # (not with a walk that starts inside the transient)
     finally:
         c.close()
+
+
+def test_walk_in_pipelined_committing_batches(monkeypatch):
+    """The walk inside ydc_dispatch_device_async batches that COMMIT: the dedicated tier runs out
+    in the second of three batches of 300k requests (cfg3's registry), every batch is enqueued
+    while the one before it is still running. Three batches == the oracle on their concatenation."""
+    monkeypatch.setenv("YDC_ZONE_GUESS", "2")
+    DA = binding.DeviceArray
+    sv, tk = synth.make_config("cfg3")
+    per, nb = 300_000, 3
+    tk = {k: v[:per * nb] for k, v in tk.items()}
+    want, _, wrun = O.dispatch(sv, tk, "sorted")
+    S = len(sv["version"])
+    c = binding.Context(device=0)
+    try:
+        c.upload_servants(pack.to_abi_columns(sv))
+        cols = [[DA.from_numpy(tk[k][b * per:(b + 1) * per]) for k in ("env_id", "min_version", "requestor_ip")]
+                for b in range(nb)]
+        outs = [DA.from_numpy(np.full(per, 0xDEADBEEF, np.uint32)) for _ in range(nb)]
+        runs = [DA(S, np.uint32) for _ in range(nb)]
+        served = []
+        c.dispatch_device_async(*cols[0], outs[0], None, runs[0], commit=True)
+        for b in range(1, nb):
+            c.dispatch_device_async(*cols[b], outs[b], None, runs[b], commit=True)
+            c.dispatch_wait()
+            served.append(c.stats()["zone_rows"])
+        c.dispatch_wait()
+        served.append(c.stats()["zone_rows"])
+        got = np.concatenate([o.numpy() for o in outs])
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], served)
+        assert np.array_equal(runs[-1].numpy(), wrun) and np.array_equal(c.get_running(), wrun)
+        assert served[1] >= 2 and served[0] == 0 and served[2] == 0, served  # (the tier ends in the second batch)
+    finally:
+        c.close()
