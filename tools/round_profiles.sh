@@ -50,6 +50,10 @@ done
 { for a in "2000 1 1" "2000 16 16" "2000 64 16" "8000 16 16" "16000 1 1" "16000 16 16"; do
     YDC_TUNE=resident=0 timeout 120 python tools/tick_probe.py $a 200; echo; done; } > profiles/${R}_tick_phases.txt 2>&1
 timeout 120 ./tests/tools/launch_probe 2000 > profiles/${R}_launch_probe.txt 2>&1
+# the walk of the dedicated tier's end on variants of cfg3's pool; the corner of DESIGN 9.7; two queues
+timeout 600 python tools/zone_probe.py > profiles/${R}_zone_probe.txt 2>&1
+{ timeout 200 python tools/cliff_probe.py; timeout 200 python tools/cliff_probe.py probe; } > profiles/${R}_cliff_probe.txt 2>&1
+{ for m in 0 1 3; do timeout 60 ./tests/tools/overlap_probe 200 150 1954 $m; echo; done; } > profiles/${R}_overlap_probe.txt 2>&1
 # the matching kernel's phases (measurement build)
 for c in cfg2 cfg3 cfg4; do timeout 300 python tools/phase_probe.py $c 10 > profiles/${R}_${c}_match_phases.txt 2>&1; done
 [ -s gpurun_out/rccl_1rank_debug.log ] && cp gpurun_out/rccl_1rank_debug.log profiles/${R}_rccl_1rank_debug.log
