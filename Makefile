@@ -26,7 +26,7 @@ oracle:
 model:
 	$(MAKE) -s -C tests/model
 # Native (C++) drive of the dispatcher through the scheduler harness; plain g++, links libydc.so.
-native: tests/native/harness_test tools/td_native_bench tools/hbm_calib tests/tools/launch_probe tests/tools/overlap_probe
+native: tests/native/harness_test tools/td_native_bench tools/hbm_calib tests/tools/launch_probe tests/tools/overlap_probe tests/tools/atomic_probe
 	$(MAKE) -s -C tests/native all
 # Counter calibration microbenchmark (tools/calibrate.sh runs it under rocprofv3 on the GPU box).
 tools/hbm_calib: tools/hbm_calib.hip
@@ -36,6 +36,8 @@ tests/tools/launch_probe: tests/tools/launch_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tests/tools/launch_probe.hip
 tests/tools/overlap_probe: tests/tools/overlap_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tests/tools/overlap_probe.hip
+tests/tools/atomic_probe: tests/tools/atomic_probe.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tests/tools/atomic_probe.hip
 tools/td_native_bench: tools/td_native_bench.cc yadcc_amd/libydc.so $(HDRS)
 	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tools/td_native_bench.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../yadcc_amd' -lpthread

@@ -54,6 +54,7 @@ timeout 120 ./tests/tools/launch_probe 2000 > profiles/${R}_launch_probe.txt 2>&
 timeout 600 python tools/zone_probe.py > profiles/${R}_zone_probe.txt 2>&1
 { timeout 200 python tools/cliff_probe.py; timeout 200 python tools/cliff_probe.py probe; } > profiles/${R}_cliff_probe.txt 2>&1
 { for m in 0 1 3; do timeout 60 ./tests/tools/overlap_probe 200 150 1954 $m; echo; done; } > profiles/${R}_overlap_probe.txt 2>&1
+{ timeout 100 ./tests/tools/atomic_probe; timeout 100 ./tests/tools/atomic_probe 1250000; } > profiles/${R}_atomic_probe.txt 2>&1
 # the matching kernel's phases (measurement build)
 for c in cfg2 cfg3 cfg4; do timeout 300 python tools/phase_probe.py $c 10 > profiles/${R}_${c}_match_phases.txt 2>&1; done
 [ -s gpurun_out/rccl_1rank_debug.log ] && cp gpurun_out/rccl_1rank_debug.log profiles/${R}_rccl_1rank_debug.log
