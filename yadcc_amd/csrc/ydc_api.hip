@@ -239,6 +239,14 @@ struct ydc_context {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     BatchPlan plan;
+    // COMMIT without a copy node (commit_swap): the step exists twice, captured with the two
+    // running_tasks columns in either role; a tick that took effect makes its output THE column
+    // and the next tick replays the other capture. run_a / run_b: the column each one reads.
+    hipGraph_t graph_b = nullptr;
+    hipGraphExec_t exec_b = nullptr;
+    BatchPlan plan_b;
+    const uint32_t *run_a = nullptr, *run_b = nullptr;
+    bool swaps = false;
     uint64_t ticks = 0, recaptures = 0, eager_fallbacks = 0;
     bool eager_only = false;  // the registry's batches cannot be captured (> 256 classes): every tick runs eagerly
     // Passes to capture: one more than the last eager batch needed, to begin with; after 64
@@ -3764,8 +3772,10 @@ void stream_release(ydc_context* c) {
   auto& sm = c->stream_mode;
   if (sm.exec) (void)hipGraphExecDestroy(sm.exec);
   if (sm.graph) (void)hipGraphDestroy(sm.graph);
-  sm.exec = nullptr;
-  sm.graph = nullptr;
+  if (sm.exec_b) (void)hipGraphExecDestroy(sm.exec_b);
+  if (sm.graph_b) (void)hipGraphDestroy(sm.graph_b);
+  sm.exec = sm.exec_b = nullptr;
+  sm.graph = sm.graph_b = nullptr;
   if (sm.h_in) (void)hipHostFree(sm.h_in);
   if (sm.h_out) (void)hipHostFree(sm.h_out);
   sm.h_in = nullptr;
@@ -3776,12 +3786,66 @@ void stream_release(ydc_context* c) {
   sm.stale = true;
 }
 
+// One capture of the step with the columns as they are now (plan: made for them).
+int stream_capture_one(ydc_context* c, const BatchPlan& plan, bool by_swap, hipGraph_t* g_out,
+                       hipGraphExec_t* e_out) {
+  auto& sm = c->stream_mode;
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  int rc = YDC_OK;
+  auto cap = [&](hipError_t e) {
+    if (e != hipSuccess && rc == YDC_OK)
+      rc = fail(c, YDC_ERR_HIP, "capture: %s", hipGetErrorString(e));
+  };
+  const size_t T = sm.max_tasks;
+  // Round 5: no copy node. The tick's inputs are read where the host put them (k_apply_tick and
+  // the request classification read every word once), the placement is stored to the page-locked
+  // result array by k_finalize, and so is the outcome block (stream_zero_copy=0: three copies).
+  const bool zc = sm.zero_copy;
+  if (!zc) cap(hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, st));
+  if (sm.max_upd + sm.max_rel) {
+    const uint32_t upd_blocks = ceil_div(sm.max_upd, 256);
+    hipLaunchKernelGGL(k_apply_tick, dim3(upd_blocks + ceil_div(sm.max_rel, 256)), dim3(256), 0, st,
+                       zc ? sm.z_upd_idx : sm.d_upd_idx, zc ? sm.z_upd_rows : sm.d_upd_rows, sm.max_upd, upd_blocks,
+                       zc ? sm.z_rel : sm.d_rel, sm.max_rel,
+                       c->n_servants, c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p,
+                       c->d_flags.p, c->d_running.p);
+  }
+  ydc_task_soa d{zc ? sm.z_env : sm.d_env, zc ? sm.z_minv : sm.d_minv, zc ? sm.z_ip : sm.d_ip};
+  if (rc == YDC_OK) rc = enqueue_front(c, plan, &d);
+  if (rc == YDC_OK && plan.wave_path)
+    for (uint32_t r = 0; r < sm.passes; ++r) enqueue_pass(c, plan, r, 1u);
+  const bool outcome_stored = zc && c->opt_outcome_store && plan.S != 0;
+  if (rc == YDC_OK) {
+    c->finalize_outcome = outcome_stored ? c->d_h_prm : nullptr;
+    c->commit_by_swap = by_swap;
+    rc = enqueue_finalize(c, plan, YDC_DISPATCH_COMMIT, zc ? sm.z_out : c->d_out_idx.p, nullptr, nullptr,
+                          plan.wave_path ? (sm.passes - 1) & 63 : kNone);
+    c->commit_by_swap = false;
+    c->finalize_outcome = nullptr;
+  }
+  if (!zc) cap(hipMemcpyAsync(sm.h_out, c->d_out_idx.p, T * 4, hipMemcpyDeviceToHost, st));
+  if (!outcome_stored) cap(hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+  hipGraph_t g = nullptr;
+  hipError_t ee = hipStreamEndCapture(st, &g);
+  if (ee != hipSuccess) return fail(c, YDC_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
+  if (rc != YDC_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  *g_out = g;
+  HIP_TRY(c, hipGraphInstantiate(e_out, g, nullptr, nullptr, 0));
+  return YDC_OK;
+}
+
 int stream_capture(ydc_context* c) {
   auto& sm = c->stream_mode;
   if (sm.exec) (void)hipGraphExecDestroy(sm.exec);
   if (sm.graph) (void)hipGraphDestroy(sm.graph);
-  sm.exec = nullptr;
-  sm.graph = nullptr;
+  if (sm.exec_b) (void)hipGraphExecDestroy(sm.exec_b);
+  if (sm.graph_b) (void)hipGraphDestroy(sm.graph_b);
+  sm.exec = sm.exec_b = nullptr;
+  sm.graph = sm.graph_b = nullptr;
   const bool was_profiling = c->profiling;
   c->profiling = false;  // no event pairs inside a capture
   // Sizes and workspace first (allocations and table uploads cannot be captured).
@@ -3798,51 +3862,20 @@ int stream_capture(ydc_context* c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   sm.passes = sm.want_passes ? sm.want_passes : std::max(2u, std::min(c->round_hint + 1, 12u));
   sm.window_max = sm.window_ticks = 0;
-  hipStream_t st = c->stream;
-  HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-  int rc = YDC_OK;
-  auto cap = [&](hipError_t e) {
-    if (e != hipSuccess && rc == YDC_OK)
-      rc = fail(c, YDC_ERR_HIP, "capture: %s", hipGetErrorString(e));
-  };
-  const size_t T = sm.max_tasks;
-  // Round 5: no copy node. The tick's inputs are read where the host put them (k_apply_tick and
-  // the request classification read every word once), the placement is stored to the page-locked
-  // result array by k_finalize, and so is the outcome block (stream_zero_copy=0: three copies).
-  const bool zc = c->opt_stream_zero_copy;
-  sm.zero_copy = zc;
-  if (!zc) cap(hipMemcpyAsync(sm.d_in.p, sm.h_in, sm.in_bytes, hipMemcpyHostToDevice, st));
-  if (sm.max_upd + sm.max_rel) {
-    const uint32_t upd_blocks = ceil_div(sm.max_upd, 256);
-    hipLaunchKernelGGL(k_apply_tick, dim3(upd_blocks + ceil_div(sm.max_rel, 256)), dim3(256), 0, st,
-                       zc ? sm.z_upd_idx : sm.d_upd_idx, zc ? sm.z_upd_rows : sm.d_upd_rows, sm.max_upd, upd_blocks,
-                       zc ? sm.z_rel : sm.d_rel, sm.max_rel,
-                       c->n_servants, c->d_version.p, c->d_nproc.p, c->d_load.p, c->d_max_tasks.p,
-                       c->d_flags.p, c->d_running.p);
+  sm.zero_copy = c->opt_stream_zero_copy;
+  sm.swaps = c->opt_commit_swap && sm.plan.S != 0;
+  sm.run_a = c->d_running.p;
+  int rc = stream_capture_one(c, sm.plan, sm.swaps, &sm.graph, &sm.exec);
+  if (rc == YDC_OK && sm.swaps) {
+    // ... and once more with the two columns in each other's role.
+    std::swap(c->d_running, c->d_running_out);
+    sm.run_b = c->d_running.p;
+    rc = plan_batch(c, sm.max_tasks, &sm.plan_b);
+    if (rc == YDC_OK) rc = stream_capture_one(c, sm.plan_b, true, &sm.graph_b, &sm.exec_b);
+    std::swap(c->d_running, c->d_running_out);
   }
-  ydc_task_soa d{zc ? sm.z_env : sm.d_env, zc ? sm.z_minv : sm.d_minv, zc ? sm.z_ip : sm.d_ip};
-  if (rc == YDC_OK) rc = enqueue_front(c, sm.plan, &d);
-  if (rc == YDC_OK && sm.plan.wave_path)
-    for (uint32_t r = 0; r < sm.passes; ++r) enqueue_pass(c, sm.plan, r, 1u);
-  const bool outcome_stored = zc && c->opt_outcome_store && sm.plan.S != 0;
-  if (rc == YDC_OK) {
-    c->finalize_outcome = outcome_stored ? c->d_h_prm : nullptr;
-    rc = enqueue_finalize(c, sm.plan, YDC_DISPATCH_COMMIT, zc ? sm.z_out : c->d_out_idx.p, nullptr, nullptr,
-                          sm.plan.wave_path ? (sm.passes - 1) & 63 : kNone);
-    c->finalize_outcome = nullptr;
-  }
-  if (!zc) cap(hipMemcpyAsync(sm.h_out, c->d_out_idx.p, T * 4, hipMemcpyDeviceToHost, st));
-  if (!outcome_stored) cap(hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
-  hipGraph_t g = nullptr;
-  hipError_t ee = hipStreamEndCapture(st, &g);
   c->profiling = was_profiling;
-  if (ee != hipSuccess) return fail(c, YDC_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
-  if (rc != YDC_OK) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
-  }
-  sm.graph = g;
-  HIP_TRY(c, hipGraphInstantiate(&sm.exec, sm.graph, nullptr, nullptr, 0));
+  if (rc != YDC_OK) return rc;
   sm.stale = false;
   ++sm.recaptures;
   return YDC_OK;
@@ -4058,11 +4091,18 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
     if (n_tasks && out_servant_idx != sm.h_out) std::memcpy(out_servant_idx, sm.h_out, (size_t)n_tasks * 4);
     return YDC_OK;
   }
-  HIP_TRY(c, hipGraphLaunch(sm.exec, c->stream));
+  const bool second = sm.swaps && c->d_running.p == sm.run_b;
+  if (sm.swaps && !second && c->d_running.p != sm.run_a)
+    return fail(c, YDC_ERR_NOT_CONVERGED, "streaming: the running_tasks column is neither of the captured ones");
+  HIP_TRY(c, hipGraphLaunch(second ? sm.exec_b : sm.exec, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   ++sm.ticks;
-  const BatchPlan& p = sm.plan;
+  const BatchPlan& p = second ? sm.plan_b : sm.plan;
+  // (a step that took effect left the registry's running_tasks in its output column)
+  if (sm.swaps && !c->h_prm->overflow && !(p.binsort && c->h_prm->window_miss) &&
+      (!p.wave_path || c->h_prm->n_changed[(sm.passes - 1) & 63] == 0))
+    std::swap(c->d_running, c->d_running_out);
   if (c->h_prm->overflow)
     return fail(c, YDC_ERR_CAPACITY, "slot workspace overflow (bound %u)", p.slot_bound);
   uint32_t rounds = sm.passes;
