@@ -54,6 +54,11 @@ constexpr uint32_t kTickInlineRel = 64;      // released grants ...
 constexpr uint32_t kTickMaxServants = 16384;  // 512 threads x 32 servants in registers
 constexpr uint32_t kTickMaxClasses = 4096;    // eligible-class mask of a request: 64 words of LDS
 constexpr uint64_t kTickNoKey = ~0ull;
+// Which builds of k_tick carry the merge of identical requests (its lists: 32 bytes of LDS per
+// thread, a dozen registers): the 256-thread ones and, with one-word candidates, 512 x 16.
+__host__ __device__ constexpr bool tick_merges(int threads, int k, bool packed) {
+  return threads <= 256 || (threads == 512 && packed);
+}
 constexpr uint32_t kTickMergeMin = 3;  // identical requests from which a command is placed as one merge
 
 // The columns of a heartbeat that changes no structure (KeepServantAlive, task_dispatcher.cc:195-201).
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
   // of). Its class and its host are only looked at when the request signature changes: LDS.
   KeyT key[K];
   uint32_t c_run[K];
-  uint32_t* const s_ip = (uint32_t*)(s_mask + W + (THREADS <= 256 ? 4 * THREADS : 0));  // [K * THREADS], behind the merge's lists
+  uint32_t* const s_ip = (uint32_t*)(s_mask + W + (tick_merges(THREADS, K, PK) ? 4 * THREADS : 0));  // [K * THREADS], behind the merge's lists
   uint16_t* const s_cls = (uint16_t*)(s_ip + K * THREADS);                              // [K * THREADS]
   uint32_t c_nproc[COLD ? K : 1], c_load[COLD ? K : 1], c_maxt[COLD ? K : 1], c_flags[COLD ? K : 1];
   uint32_t in_cls = 0;   // bit k: servant k of this thread accepts tasks at all (max_tasks != 0)
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
     // runs an eligible free servant (`self`, :372-396) take the pick-by-pick loop below.
     // (256-thread kernels: the wider ones have no registers to spare for it)
     // (the one-word candidate does not hold the utilisation: a caller that wants it gets the loop below)
-    if (THREADS <= 256 && !p_tenv && n_tasks >= kTickMergeMin && n_tasks <= kTickBlock && !(PK && p_out_util)) {
+    if (tick_merges(THREADS, K, PK) && !p_tenv && n_tasks >= kTickMergeMin && n_tasks <= kTickBlock && !(PK && p_out_util)) {
       const bool differs = lane < n_tasks && (s_env[lane] != s_env[0] || s_minv[lane] != s_minv[0] || s_rip[lane] != s_rip[0]);
       if (__ballot(differs) == 0) {
         set_signature((uint32_t)__builtin_amdgcn_readfirstlane((int)s_env[0]),

@@ -309,9 +309,11 @@ struct ydc_context {
   // ~90 / ~165 us whatever the batch holds (profiles/r05_td_latency_*.json).
   static constexpr uint32_t kSmallBatchAuto = 0xFFFFFFFFu;
   uint32_t opt_small_batch = kSmallBatchAuto;
-  uint32_t small_batch() const {
+  // `same`: the requests are copies of one another (one RPC) and the kernel will place them as
+  // one merge (tick_merges): ~0.5 us per request at 2k servants, ~1 us at 16k.
+  uint32_t small_batch(bool same = false) const {
     if (opt_small_batch != kSmallBatchAuto) return opt_small_batch;
-    return n_servants <= 4096 ? 64u : n_servants <= 8192 ? 48u : 32u;
+    return n_servants <= 4096 || same ? 64u : n_servants <= 8192 ? 48u : 32u;
   }
   uint64_t tick_batches = 0;
   // The resident form: the kernel of a COMMITting tick stays on its CU, the registry in its
@@ -2165,8 +2167,29 @@ int fall_back_to_radix(ydc_context* c, uint32_t N, BatchPlan* p) {
 namespace {
 
 // Registries and batches the one-workgroup kernel takes (tables must be current).
-bool tick_takes(const ydc_context* c, uint32_t n_tasks) {
-  return n_tasks <= c->small_batch() && c->small_batch() && c->n_servants <= kTickMaxServants &&
+// The one-word candidate where the integer key and a registry index share 32 bits (capacities
+// below 2^10 and a registry that leaves room: every realistic pool); the reference's double as
+// the key otherwise (packed_tick=0: always).
+bool tick_packed(const ydc_context* c, uint32_t* idx_bits_out = nullptr) {
+  uint32_t idx_bits = 1;
+  while ((1u << idx_bits) < std::max(c->n_servants, 2u)) ++idx_bits;
+  if (idx_bits_out) *idx_bits_out = idx_bits;
+  return c->opt_tick_packed && c->tables.cap_bits <= 10 && 2 * c->tables.cap_bits + 1 + idx_bits <= 32;
+}
+
+// Host request columns that are copies of their first entry (what one RPC sends).
+bool tick_same_requests(const ydc_task_soa* tk, uint32_t n) {
+  if (!tk || n < 2 || n > kTickBlock) return false;
+  const uint32_t *e = (const uint32_t*)tk->env_id, *m = (const uint32_t*)tk->min_version,
+                 *r = (const uint32_t*)tk->requestor_ip;
+  for (uint32_t i = 1; i < n; ++i)
+    if (e[i] != e[0] || m[i] != m[0] || r[i] != r[0]) return false;
+  return true;
+}
+
+bool tick_takes(const ydc_context* c, uint32_t n_tasks, bool same = false) {
+  same = same && tick_packed(c);  // (the wide builds of the kernel merge with one-word candidates only)
+  return n_tasks <= c->small_batch(same) && c->small_batch() && c->n_servants <= kTickMaxServants &&
          c->tables.n_classes() <= kTickMaxClasses && c->h_alias_ip.empty() && c->group.n_ranks == 0 &&
          !c->stream_mode.active && c->pend_count == 0 && !c->debug_sim && !c->debug_verify_binsort;
 }
@@ -2503,24 +2526,21 @@ int tick_run(ydc_context* c, const TickCall& io) {
   // (tick_kernel.h): 256 threads up to 4096 servants, 512 beyond (32 per thread above 8192).
   // LDS: the eligible-class mask, the candidate lists of the merge (256-thread kernels, 32 B per
   // thread), the servants' hosts and classes (6 B per servant slot).
-  auto launch = [&](auto kernel, uint32_t threads, uint32_t k) -> int {
-    const size_t lds = (size_t)W * 8 + (threads <= 256 ? (size_t)32 * threads : 0) + (size_t)6 * threads * k;
+  auto launch = [&](auto kernel, uint32_t threads, uint32_t k, bool pk) -> int {
+    const size_t lds = (size_t)W * 8 + (tick_merges((int)threads, (int)k, pk) ? (size_t)32 * threads : 0) +
+                       (size_t)6 * threads * k;
     if (lds > 48 * 1024)
       HIP_TRY(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     YDC_LAUNCH(c, "k_tick", kernel, dim3(1), dim3(threads), lds, launch_stream, a);
     return YDC_OK;
   };
-  // The one-word candidate where the integer key and a registry index share 32 bits (capacities
-  // below 2^10 and a registry that leaves room: every realistic pool); the reference's double as
-  // the key otherwise (packed_tick=0: always).
   uint32_t idx_bits = 1;
-  while ((1u << idx_bits) < std::max(S, 2u)) ++idx_bits;
-  const bool packed = c->opt_tick_packed && c->tables.cap_bits <= 10 && 2 * c->tables.cap_bits + 1 + idx_bits <= 32;
+  const bool packed = tick_packed(c, &idx_bits);
   a.cap_bits = c->tables.cap_bits;
   a.idx_bits = idx_bits;
   int lrc;
 #define YDC_TICK_LAUNCH(T, KK, COLD) \
-  lrc = packed ? launch(k_tick<T, KK, COLD, true>, T, KK) : launch(k_tick<T, KK, COLD, false>, T, KK)
+  lrc = packed ? launch(k_tick<T, KK, COLD, true>, T, KK, true) : launch(k_tick<T, KK, COLD, false>, T, KK, false)
   if (per_thread <= 1) YDC_TICK_LAUNCH(256, 1, true);
   else if (per_thread <= 2) YDC_TICK_LAUNCH(256, 2, true);
   else if (per_thread <= 4) YDC_TICK_LAUNCH(256, 4, true);
@@ -2773,7 +2793,8 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
                  uint32_t* out_idx, double* out_util, uint32_t* out_running) {
   if (!c || (N && (!tk || !out_idx))) return YDC_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (N && N <= c->small_batch()) {
+  const bool same = N <= kTickBlock && tick_same_requests(tk, N);
+  if (N && N <= c->small_batch(same)) {
     // A handful of requests: one launch of the one-workgroup kernel, the requests as kernel
     // arguments, the results stored to page-locked memory (tick_kernel.h).
     if (c->max_tasks && N > c->max_tasks)
@@ -2781,7 +2802,7 @@ int ydc_dispatch(ydc_context* c, const ydc_task_soa* tk, uint32_t N, uint32_t fl
     if (c->pend_count) return fail(c, YDC_ERR_INVALID_ARGUMENT, "pipelined batches outstanding: ydc_dispatch_wait first");
     if (c->tables_dirty)
       if (int rc = rebuild_tables(c)) return rc;
-    if (tick_takes(c, N)) {
+    if (tick_takes(c, N, same)) {
       TickCall io;
       io.tasks = tk;
       io.n_tasks = N;
@@ -2894,7 +2915,8 @@ int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant
     if (int rc = rebuild_tables(c)) return rc;
   // (registry deltas ride in the launch only with COMMIT: running_tasks goes back once, into the
   // column the picks work on)
-  const bool fast = !structural && tick_takes(c, n_tasks) &&
+  const bool same = tick_same_requests(tasks, n_tasks);
+  const bool fast = !structural && tick_takes(c, n_tasks, same) &&
                     ((flags & YDC_DISPATCH_COMMIT) || (!n_upd && !n_rel));
   if (!fast) {
     if (n_upd)
@@ -2902,7 +2924,7 @@ int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant
     n_upd = 0;
     if (c->tables_dirty)
       if (int rc = rebuild_tables(c)) return rc;
-    if (!tick_takes(c, n_tasks) || (n_rel && !(flags & YDC_DISPATCH_COMMIT))) {
+    if (!tick_takes(c, n_tasks, same) || (n_rel && !(flags & YDC_DISPATCH_COMMIT))) {
       if (n_rel)
         if (int rc = ydc_release_slots(c, release_servant_idx, n_rel)) return rc;
       if (!n_tasks) return YDC_OK;
