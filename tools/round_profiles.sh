@@ -38,6 +38,7 @@ for c in driver_line cfg2 cfg2_sync cfg3 cfg4 cfg5 gpus2_one_device; do
     echo "no bench line for $c" >&2; tail -3 $F/bench_$c.err >&2
   fi
 done
+[ -s profiles/${R}_bench_driver_line.json ] && python tools/latency_table.py profiles/${R}_bench_driver_line.json > profiles/${R}_td_latency_table.txt
 # the TaskDispatcher surface, natively
 { for a in "wait 2000 10000 50" "wait 2000 100000 20" "heartbeat 16000 1000000 3" "heartbeat 2000 100000 5" \
            "latency 2000 1000" "latency 8000 1000" "latency 16000 1000"; do

@@ -306,7 +306,7 @@ struct ydc_context {
   uint32_t tick_seq = 0;
   // Batches up to this many requests take it (small_batch=0: none does). kSmallBatchAuto: by
   // registry size — a pick costs ~1 us at 2k servants and ~4 us at 16k, the batch pipeline
-  // ~90 / ~165 us whatever the batch holds (profiles/r05_td_latency_*.json).
+  // ~90 / ~165 us whatever the batch holds (profiles/r05_td_latency_table.txt).
   static constexpr uint32_t kSmallBatchAuto = 0xFFFFFFFFu;
   uint32_t opt_small_batch = kSmallBatchAuto;
   // `same`: the requests are copies of one another (one RPC) and the kernel will place them as
