@@ -669,3 +669,46 @@ def test_walk_in_pipelined_committing_batches(monkeypatch):
         assert served[1] >= 2 and served[0] == 0 and served[2] == 0, served  # (the tier ends in the second batch)
     finally:
         c.close()
+
+
+def test_walk_on_random_pools(monkeypatch):
+    """The walk of the tier's end (zone_guess.h) forced on (YDC_ZONE_GUESS=2, radix pipeline) over
+    random pools of 4 digests: batches that end before the dedicated tier does, reach just past it,
+    or start with it exhausted; hosts with several servants, oversubscription, initial load,
+    committed halves. Every placement, utilisation and running_tasks column equal to the oracle's."""
+    monkeypatch.setenv("YDC_ZONE_GUESS", "2")
+    monkeypatch.setenv("YDC_BINSORT", "0")
+    walked = 0
+    for seed in range(300, 324):
+        rng = np.random.default_rng(seed)
+        kw = dict(seed=seed, n_tasks=int(rng.choice([40_000, 70_000, 130_000, 220_000])),
+                  n_servants=int(rng.choice([600, 1500, 4000])), n_envs=4,
+                  self_frac=float(rng.choice([0.0, 0.1, 0.4])), unknown_env_frac=float(rng.choice([0.0, 0.01])),
+                  min_version_20_frac=float(rng.choice([0.0, 0.5])))
+        if rng.random() < 0.3:
+            kw["oversubscribed"] = True
+        if rng.random() < 0.3:
+            kw["shared_ip_frac"] = 0.2
+        if rng.random() < 0.4:
+            kw["initial_running"] = True
+        monkeypatch.setenv("YDC_CHUNK_SIZE", str(int(rng.choice([64, 128, 512]))))
+        sv, tk = cases.random_case(**kw)
+        n = len(tk["env_id"])
+        want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+        c = binding.Context(device=0)
+        try:
+            c.upload_servants(pack.to_abi_columns(sv))
+            if rng.random() < 0.4:
+                cut = int(rng.integers(1, n))
+                a, ua, _ = c.dispatch({k: v[:cut] for k, v in tk.items()}, commit=True)
+                walked += c.stats()["zone_rows"] >= 2
+                b, ub, grun = c.dispatch({k: v[cut:] for k, v in tk.items()}, commit=True)
+                got, gutil = np.concatenate([a, b]), np.concatenate([ua, ub])
+            else:
+                got, gutil, grun = c.dispatch(tk)
+            st = c.stats()
+            walked += st["zone_rows"] >= 2
+        finally:
+            c.close()
+        assert np.array_equal(got, want) and np.array_equal(grun, wrun) and np.array_equal(gutil, wutil), (kw, st)
+    assert walked >= 4, walked  # (the shapes are drawn so that the tier ends inside a good part of the batches)
