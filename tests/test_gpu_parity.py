@@ -712,3 +712,32 @@ def test_walk_on_random_pools(monkeypatch):
             c.close()
         assert np.array_equal(got, want) and np.array_equal(grun, wrun) and np.array_equal(gutil, wutil), (kw, st)
     assert walked >= 4, walked  # (the shapes are drawn so that the tier ends inside a good part of the batches)
+
+
+@pytest.mark.parametrize("counted", ["1", "0"])
+def test_long_release_lists(counted, monkeypatch):
+    """FreeTask for a whole batch's grants at once (ydc_release_slots / _device): long lists are
+    counted per servant in LDS first and go out as one atomic per servant (release_counted=0: an
+    atomic per slot). COMMIT + release restores the registry; a second batch places like the first."""
+    monkeypatch.setenv("YDC_RELEASE_COUNTED", counted)
+    DA = binding.DeviceArray
+    for cfg, n_srv in (("cfg2", None), ("cfg3", 14_000)):
+        sv, tk = synth.make_config(cfg, n_tasks=150_000, n_servants=n_srv)
+        c = binding.Context(device=0)
+        try:
+            c.upload_servants(pack.to_abi_columns(sv))
+            before = c.get_running().copy()
+            d = [DA.from_numpy(tk[k]) for k in ("env_id", "min_version", "requestor_ip")]
+            out = DA(len(tk["env_id"]), np.uint32)
+            c.dispatch_device(d[0], d[1], d[2], out, commit=True)
+            first = out.numpy().copy()
+            granted = first[first < binding.IDX_ENV_NOT_FOUND]
+            assert np.array_equal(c.get_running() - before, np.bincount(granted, minlength=len(before)))
+            c.release_slots_device(out)      # (entries that are no servant index are skipped)
+            assert np.array_equal(c.get_running(), before)
+            c.dispatch_device(d[0], d[1], d[2], out, commit=True)
+            assert np.array_equal(out.numpy(), first)
+            c.release_slots(granted)         # the same list from the host
+            assert np.array_equal(c.get_running(), before)
+        finally:
+            c.close()

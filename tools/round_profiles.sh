@@ -51,6 +51,7 @@ done
 { for a in "2000 1 1" "2000 16 16" "2000 64 16" "8000 16 16" "16000 1 1" "16000 16 16"; do
     YDC_TUNE=resident=0 timeout 120 python tools/tick_probe.py $a 200; echo; done; } > profiles/${R}_tick_phases.txt 2>&1
 timeout 120 ./tests/tools/launch_probe 2000 > profiles/${R}_launch_probe.txt 2>&1
+timeout 300 python tools/commit_loop.py 300 > profiles/${R}_commit_loop.txt 2>&1
 # the walk of the dedicated tier's end on variants of cfg3's pool; the corner of DESIGN 9.7; two queues
 timeout 600 python tools/zone_probe.py > profiles/${R}_zone_probe.txt 2>&1
 { timeout 200 python tools/cliff_probe.py; timeout 200 python tools/cliff_probe.py probe; } > profiles/${R}_cliff_probe.txt 2>&1

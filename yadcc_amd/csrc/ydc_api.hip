@@ -264,6 +264,7 @@ struct ydc_context {
   // caller reads d_prm back with a copy) — kernels.h: RunningArgs::host_outcome.
   DeviceParams* finalize_outcome = nullptr;
   bool opt_outcome_store = true;  // (outcome_store=0: always the copy)
+  bool opt_release_counted = true;  // long release lists counted in LDS first (release_counted=0: an atomic per slot)
   bool opt_stream_zero_copy = true;  // streaming: the captured step reads / writes the page-locked arenas in place
 
   // Staging for the host-pointer entry point (ydc_dispatch): the three request columns in
@@ -821,6 +822,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("commit_swap")) c->opt_commit_swap = atoi(s) != 0;
   if (const char* s = tune_value("outcome_store")) c->opt_outcome_store = atoi(s) != 0;
   if (const char* s = tune_value("stream_zero_copy")) c->opt_stream_zero_copy = atoi(s) != 0;
+  if (const char* s = tune_value("release_counted")) c->opt_release_counted = atoi(s) != 0;
   if (const char* s = tune_value("walk_after")) c->opt_walk_after = (uint32_t)std::max(2, atoi(s));
   if (const char* s = tune_value("rounds_per_check"))
     c->opt_rounds_per_check = std::max(1, atoi(s));
@@ -1102,6 +1104,20 @@ int ydc_remove_servants(ydc_context* c, const uint32_t* idx, uint32_t n) {
   return rebuild_tables(c);  // classes, the ip table and the slot bound follow the registry
 }
 
+// FreeTask's --running_tasks for a list of grants (servant indexes on the device).
+static void launch_release(ydc_context* c, const uint32_t* d_idx, uint32_t n) {
+  if (n >= 4096 && c->n_servants <= 16384 && c->opt_release_counted) {
+    if ((size_t)c->n_servants * 4 > 48 * 1024)  // (above 48 KB of dynamic LDS the runtime wants to be told)
+      (void)hipFuncSetAttribute((const void*)k_release_slots_counted, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)c->n_servants * 4));
+    hipLaunchKernelGGL(k_release_slots_counted, dim3(ceil_div(n, kReleaseTile)), dim3(1024),
+                       (size_t)c->n_servants * 4, c->stream, d_idx, n, c->n_servants, c->d_running.p);
+  } else {
+    hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, d_idx, n,
+                       c->n_servants, c->d_running.p);
+  }
+}
+
 int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
   if (!c || (n && !servant_idx)) return YDC_ERR_INVALID_ARGUMENT;
   if (!n) return YDC_OK;
@@ -1123,8 +1139,7 @@ int ydc_release_slots(ydc_context* c, const uint32_t* servant_idx, uint32_t n) {
   std::memcpy(c->h_rel, servant_idx, (size_t)n * 4);
   HIP_TRY(c, hipMemcpyAsync(c->d_upd_idx.p, c->h_rel, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->h_rel_ev, c->stream));
-  hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream,
-                     c->d_upd_idx.p, n, c->n_servants, c->d_running.p);
+  launch_release(c, c->d_upd_idx.p, n);
   HIP_TRY(c, hipGetLastError());
   return YDC_OK;
 }
@@ -1134,8 +1149,7 @@ int ydc_release_slots_device(ydc_context* c, const uint32_t* d_servant_idx, uint
   if (!n) return YDC_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   resident_stop(c);  // (the registry leaves the resident kernel's registers)
-  hipLaunchKernelGGL(k_release_slots, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, d_servant_idx, n,
-                     c->n_servants, c->d_running.p);
+  launch_release(c, d_servant_idx, n);
   HIP_TRY(c, hipGetLastError());
   return YDC_OK;
 }
