@@ -313,6 +313,16 @@ def td_surface(with_reference=True):
             except Exception as e:  # noqa: BLE001
                 rec["reference"] = {"error": str(e)}
         out["latency"]["servants_%d" % S] = rec
+    # Many RPC handlers at once: 1 .. 32 caller threads, each a loop of one WaitForStartingNewTask +
+    # FreeTask from its own requestor address. Whoever holds the dispatcher's lock places everything
+    # that is queued in one device turn; the others spin for their answer. (The reference serialises
+    # its callers on one lock around an 18 us scan: <= 5.5e4 calls/s whatever the thread count.)
+    try:
+        r = subprocess.run([tool, "concurrent", "2000", "2000"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+        out["concurrent_callers_2k_servants"] = json.loads(r.stdout.strip().splitlines()[-1])["threads"] if r.returncode == 0 else {
+            "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+    except Exception as e:  # noqa: BLE001
+        out["concurrent_callers_2k_servants"] = {"error": str(e)}
     if with_reference:
         try:
             out["reference"] = reference_td_surface()

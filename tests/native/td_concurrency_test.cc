@@ -111,6 +111,44 @@ static void CompletedByOthers() {
   for (auto& r : rs) CHECK(!r.ok && r.status == WaitStatus::Timeout);
 }
 
+// A pool that is always full: eight threads take turns on two slots, every grant freed at once.
+// Six of them are parked (asleep on the condition variable, or about to be) at any time, and every
+// FreeTask — queued behind a device turn of somebody else's, or applied by the caller itself —
+// must wake them (gpu_task_dispatcher.h: free_queue_, sleepers_): with no timer thread around, a
+// lost wake-up would sleep until its deadline.
+static void FullPoolChurn() {
+  GpuTaskDispatcher::Options opt;
+  opt.start_expiration_timer = false;
+  GpuTaskDispatcher td(opt);
+  td.KeepServantAlive(Servant("10.0.0.1:1", 2, "d"), 60s);
+  const int kThreads = 8, kRounds = 150;
+  std::atomic<int> granted{0}, timeouts{0};
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> ts;
+  for (int t = 0; t < kThreads; ++t)
+    ts.emplace_back([&, t] {
+      TaskPersonality p{"9.9.9." + std::to_string(t), 0, "d"};
+      for (int r = 0; r < kRounds; ++r) {
+        auto g = td.WaitForStartingNewTask(p, 60s, td.Now() + 10s, false);
+        if (!g.ok) {
+          ++timeouts;
+          continue;
+        }
+        ++granted;
+        if (r & 1) std::this_thread::yield();
+        td.FreeTask(g->task_id);
+      }
+    });
+  for (auto& t : ts) t.join();
+  CHECK(timeouts == 0);
+  CHECK(granted == kThreads * kRounds);
+  CHECK(std::chrono::steady_clock::now() - t0 < 30s);
+  auto a = td.WaitForStartingNewTask(TaskPersonality{"9.9.9.9", 0, "d"}, 60s, td.Now(), false);
+  auto b = td.WaitForStartingNewTask(TaskPersonality{"9.9.9.9", 0, "d"}, 60s, td.Now(), false);
+  auto c = td.WaitForStartingNewTask(TaskPersonality{"9.9.9.9", 0, "d"}, 60s, td.Now(), false);
+  CHECK(a.ok && b.ok && !c.ok);  // (the books balance: exactly the two slots are free again)
+}
+
 static void Storm() {
   GpuTaskDispatcher::Options opt;
   opt.start_expiration_timer = true;  // the dispatcher's own 1 s timer thread runs too
@@ -221,6 +259,7 @@ int main() {
   NullDigestAndLeasePages();
   WakeOrder();
   CompletedByOthers();
+  FullPoolChurn();
   Storm();
   std::printf("TD-CONCURRENCY-OK\n");
   return 0;

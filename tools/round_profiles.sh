@@ -43,6 +43,7 @@ done
 { for a in "wait 2000 10000 50" "wait 2000 100000 20" "heartbeat 16000 1000000 3" "heartbeat 2000 100000 5" \
            "latency 2000 1000" "latency 8000 1000" "latency 16000 1000"; do
     echo "== td_native_bench $a"; timeout 300 ./tools/td_native_bench $a; done
+  for a in "concurrent 2000 3000" "concurrent 16000 3000"; do echo "== td_native_bench $a"; timeout 300 ./tools/td_native_bench $a; done
   echo "== td_native_bench latency 2000 1000 (YDC_TUNE=resident=0: one launch per call)"
   YDC_TUNE=resident=0 timeout 300 ./tools/td_native_bench latency 2000 500
   echo "== td_native_bench latency 2000 1000 (YDC_TUNE=packed_tick=0: the reference's double as the key)"

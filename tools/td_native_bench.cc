@@ -20,6 +20,11 @@
 //       batches of 2 / 16 / 256 through ydc_td_wait_for_starting_new_tasks, registry warm, the
 //       grants freed between two calls (so the release reaches the device inside the next call),
 //       a servant's heartbeat with a new load figure before every fourth call.
+//   td_native_bench concurrent <servants> <calls per thread>
+//       1, 2, 4, 8, 16 and 32 caller threads (RPC handlers), each a loop of one
+//       WaitForStartingNewTask + FreeTask from its own requestor address: calls/s of all threads
+//       together and p50 / p99 per call. Callers that arrive while a batch is being placed are
+//       placed together by whoever gets the lock next (gpu_task_dispatcher.cc: the queue).
 // Links libydc.so (GPU) or tests/native/libtd_stub.so (CPU model of the device API: host-side
 // profiling without a GPU). Prints one JSON object.
 #include <algorithm>
@@ -28,7 +33,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "yadcc_dispatch.h"
@@ -358,6 +365,82 @@ static int LatencyMode(int n_servants, int samples) {
   return 0;
 }
 
+static int ConcurrentMode(int n_servants, int calls) {
+  ydc_td* td = Create();
+  std::mt19937_64 rng(3);
+  std::vector<ydc_td_servant> sv;
+  std::vector<std::string> locations;
+  std::vector<std::vector<const char*>> envs;
+  Register(td, n_servants, rng, 1, &sv, &locations, &envs);
+  std::printf("{\"mode\": \"concurrent\", \"servants\": %d, \"calls_per_thread\": %d, \"threads\": {", n_servants, calls);
+  bool first = true;
+  for (int T : {1, 2, 4, 8, 16, 32}) {
+    ydc_td_stats st0{}, st1{};
+    ydc_td_host_stats(td, &st0);
+    std::vector<std::vector<double>> lat(T);
+    std::vector<double> free_us(T, 0.0);
+    std::atomic<int> ready{0}, failed{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const std::string ip = "172.20." + std::to_string(t) + ".7";
+        char loc[32];
+        std::uint64_t id = 0;
+        lat[t].reserve(calls);
+        for (int r = -50; r < calls; ++r) {
+          if (r == 0) {  // (the timed part starts when every thread has made its first calls)
+            ++ready;
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+          }
+          auto t0 = Clk::now();
+          const int rc = ydc_td_wait_for_starting_new_task(td, ip.c_str(), 20, g_env_ptrs[(unsigned)(r + t) % 4],
+                                                           15ll * 1000000000ll, 0, 0, &id, loc, sizeof loc);
+          auto t1 = Clk::now();
+          if (rc < 0) {
+            ++failed;
+            return;
+          }
+          if (rc == YDC_TD_GRANTED) ydc_td_free_task(td, id);
+          auto t2 = Clk::now();
+          if (r >= 0) {
+            lat[t].push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+            free_us[t] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+          }
+        }
+      });
+    while (ready.load() < T) std::this_thread::yield();
+    auto w0 = Clk::now();
+    go.store(true, std::memory_order_release);
+    for (auto& x : th) x.join();
+    auto w1 = Clk::now();
+    if (failed.load()) {
+      std::fprintf(stderr, "device error in a caller thread\n");
+      return 1;
+    }
+    std::vector<double> all;
+    for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+    double p50, p99, mean;
+    Percentiles(all, &p50, &p99, &mean);
+    double free_sum = 0;
+    for (double v : free_us) free_sum += v;
+    ydc_td_host_stats(td, &st1);
+    const double per_batch = (double)(st1.requests - st0.requests) / std::max<std::uint64_t>(1, st1.batches - st0.batches);
+    const double dev_us = (double)(st1.device_ns - st0.device_ns) / 1e3 / std::max<std::uint64_t>(1, st1.batches - st0.batches);
+    const double host_us = (double)(st1.host_ns - st0.host_ns) / 1e3 / std::max<std::uint64_t>(1, st1.batches - st0.batches);
+    const double turns_per_s = (double)(st1.batches - st0.batches) / Secs(w0, w1);
+    std::printf("%s\"%d\": {\"calls_per_s\": %.0f, \"p50_us\": %.2f, \"p99_us\": %.2f, \"mean_us\": %.2f, "
+                "\"free_task_mean_us\": %.2f, \"requests_per_device_turn\": %.2f, \"device_us_per_turn\": %.2f, "
+                "\"host_us_per_turn\": %.2f, \"us_between_turn_starts\": %.2f}",
+                first ? "" : ", ", T, (double)T * calls / Secs(w0, w1), p50, p99, mean, free_sum / all.size(),
+                per_batch, dev_us, host_us, 1e6 / turns_per_s);
+    first = false;
+  }
+  std::printf("}}\n");
+  ydc_td_destroy(td);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   for (int i = 0; i < 4; ++i) {
     char b[80];
@@ -374,6 +457,8 @@ int main(int argc, char** argv) {
                          argc > 4 ? std::atoi(argv[4]) : 3);
   if (mode == "latency")
     return LatencyMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 1000);
-  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat|latency ...\n");
+  if (mode == "concurrent")
+    return ConcurrentMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 2000);
+  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat|latency|concurrent ...\n");
   return 2;
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a small-batch launch (k_tick, yadcc_amd/csrc/tick_kernel.h) spends its time: phase stamps
 of the measurement build (`make probe` -> yadcc_amd/libydc_probe.so), thread 0's 100 MHz wall clock.
-usage: python tools/tick_probe.py [servants] [requests] [releases] [reps]"""
+usage: python tools/tick_probe.py [servants] [requests] [releases] [reps] [distinct]"""
 import ctypes as C
 import os
 import sys
@@ -30,8 +30,10 @@ def main():
     ctx = binding.Context(device=0)
     ctx.upload_servants(pack.to_abi_columns(sv))
     tk = synth.make_tasks(n, sv, n_envs=4, seed=5, self_frac=0.0)
-    for k in tk:  # one RPC: one signature
-        tk[k][:] = tk[k][0]
+    distinct = len(sys.argv) > 5 and sys.argv[5] == "distinct"  # (default: one RPC, one signature)
+    if not distinct:
+        for k in tk:
+            tk[k][:] = tk[k][0]
     acc, wall = [], []
     held = []
     for r in range(reps + 20):
@@ -50,8 +52,8 @@ def main():
             wall.append((t1 - t0) * 1e6)
     T = np.stack(acc)
     assert ctx.stats()["small_batch"] == 1
-    print("k_tick on %d servants, %d requests of one signature, %d released grants per call; %d calls; "
-          "microseconds after the kernel's entry (p50)" % (S, n, n_rel, reps))
+    print("k_tick on %d servants, %d requests of %s, %d released grants per call; %d calls; "
+          "microseconds after the kernel's entry (p50)" % (S, n, "their own signatures" if distinct else "one signature", n_rel, reps))
     rel = (T - T[:, :1]) / 100.0
     order = [0, 1, 2, 3, 4] + ([5] + list(range(8, 8 + min(n, 16))) if not T[:, 27].any() else []) + [6, 7]
     prev = 0.0

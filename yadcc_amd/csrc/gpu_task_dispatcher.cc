@@ -350,7 +350,7 @@ void GpuTaskDispatcher::TimerLoop() {
 }
 
 GpuTaskDispatcher::HostStats GpuTaskDispatcher::host_stats() const {
-  std::scoped_lock _(allocation_lock_);
+  Section sec(const_cast<GpuTaskDispatcher*>(this));
   HostStats s = host_stats_;
   s.bookkeeper_rebuilds = running_task_bookkeeper_.rebuilds();
   s.lease_pages = tasks_.pages();
@@ -458,7 +458,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantPersonality& servant,
 }
 
 void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono::nanoseconds expires_in) {
-  std::scoped_lock _(allocation_lock_);
+  Section sec(this);
   auto now = Now();
   ++host_stats_.heartbeats;
   auto assign_scalars = [&](ServantPersonality& p) {
@@ -559,7 +559,7 @@ std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(std::str
                                                                         const RunningTaskView* tasks,
                                                                         std::size_t n) {
   std::vector<std::uint64_t> unknown_tasks;
-  std::scoped_lock _(allocation_lock_);
+  Section sec(this);
   const std::uint32_t* known = index_of_location_.find(servant_location);
   if (!known) {  // :241-243: the servant itself has expired — every reported id comes back
     unknown_tasks.reserve(n);
@@ -595,7 +595,7 @@ std::vector<RunningTask> GpuTaskDispatcher::GetRunningTasks() const {
 // Leases
 // ---------------------------------------------------------------------------
 bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanoseconds new_expires_in) {
-  std::scoped_lock _(allocation_lock_);
+  Section sec(this);
   Task* t = tasks_.find(task_id);
   if (!t) return false;        // :146-153
   if (t->zombie) return false;  // :154-162
@@ -603,15 +603,47 @@ bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanose
   return true;
 }
 
-void GpuTaskDispatcher::FreeTask(std::uint64_t task_id) {
-  std::scoped_lock _(allocation_lock_);
-  UnsafeFreeTasks(&task_id, 1);
+void GpuTaskDispatcher::LockBriefly(std::unique_lock<std::mutex>& lk) {
+  for (int spins = 0; spins < 4000; ++spins) {
+    if (lk.try_lock()) return;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  lk.lock();
 }
 
-void GpuTaskDispatcher::FreeTasks(const std::uint64_t* task_ids, std::size_t n) {
-  std::scoped_lock _(allocation_lock_);
+bool GpuTaskDispatcher::UnsafeApplyQueuedFrees() {
+  if (free_queued_.load(std::memory_order_seq_cst) == 0) return false;
+  std::vector<std::uint64_t> ids;
+  {
+    std::scoped_lock _(queue_lock_);
+    ids.swap(free_queue_);
+    free_queued_.store(0, std::memory_order_seq_cst);
+  }
   // (n calls, not one call with n ids: an unknown id ends a call, not the others — :176-180)
-  for (std::size_t i = 0; i != n; ++i) UnsafeFreeTasks(task_ids + i, 1);
+  for (std::uint64_t id : ids) UnsafeFreeTasks(&id, 1);
+  return !ids.empty();
+}
+
+void GpuTaskDispatcher::FreeTask(std::uint64_t task_id) { FreeTasks(&task_id, 1); }
+
+void GpuTaskDispatcher::FreeTasks(const std::uint64_t* task_ids, std::size_t n) {
+  if (n == 0) return;
+  {
+    std::scoped_lock _(queue_lock_);
+    free_queue_.insert(free_queue_.end(), task_ids, task_ids + n);
+    free_queued_.fetch_add((std::uint32_t)n, std::memory_order_seq_cst);
+  }
+  std::unique_lock lk(allocation_lock_, std::try_to_lock);
+  if (!lk.owns_lock()) {
+    // Somebody is in the middle of a device turn: it applies the ids when it is done (Section).
+    // Unless threads sleep on the condition variable — they hold no lock, and the wake-up
+    // (:187) is theirs.
+    if (sleepers_.load(std::memory_order_seq_cst) == 0) return;
+    lk.lock();
+  }
+  Section sec(this, std::move(lk));
 }
 
 void GpuTaskDispatcher::UnsafeFreeTasks(const std::uint64_t* task_ids, std::size_t n) {
@@ -655,7 +687,7 @@ void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant, const RunningTask
 
 void GpuTaskDispatcher::OnExpirationTimer() {
   auto now = Now();
-  std::scoped_lock _(allocation_lock_);
+  Section sec(this);
 
   // Expired servants leave the registry; the order of the others is kept
   // because it decides ties (:503-516).
@@ -1013,6 +1045,7 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
     std::scoped_lock _(queue_lock_);
     waiting_.insert(waiting_.end(), queue_.begin(), queue_.end());
     queue_.clear();
+    queued_.store(0, std::memory_order_relaxed);
   }
   // One device batch, arrival order. A parked request is only retried after FreeTask has
   // woken the waiters (wake_epoch_): in the reference a waiter sleeps until notify_all or
@@ -1022,10 +1055,15 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
     if (!r->done && r->tried_epoch != wake_epoch_) batch.push_back(r);
   UnsafeDispatch(batch);
   const std::size_t before = waiting_.size();
+  // (`batch` is reused for the served ones: after its `published` flag is up a record may be gone)
+  batch.clear();
+  for (auto* r : waiting_)
+    if (r->done) batch.push_back(r);
   waiting_.erase(std::remove_if(waiting_.begin(), waiting_.end(), [](Pending* r) { return r->done; }),
                  waiting_.end());
+  for (auto* r : batch) r->published.store(true, std::memory_order_release);
   // Requests of other threads may just have been completed by this one: wake their owners
-  // (they sleep on the condition variable until their deadline otherwise).
+  // (those that have given up spinning sleep on the condition variable until their deadline).
   if (waiting_.size() != before) allocation_cv_.notify_all();
 }
 
@@ -1041,12 +1079,41 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
     // places all of them as one batch.
     std::scoped_lock _(queue_lock_);
     queue_.push_back(&req);
+    queued_.fetch_add(1, std::memory_order_relaxed);
   }
-  std::unique_lock lk(allocation_lock_);
+  // Whoever holds allocation_lock_ next places everything that is queued, this request included:
+  // its owner spins for the answer (one device turn away) instead of sleeping on the lock, and
+  // takes the lock itself — placing everybody else's — when it is free.
+  std::unique_lock held(allocation_lock_, std::defer_lock);
+  for (int spins = 0; busy_.load(std::memory_order_relaxed) || !held.try_lock(); ++spins) {
+    if (req.published.load(std::memory_order_acquire)) return req.result;
+    if (spins >= 20000) {  // (a long batch of somebody else's, or a parked request: sleep like the reference)
+      held.lock();
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  Section sec(this, std::move(held));
+  std::unique_lock<std::mutex>& lk = sec.lock();
   for (;;) {
-    UnsafeDrainQueue();
+    if (!req.done) {
+      UnsafeDrainQueue();
+      // Requests that came in during that turn are placed before the lock changes hands (a new
+      // holder would do the same a hand-over later) — a few turns, then this caller goes home.
+      for (int extra = 0; extra < 3 && queued_.load(std::memory_order_relaxed) != 0; ++extra) UnsafeDrainQueue();
+    }
     if (req.done) return req.result;
+    // About to sleep: say so first, then look for queued FreeTasks once more — a FreeTask that
+    // comes later sees the sleeper and takes the lock itself (gpu_task_dispatcher.h: sleepers_).
+    sleepers_.fetch_add(1, std::memory_order_seq_cst);
+    if (UnsafeApplyQueuedFrees()) {
+      sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+      continue;  // (waiters were woken: this one tries again, :116-118)
+    }
     bool timed_out;
+    busy_.store(false, std::memory_order_relaxed);  // (the waits below release the lock)
     if (options_.clock) {
       // Injected (test) clock: poll it, do not sleep on the real one.
       timed_out = Now() >= req.deadline;
@@ -1066,6 +1133,9 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
       timed_out = allocation_cv_.wait_until(lk, req.deadline) == std::cv_status::timeout;
 #endif
     }
+    busy_.store(true, std::memory_order_relaxed);
+    sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+    UnsafeApplyQueuedFrees();
     if (req.done) return req.result;  // a concurrent drain served us meanwhile
     if (timed_out) {
       waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), &req), waiting_.end());
@@ -1117,7 +1187,7 @@ int GpuTaskDispatcher::WaitForStartingNewTasksInto(std::size_t n, const RequestV
                                                    std::chrono::nanoseconds expires_in,
                                                    std::int32_t* out_status, std::uint64_t* out_task_ids,
                                                    char* out_locations, std::size_t location_stride) {
-  std::unique_lock lk(allocation_lock_);
+  Section sec(this);
   return UnsafePlaceAndGrant(n, requests, expires_in,
                              [&](std::size_t i, int status, std::uint64_t id, const Servant* pick) {
     char* loc = out_locations && location_stride ? out_locations + i * location_stride : nullptr;
@@ -1156,7 +1226,7 @@ std::vector<WaitResult> GpuTaskDispatcher::WaitForStartingNewTasks(
     views[i] = {personalities[i].requestor_ip, personalities[i].compiler_digest,
                 personalities[i].min_version, i < prefetching.size() && prefetching[i]};
   std::vector<WaitResult> out(n);
-  std::unique_lock lk(allocation_lock_);
+  Section sec(this);
   UnsafePlaceAndGrant(n, views.data(), expires_in,
                       [&](std::size_t i, int status, std::uint64_t id, const Servant* pick) {
     if (status == 0) {
@@ -1178,7 +1248,7 @@ std::vector<WaitResult> GpuTaskDispatcher::WaitForStartingNewTasks(
 // DumpInternals (task_dispatcher.cc:538-614): same keys.
 // ---------------------------------------------------------------------------
 std::string GpuTaskDispatcher::DumpInternals() {
-  std::scoped_lock _(allocation_lock_);
+  Section sec(this);
   auto format_time = [this](Clock::time_point tp) {
     // steady -> system clock, like flare::internal::SystemClockView.
     auto sys = std::chrono::system_clock::now() +

@@ -16,6 +16,7 @@
 #ifndef YADCC_AMD_GPU_TASK_DISPATCHER_H_
 #define YADCC_AMD_GPU_TASK_DISPATCHER_H_
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -334,9 +335,56 @@ class GpuTaskDispatcher {
     RequestView request;
     std::chrono::nanoseconds expires_in;
     Clock::time_point deadline;
-    bool done = false;
+    bool done = false;                   // (the thread that holds allocation_lock_)
     std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     WaitResult result;
+    // Set by the thread that placed this request for its owner, as its LAST access to the record:
+    // the owner — spinning for it instead of sleeping on the lock — may return at once.
+    std::atomic<bool> published{false};
+  };
+  // allocation_lock_ for a short critical section: a holder is a few microseconds from releasing
+  // it (one device turn), a sleep on the futex and the wake-up cost ten times that.
+  void LockBriefly(std::unique_lock<std::mutex>& lk);
+
+  // FreeTask never waits for a device turn of somebody else's: when allocation_lock_ is taken its
+  // ids are queued, and whoever holds the lock applies them — on entering its critical section
+  // and again after leaving it (Section) — in arrival order, each id a FreeTask call of its own.
+  // sleepers_: threads asleep (or about to be) on allocation_cv_ hold no lock and apply nothing;
+  // a FreeTask that finds one takes the lock itself, so that its notify_all is not lost.
+  std::vector<std::uint64_t> free_queue_;  // guarded by queue_lock_
+  std::atomic<std::uint32_t> free_queued_{0};
+  std::atomic<std::uint32_t> sleepers_{0};
+  // allocation_lock_ is held (a hint for the spinners of WaitForStartingNewTask: they read this
+  // word — shared, in their caches — and go for the lock's own cache line only when it says free).
+  std::atomic<bool> busy_{false};
+  bool UnsafeApplyQueuedFrees();  // true: something was applied (waiters were woken)
+  // allocation_lock_ held for a scope.
+  class Section {
+   public:
+    explicit Section(GpuTaskDispatcher* d, bool brief = false) : d_(d), lk_(d->allocation_lock_, std::defer_lock) {
+      if (brief) d->LockBriefly(lk_); else lk_.lock();
+      d->busy_.store(true, std::memory_order_relaxed);
+      d->UnsafeApplyQueuedFrees();
+    }
+    Section(GpuTaskDispatcher* d, std::unique_lock<std::mutex>&& held) : d_(d), lk_(std::move(held)) {
+      d->busy_.store(true, std::memory_order_relaxed);
+      d->UnsafeApplyQueuedFrees();
+    }
+    ~Section() {
+      // A FreeTask that found the lock taken has left its ids behind: nobody else may come by soon.
+      for (;;) {
+        d_->busy_.store(false, std::memory_order_relaxed);
+        lk_.unlock();
+        if (d_->free_queued_.load(std::memory_order_seq_cst) == 0) return;
+        if (!lk_.try_lock()) return;  // (the new holder applies them, on its way in or out)
+        d_->busy_.store(true, std::memory_order_relaxed);
+        d_->UnsafeApplyQueuedFrees();
+      }
+    }
+    std::unique_lock<std::mutex>& lock() { return lk_; }
+   private:
+    GpuTaskDispatcher* d_;
+    std::unique_lock<std::mutex> lk_;
   };
 
   std::size_t CapacityAvailable(const Servant& s) const;  // task_dispatcher.cc:283-313
@@ -431,8 +479,28 @@ class GpuTaskDispatcher {
   std::vector<std::uint32_t> col_digest_name_;  // NamePool id of every request's digest (known ones)
 
   // request combining
-  std::mutex queue_lock_;
+  // (held for a push or a swap of a vector: a thread that finds it taken is a few nanoseconds
+  // from getting it — a futex sleep costs ten thousand times that)
+  class SpinLock {
+   public:
+    void lock() {
+      for (;;) {
+        if (!flag_.exchange(true, std::memory_order_acquire)) return;
+        while (flag_.load(std::memory_order_relaxed)) {
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+      }
+    }
+    bool try_lock() { return !flag_.exchange(true, std::memory_order_acquire); }
+    void unlock() { flag_.store(false, std::memory_order_release); }
+   private:
+    std::atomic<bool> flag_{false};
+  };
+  SpinLock queue_lock_;
   std::deque<Pending*> queue_;
+  std::atomic<std::uint32_t> queued_{0};  // entries of queue_ (read without the lock)
   std::vector<Pending*> waiting_;  // found no free servant; arrival order
 
   RunningTaskBookkeeper running_task_bookkeeper_;
