@@ -452,8 +452,12 @@ YDC_HD ClassState class_run_state(const ClassRun& r) {
 
 // The class's smallest unconsumed slot that is NOT on the requestor's own
 // servant [self_lo, self_hi). Returns false if there is none.
+// skip_to (optional): the caller has found out by itself — a wave looking at 64 entries at a time —
+// that the head and the entries behind it up to skip_to are all the requestor's own (and that no
+// foreign holes exist): the walk below starts there.
 YDC_HD bool class_candidate(const ClassLists& L, const ClassRun& r, uint32_t self_lo,
-                            uint32_t self_hi, uint32_t& ci, uint32_t& cp, uint32_t& cg) {
+                            uint32_t self_hi, uint32_t& ci, uint32_t& cp, uint32_t& cg,
+                            uint32_t skip_to = kNone) {
   if (r.lo < r.cursor && r.hown_lo != self_lo) {
     // The smallest unconsumed slot is a hole somebody else's request may take.
     ci = r.lo;
@@ -469,6 +473,13 @@ YDC_HD bool class_candidate(const ClassLists& L, const ClassRun& r, uint32_t sel
   // One servant's class and it is the requestor's own: nothing but own slots to walk over
   // (the reference looks at servants, not slots: task_dispatcher.cc:372-380 drops `self` once).
   if (r.single && ci < r.end && cg >= self_lo && cg < self_hi) return false;
+  if (skip_to != kNone && skip_to > ci) {
+    ci = skip_to < r.end ? skip_to : r.end;
+    if (ci < r.end) {
+      cp = list_rank(L, ci);
+      cg = list_slot(L, ci);
+    }
+  }
   while (ci < r.end && cg >= self_lo && cg < self_hi) {
     ++ci;
     if (ci < r.end) {

@@ -1331,13 +1331,51 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
           };
           resolve_shared_self(mw, self_lo, &shared, state_of, self_lo, self_hi);
         }
+        // A head that is the requestor's own slot is walked over (class_candidate) — an entry per
+        // memory round trip. Registries of a few servants with tens of thousands of slots each have
+        // runs of thousands of them (a request took 830 us there): where the entry behind the head
+        // is the requestor's too, the wave looks for the end of the run together, 64 entries at a time.
+        uint32_t skip[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) skip[j] = kNone;
+        if (self_lo != kNone) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const LaneClass& q = w.k[j];
+            bool run2 = false;
+            if (((mw[j] >> lane) & 1u) && q.cursor + 1 < q.end && !q.single &&
+                !(q.lo < q.cursor && q.hown_lo != self_lo)) {
+              const uint32_t g0 = w.ring_g[w.at(lane + 64 * j, q.cursor)];
+              const uint32_t g1 = w.ring_g[w.at(lane + 64 * j, q.cursor + 1)];
+              run2 = g0 >= self_lo && g0 < self_hi && g1 >= self_lo && g1 < self_hi;
+            }
+            uint64_t todo = __ballot(run2);
+            while (todo) {
+              const uint32_t cc = (uint32_t)__builtin_ctzll(todo);
+              todo &= todo - 1;
+              const uint32_t end_c = readlane_u32(q.end, cc);
+              uint32_t pos = readlane_u32(q.cursor, cc) + 2, found = end_c;
+              while (pos < end_c) {
+                const uint32_t e = pos + lane;
+                const uint32_t g = e < end_c ? list_slot(L, e) : kNone;
+                const uint64_t other = __ballot(e >= end_c || g < self_lo || g >= self_hi);
+                if (other) {
+                  found = min(end_c, pos + (uint32_t)__builtin_ctzll(other));
+                  break;
+                }
+                pos += 64;
+              }
+              if (lane == cc) skip[j] = found;
+            }
+          }
+        }
         uint32_t bp = kNone, bi = 0;
         int bj = 0;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           if ((mw[j] >> lane) & 1u) {
             uint32_t ci, cp, cg;
-            if (class_candidate(L, w.as_run(j), self_lo, self_hi, ci, cp, cg) && cp < bp) {
+            if (class_candidate(L, w.as_run(j), self_lo, self_hi, ci, cp, cg, skip[j]) && cp < bp) {
               bp = cp;
               bi = ci;
               bj = j;
