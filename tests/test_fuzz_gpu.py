@@ -62,6 +62,34 @@ def test_no_cliff_where_every_chunk_boundary_carries_a_hole(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_runs_of_the_requestors_own_slots_one_batch(monkeypatch):
+    """... and the worst of that family from the same run (seed 700907, chunks of 4096, one digest,
+    a batch that oversubscribes the pool): 114 s per case in the tool before, 30 ms for the batch with the run search."""
+    import time
+
+    import numpy as np
+
+    from oracle import oraclebind as O
+    from tests import cases
+    from yadcc_amd import binding, pack
+    monkeypatch.setenv("YDC_CHUNK_SIZE", "4096")
+    sv, tk = cases.random_case(seed=700907, n_tasks=120000, n_servants=3, n_envs=1, self_frac=0.5,
+                               unknown_env_frac=0.01, min_version_20_frac=1.0)
+    want, wutil, wrun = O.dispatch(sv, tk, "sorted")
+    c = binding.Context(device=0)
+    try:
+        c.upload_servants(pack.to_abi_columns(sv))
+        t0 = time.perf_counter()
+        got, gutil, grun = c.dispatch(tk)
+        dt = time.perf_counter() - t0
+    finally:
+        c.close()
+    assert np.array_equal(got, want) and np.array_equal(grun, wrun) and np.array_equal(gutil, wutil)
+    assert dt < 6.0, dt
+    print("seed 700907: %.3f s" % dt)
+
+
+@pytest.mark.gpu
 def test_runs_of_the_requestors_own_slots(monkeypatch):
     """Another corner the randomised differential found (seed 704899: three servants offering 180k
     slots, half of 120k requests from their own hosts, chunks of 1024): a request whose own
