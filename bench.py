@@ -644,7 +644,7 @@ def setup(args):
     return E
 
 
-def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
+def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0, cpu_prefix=0):
     """Times `steps` batches of `config` on the run's context(s). detail "full": the driver's
     line (end-to-end loops, CPU baseline, >= 100 latency samples); "compact": a sub-record of
     it (resident loop, synchronous latencies, per-kernel events, parity against the committed
@@ -725,7 +725,7 @@ def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
     # Per-batch latency (p50 / p99) and the synchronous rate: one batch in flight, a few untimed
     # calls first (the switch from the pipelined loop, a short run's clocks still settling), at
     # least n_lat samples whatever --steps is.
-    n_lat = 100 if full else 30
+    n_lat = 100  # per-batch wall time over >= 100 repeats, sub-records included
     lat = []
     if pipelined:
         for _ in range(5):
@@ -981,8 +981,12 @@ def measure_config(E, args, config, scaling, steps, warmup, detail, digests=0):
         if full:
             out["roofline"]["note"] = ("the dominant kernel is bound by the dependency chain of the "
                                        "greedy merge, not by bandwidth: see DESIGN.md 3.4")
-    if full and world == 1 and not args.no_cpu_baseline:
-        ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000)
+    if world == 1 and not args.no_cpu_baseline and (full or cpu_prefix):
+        # cfg2: the whole batch. cfg3 / cfg4: the first 50k requests, the rate taken
+        # as the batch's (the reference only gets slower as servants fill up: full runs take
+        # ~2 min / ~20 min).
+        ref_idx, base = cpu_baseline(sv, tk, max_tasks=100_000 if full else cpu_prefix)
+        base["requests"] = int(len(ref_idx))
         out["cpu_baseline"] = base
         out["parity_vs_cpu_baseline"] = bool(np.array_equal(ref_idx, host_idx[:len(ref_idx)]))
     return out
@@ -992,7 +996,8 @@ COMPACT_KEYS = ("value", "unit", "ms_per_step", "ms_per_step_synchronous", "step
                 "n_gpus", "dtype", "p50_dispatch_latency_ms", "p99_dispatch_latency_ms",
                 "latency_samples", "kernels_us_per_step", "kernel_launches_per_step",
                 "parity_vs_reference_fixture", "fixture_requests", "fixture_ticks", "conservation",
-                "parity_vs_oracle", "sharded", "transport", "value_end_to_end")
+                "parity_vs_oracle", "sharded", "transport", "value_end_to_end", "cpu_baseline",
+                "parity_vs_cpu_baseline")
 
 
 def compact(rec):
@@ -1016,6 +1021,111 @@ def compact(rec):
     return c
 
 
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 8192  # the driver keeps a bounded tail of stdout: a line it cannot ingest is no measurement
+
+
+def r4(x):
+    """Four significant digits for the sub-records of the line (the contract keys stay exact)."""
+    if isinstance(x, float):
+        return float("%.4g" % x)
+    if isinstance(x, dict):
+        return {k: r4(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [r4(v) for v in x]
+    return x
+
+
+def driver_line(full):
+    """The ONE line of stdout: the bench contract's keys, `roofline`, `cpu_baseline`, and one short
+    record per BASELINE.json configuration. Everything else that was measured in this run (per-kernel
+    times, the latency tables of the TaskDispatcher surface, concurrent callers, the pageable-buffer
+    variants, ...) is in DETAIL_FILE, written next to this script; the line names it."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config")
+    line = {k: full[k] for k in keep}
+    if "roofline" in full:
+        line["roofline"] = {k: full["roofline"][k] for k in (
+            "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us",
+            "algorithmic_bytes_per_launch") if k in full["roofline"]}
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in (
+            "value", "unit", "cores", "kind", "sample", "p99_latency_us", "soa_port_value")
+            if k in full["cpu_baseline"]}
+    side = {}
+    for k in ("value_definition", "value_synchronous", "value_end_to_end", "ms_per_step_synchronous",
+              "p50_dispatch_latency_ms", "p99_dispatch_latency_ms", "latency_samples", "granted_all_ranks",
+              "parity_vs_cpu_baseline", "parity_vs_reference_fixture", "fixture_requests", "fixture_ticks",
+              "parity_ticks", "conservation", "parity_vs_oracle", "sharded", "transport", "rccl_ranks"):
+        if k in full:
+            side[k] = full[k]
+    if "end_to_end" in full:
+        side["end_to_end_ms"] = full["end_to_end"]["ms_per_batch"]
+        side["end_to_end_p99_ms"] = full["end_to_end"]["p99_ms"]
+    if "steady_state_commit" in full:
+        side["commit_and_release_ms_per_step"] = full["steady_state_commit"]["ms_per_step"]
+    line.update(r4(side))
+
+    def short(c):
+        s = {k: c[k] for k in ("ms_per_step", "value", "value_end_to_end", "p50_dispatch_latency_ms",
+                               "p99_dispatch_latency_ms", "latency_samples", "steps",
+                               "parity_vs_reference_fixture", "fixture_requests", "fixture_ticks",
+                               "parity_vs_oracle", "conservation", "n_gpus", "scaling", "sharded")
+             if c.get(k) is not None}
+        if "roofline" in c:
+            s["roofline"] = {k: c["roofline"].get(k) for k in ("kernel", "frac", "avg_launch_us", "traffic")}
+        if "cpu_baseline" in c:
+            s["cpu_baseline"] = {k: c["cpu_baseline"][k] for k in ("value", "kind", "cores", "requests")
+                                 if k in c["cpu_baseline"]}
+            s["parity_vs_cpu_baseline"] = c.get("parity_vs_cpu_baseline")
+        return r4(s)
+
+    if "configs" in full:
+        line["configs"] = {k: short(v) for k, v in full["configs"].items() if v}
+    if full.get("strong_cfg4"):
+        line["strong_cfg4"] = short(full["strong_cfg4"])
+    td = full.get("td_surface") or {}
+    if td and "error" not in td:
+        s = {}
+        for S in (2000, 16000):
+            lat = td.get("latency", {}).get("servants_%d" % S, {})
+            one = lat.get("tick", {}).get("single_1")
+            ref = lat.get("reference", {}).get("single_1") if isinstance(lat.get("reference"), dict) else None
+            if isinstance(one, dict):
+                s["call_us_%dk_servants" % (S // 1000)] = {
+                    "p50": one.get("p50"), "p99": one.get("p99"), "p999": one.get("p999"),
+                    "reference_p50": ref and ref.get("p50"), "reference_p99": ref and ref.get("p99")}
+        for k in ("timer_on", "parked_waiters"):
+            if k in td:
+                s[k] = td[k]
+        cc = td.get("concurrent_callers_2k_servants")
+        if isinstance(cc, dict) and "error" not in cc:
+            s["concurrent_calls_per_s"] = {k: v.get("calls_per_s") for k, v in cc.items() if isinstance(v, dict)}
+        line["td_surface"] = r4(s)
+    line["detail_file"] = DETAIL_FILE
+    return line
+
+
+def emit(full):
+    """Writes everything measured to DETAIL_FILE and prints the driver's line (< LINE_LIMIT bytes,
+    asserted: a line the driver cannot parse is an unmeasured round — BENCH_r05)."""
+    line = driver_line(full)
+    try:
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:  # (a read-only checkout: the line still goes out)
+        line["detail_file"] = "not written: %s" % e
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:  # never reached with today's records; degrade rather than lose the round
+        for k in ("td_surface", "strong_cfg4", "configs"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) < LINE_LIMIT:
+                break
+    assert len(text) < LINE_LIMIT, len(text)
+    print(text, flush=True)
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -1035,7 +1145,7 @@ def main():
             return 2
         out = stream_record(args, args.steps, args.warmup, 0 if args.no_cpu_baseline else 30,
                             device=int(os.environ.get("LOCAL_RANK", 0)))
-        print(json.dumps(out))
+        emit(out)
         return 0
 
     E = setup(args)
@@ -1055,7 +1165,8 @@ def main():
             k = max(5, min(args.steps, 20))
             # (ten untimed batches: the library decides from a shape's first seven whether the walk of
             # the dedicated tier's end pays on this registry — DESIGN.md 9.3)
-            out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 10, "compact"))
+            out["configs"][cfg] = compact(measure_config(E, args, cfg, "weak", k, 10, "compact",
+                                                         cpu_prefix=50_000))
         # Sparse eligibility: cfg2's batch on a pool with 150 digests, every servant advertising its
         # own handful (~one servant class per servant; the reference has no limit on them,
         # task_dispatcher.h:93-94) — the walk in groups of 64 requests (wide_kernel.h).
@@ -1072,7 +1183,9 @@ def main():
         E.ctx.group_destroy()
     E.ctx.close()
     if line_obj is not None and "configs" in line_obj:
-        rec = stream_record(args, 200, 20, 0, device=E.device)
+        # (>= 1000 ticks for the p99, SURVEY.md 8d: 0.1 s of device time; the reference replays the
+        # first 30 of them beside it: ~4 s)
+        rec = stream_record(args, 1000, 50, 0 if args.no_cpu_baseline else 30, device=E.device)
         c = compact(rec)
         c["value_definition"] = rec["value_definition"]
         line_obj["configs"]["cfg5"] = c
@@ -1086,7 +1199,7 @@ def main():
         E.dist.barrier()
         E.dist.destroy_process_group()
     if line_obj is not None:
-        print(json.dumps(line_obj), flush=True)
+        emit(line_obj)
     if stuck:
         os._exit(0)  # (do not tear the context down under a bootstrap that never returned)
     return 0

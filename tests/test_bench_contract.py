@@ -65,7 +65,32 @@ def run_bench(*args, env=None, timeout=420):
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "bench.py must print exactly ONE JSON line: %r" % out.stdout[-800:]
     assert out.stdout.strip().splitlines()[-1] == lines[0]  # ... and it is the last thing on stdout
-    return json.loads(lines[0])
+    # ... short enough for the driver to ingest (BENCH_r05: a 23.8 KB line came back "parsed": null)
+    assert len(lines[0]) < 8192, len(lines[0])
+    line = json.loads(lines[0])
+    validate_line(line)
+    # everything else that was measured is in the file the line names
+    detail = json.load(open(os.path.join(ROOT, line["detail_file"])))
+    for k in REQUIRED:
+        assert detail[k] == line[k], k
+    detail["_line"] = line
+    return detail
+
+
+def validate_line(j, cpu_baseline=None):
+    """What the driver reads: the contract keys, `roofline`, `cpu_baseline`."""
+    for k in REQUIRED:
+        assert k in j, k
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ROOFLINE:
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    if cpu_baseline if cpu_baseline is not None else "cpu_baseline" in j:
+        for k in CPU:
+            assert k in j["cpu_baseline"], k
+        assert j["parity_vs_cpu_baseline"] is True
+    assert j["detail_file"] == "bench_detail.json"
 
 
 @pytest.mark.gpu
@@ -103,8 +128,18 @@ def test_bench_cfg2_line():
         assert r["p99_dispatch_latency_ms"] >= r["p50_dispatch_latency_ms"] > 0
         assert r["roofline"]["kernel"] in r["kernels_us_per_step"] and 0 < r["roofline"]["frac"] < 1
         assert r["end_to_end_ms"] > 0
+        assert r["latency_samples"] >= 100
+        assert r["cpu_baseline"]["kind"] == "reference" and r["cpu_baseline"]["requests"] == 50_000
+        assert r["parity_vs_cpu_baseline"] is True
     assert c["cfg5"]["parity_vs_reference_fixture"] is True and c["cfg5"]["fixture_ticks"] == 200
-    assert c["cfg5"]["steps"] == 200 and c["cfg5"]["ms_per_step"] > 0
+    assert c["cfg5"]["steps"] == 1000 and c["cfg5"]["ms_per_step"] > 0
+    assert c["cfg5"]["latency_samples"] >= 1000 and c["cfg5"]["parity_vs_cpu_baseline"] is True
+    # the driver's line carries a short record of each, and its own baseline
+    ln = j["_line"]
+    assert set(ln["configs"]) == set(c) and "cpu_baseline" in ln and "roofline" in ln
+    for k in ("cfg3", "cfg4", "cfg5"):
+        assert ln["configs"][k]["cpu_baseline"]["value"] > 0 and ln["configs"][k]["roofline"]["frac"] > 0
+    assert ln["value_end_to_end"] > 0 and ln["td_surface"]
 
 
 @pytest.mark.gpu
@@ -165,3 +200,21 @@ def test_bench_baseline_json_agrees():
     b = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "assignments/sec" in b["metric"]
     assert b.get("published") == {}  # nothing published for this path: vs_baseline stays null
+
+
+def test_driver_line_of_a_full_record_stays_short():
+    """bench.driver_line() on the largest record this repo ever produced (round 5's 23.8 KB line,
+    which the driver could not parse): contract keys intact, roofline + cpu_baseline carried,
+    one short record per configuration, well under the limit. No GPU needed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_line.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.driver_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT // 2, len(text)
+    validate_line(line, cpu_baseline=True)
+    for k in REQUIRED:
+        assert line[k] == full[k]
+    assert set(line["configs"]) == {"cfg3", "cfg4", "cfg5", "cfg2_150_digests"}
+    assert line["td_surface"]["concurrent_calls_per_s"]["16"] > 0
