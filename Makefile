@@ -26,7 +26,7 @@ oracle:
 model:
 	$(MAKE) -s -C tests/model
 # Native (C++) drive of the dispatcher through the scheduler harness; plain g++, links libydc.so.
-native: tests/native/harness_test tools/td_native_bench tools/hbm_calib tests/tools/launch_probe tests/tools/overlap_probe tests/tools/atomic_probe
+native: tests/native/harness_test tests/native/td_linearize_gpu tools/td_native_bench tools/hbm_calib tests/tools/launch_probe tests/tools/overlap_probe tests/tools/atomic_probe
 	$(MAKE) -s -C tests/native all
 # Counter calibration microbenchmark (tools/calibrate.sh runs it under rocprofv3 on the GPU box).
 tools/hbm_calib: tools/hbm_calib.hip
@@ -48,6 +48,11 @@ tools/td_native_bench_stub: tools/td_native_bench.cc $(HDRS)
 	    -Ltests/native -ltd_stub -Wl,-rpath,'$$ORIGIN/../tests/native' -lpthread
 tests/native/harness_test: tests/native/harness_test.cc tests/native/scheduler_harness.cc tests/native/scheduler_harness.h yadcc_amd/libydc.so $(HDRS)
 	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -Itests/native -o $@ tests/native/harness_test.cc tests/native/scheduler_harness.cc \
+	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../../yadcc_amd' -lpthread
+# Concurrent callers through the C-ABI against the real library (verified against the reference by
+# tests/test_task_dispatcher_gpu.py).
+tests/native/td_linearize_gpu: tests/native/td_linearize.cc yadcc_amd/libydc.so include/yadcc_dispatch.h
+	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ tests/native/td_linearize.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../../yadcc_amd' -lpthread
 # Sanitizer builds of the host class against the CPU stand-in of the device API (no GPU).
 tsan asan:

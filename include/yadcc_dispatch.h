@@ -109,6 +109,9 @@ typedef struct ydc_stats {
   uint32_t shard_sort_batches, shard_sort_misses;
   uint32_t small_batch;    /* 1: the one-launch path placed the batch (ydc_dispatch_tick) */
   uint32_t zone_rows;      /* chunks around the dedicated tier's end that started from a walked state (0: no walk) */
+  /* cumulative over the context's life: calls answered by the resident tick kernel (no launch),
+   * by a launched tick kernel, and batches placed by the batch pipeline */
+  uint32_t tick_resident_calls, tick_launched_calls, pipeline_batches;
   float stage_ms[16];      /* per-stage GPU time when profiling is on (ydc_set_profiling) */
 } ydc_stats;
 
@@ -451,12 +454,27 @@ typedef struct ydc_td_stats {
   uint64_t requests, batches, device_ns, host_ns;
   uint64_t heartbeats, heartbeats_unchanged, bookkeeper_rebuilds;
   uint64_t lease_pages; /* pages of the lease table in use (4096 grant ids each): bounded by the live leases */
+  /* OnExpirationTimer (task_dispatcher.cc:498-536): ticks so far; lease entries the last tick looked
+   * at (those filed under the seconds that were due — the reference looks at every lease, :523-535);
+   * how long the last tick held the dispatcher's lock, and the longest any tick did; entries in
+   * the expiry index at the moment (live leases + not yet discarded renewals). */
+  uint64_t timer_ticks, timer_lease_entries_seen, timer_last_ns, timer_max_ns, lease_wheel_entries;
 } ydc_td_stats;
 int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out);
 /* OnExpirationTimer, task_dispatcher.cc:498-536 (for hosts that drive the 1 s tick themselves). */
 int ydc_td_on_expiration_timer(ydc_td* td);
 /* DumpInternals, task_dispatcher.cc:538-614, as JSON. Valid until the next call on td. */
 const char* ydc_td_dump_internals(ydc_td* td);
+/* Test switch: the order in which calls took effect. With the log on, every call appends one
+ * record under the dispatcher's lock at the moment it reads or changes the state (each placement
+ * attempt with its answer, each freed id, renewal, heartbeat, servant report, timer tick — with the
+ * clock reading it used). ydc_td_oplog_take returns the records so far as a JSON array (valid until
+ * the next call on td) and empties the log. Replaying them, single-threaded, through the
+ * reference class (task_dispatcher.cc:93-140,167-188 ...) must give the same answers and the same
+ * DumpInternals: that is what "concurrent callers are linearizable" means here, and what
+ * tests/td_scenarios.py:concurrent_callers_linearize checks. */
+int ydc_td_oplog_enable(ydc_td* td, int on);
+const char* ydc_td_oplog_take(ydc_td* td);
 
 #ifdef __cplusplus
 }

@@ -194,3 +194,9 @@ int ydc_dispatch_tick(ydc_context* c, const uint32_t* upd_idx, const ydc_servant
 }
 
 }  // extern "C"
+
+extern "C" int ydc_get_stats(const ydc_context* c, ydc_stats* out) {  // (no device paths to tell apart here)
+  if (!c || !out) return YDC_ERR_INVALID_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  return YDC_OK;
+}

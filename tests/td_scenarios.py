@@ -520,3 +520,411 @@ def assert_same_dump(ours, theirs):
     for k in ta:
         assert set(ta[k]) == set(tb[k])
         assert strip(ta[k]) == strip(tb[k]), k
+
+
+# ---------------------------------------------------------------------------------------------
+# Concurrent callers: linearizability against the reference
+# ---------------------------------------------------------------------------------------------
+def replay_oplog_through_reference(log, ref):
+    """Replays the order in which calls took effect (ydc_td_oplog_take) through the reference
+    class, one call at a time, each with the clock reading the concurrent run used; every answer
+    must be the one the concurrent run gave (task_dispatcher.cc:93-140 WaitForStartingNewTask,
+    :142-163 KeepTaskAlive, :165-188 FreeTask, :190-220 KeepServantAlive, :222-277
+    NotifyServantRunningTasks, :498-536 OnExpirationTimer). Returns the number of records."""
+    L = R.lib()
+    base = None  # the reference's fake clock at the run's clock 0 (whole milliseconds on both sides)
+
+    def set_clock(now_ns):
+        nonlocal base
+        assert now_ns % 1_000_000 == 0
+        if base is None:
+            base = L.ref_clock_now_ns() - now_ns
+        delta = base + now_ns - L.ref_clock_now_ns()
+        assert delta % 1_000_000 == 0
+        R.clock_advance_ms(delta // 1_000_000)
+
+    for k, e in enumerate(log):
+        op = e["op"]
+        if "now" in e:
+            set_clock(e["now"])
+        if op == "wait":
+            st, tid, loc = ref.wait_for_starting_new_task(e["ip"], e["digest"], min_version=e["minv"],
+                                                          expires_in_ms=e["lease"] // 1_000_000, timeout_in_ms=0)
+            assert (st, tid, loc) == (e["st"], e.get("id"), e.get("loc")), (k, e, (st, tid, loc))
+        elif op == "free":
+            ref.free_task(e["id"])
+        elif op == "renew":
+            assert ref.keep_task_alive(e["id"], e["lease"] // 1_000_000) == bool(e["ok"]), (k, e)
+        elif op == "servant":
+            ref.keep_servant_alive(e["location"], e["envs"], e["max_tasks"], e["num_processors"], e["current_load"],
+                                   priority=e["priority"], version=e["version"], total_memory=e["total_memory"],
+                                   memory_available=e["memory_available"], expires_in_ms=e["lease"] // 1_000_000,
+                                   reported=e["reported"], reason=e["reason"])
+        elif op == "report":
+            assert ref.notify_servant_running_tasks(e["loc"], e["ids"]) == e["unknown"], (k, e)
+        elif op == "timer":
+            R.fire_timers()
+        else:
+            raise AssertionError(e)
+    return len(log)
+
+
+def verify_linearizable(log, dump, threads, check_real_time=True):
+    """log: the order in which calls took effect (ydc_td_oplog_take); dump: the final
+    DumpInternals; threads: [{"ip": the requestor address the thread used (None: it only freed),
+    "ops": [("wait", (status, id, location), t_invoke, t_return) | ("free", id, t_invoke,
+    t_return), ...] in program order}]. Checks (1) program order, (2) real-time order, (3) the
+    reference's answers and final state for the logged order. Returns the number of records."""
+    waits_of, free_at = {}, {}
+    for pos, e in enumerate(log):
+        if e["op"] == "wait":
+            waits_of.setdefault(e["ip"], []).append((pos, e))
+        elif e["op"] == "free":
+            free_at.setdefault(e["id"], []).append(pos)
+    users = {}
+    for t in threads:
+        if t["ip"] is not None:
+            users[t["ip"]] = users.get(t["ip"], 0) + 1
+    intervals = []  # (log position, t_invoke, t_return)
+    for t in threads:
+        if t["ip"] is not None and users[t["ip"]] > 1:
+            continue  # (two callers drew the same servant host: their entries cannot be told apart)
+        last = -1
+        calls_, cur = [], None  # attempts of one call: "try" restarts at 1
+        for pos, e in waits_of.get(t["ip"], []):
+            if e["try"] == 1:
+                cur = []
+                calls_.append(cur)
+            cur.append((pos, e))
+        it = iter(calls_)
+        for kind, payload, t0, t1 in t["ops"]:
+            if kind == "wait":
+                attempts = next(it)
+                pos, e = attempts[-1]
+                assert (e["st"], e.get("id"), e.get("loc")) == tuple(payload), (t["ip"], payload, e)
+                assert all(a["st"] == D.TIMEOUT for _, a in attempts[:-1])
+                exact = len(attempts) == 1 or payload[0] != D.TIMEOUT
+            else:
+                # (a grant that did not fit the caller's buffer is freed by the library itself first)
+                pos = free_at[payload][-1]
+                exact = True
+            assert pos > last, ("program order", t["ip"], kind, payload, pos, last)
+            if exact:
+                intervals.append((pos, t0, t1))
+            last = pos
+        assert next(it, None) is None, ("calls in the log that the thread never made", t["ip"])
+    if check_real_time:
+        latest_invoke = -1.0
+        for pos, t0, t1 in sorted(intervals):
+            assert t1 >= latest_invoke, ("took effect after a call that was made after it had returned", pos)
+            latest_invoke = max(latest_invoke, t0)
+    ref = R.RefDispatcher()
+    try:
+        n = replay_oplog_through_reference(log, ref)
+        assert_same_dump(dump, ref.dump_internals())
+    finally:
+        ref.close()
+    return n
+
+
+def native_linearize(binary, out_path, n_servants=2000, n_threads=12, calls=2000, cap=0, seed=1, env=None):
+    """Runs tests/native/td_linearize (threads in C++, through the C-ABI) and verifies what it wrote."""
+    import json
+    import subprocess
+    r = subprocess.run([binary, out_path, str(n_servants), str(n_threads), str(calls), str(cap), str(seed)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "TD-LINEARIZE-WRITTEN" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    j = json.load(open(out_path))
+    threads = [{"ip": t["ip"], "ops": [(o[0], tuple(o[1:4]), o[4], o[5]) if o[0] == "wait" else (o[0], o[1], o[2], o[3])
+                                       for o in t["ops"]]} for t in j["threads"]]
+    n = verify_linearizable(j["log"], j["dump"], threads)
+    kinds = {}
+    for e in j["log"]:
+        k = e["op"] + (":%d" % e["st"] if e["op"] == "wait" else "")
+        kinds[k] = kinds.get(k, 0) + 1
+    return {"records": n, "kinds": kinds, "requests_per_device_turn": j["requests_per_device_turn"],
+            "retried_attempts": sum(1 for e in j["log"] if e["op"] == "wait" and e["try"] > 1)}
+
+
+def concurrent_callers_linearize(make, seed=1, n_servants=2000, n_threads=12, calls=400, check_real_time=True,
+                                 max_tasks_cap=None):
+    """Many threads at once on one dispatcher — single requests (some parked with a deadline), small
+    batches, FreeTask of own and of other threads' grants, lease renewals, heartbeats that change
+    loads and capacities, servant reports, clock + timer ticks with leases and servants expiring —
+    and then the proof that the combined result is what SOME sequential order of the same calls
+    gives on the reference: the dispatcher logs the order in which the calls took effect; that
+    order, replayed single-threaded through the reference's own translation units, must give
+    identical (status, task id, location) for every call and an identical final DumpInternals.
+    On top: every thread finds its own calls in the log in the order it made them (a FreeTask
+    before the thread's next request included), and — check_real_time — a call that had returned
+    before another was made precedes it in the log."""
+    import threading
+    import time
+    rng0 = np.random.default_rng(seed)
+    digests = ["c0ffee%04d" % i + "0" * 54 for i in range(4)]
+    td = make(fake_clock=True)
+    pers = []
+    for i in range(n_servants):
+        p = _random_personality(rng0, i, digests)
+        p["location"] = "10.%d.%d.%d:%d" % (2 + i // 60000, (i // 250) % 240, i % 250, 8335)
+        p["expires_in_ms"] = int(rng0.integers(3000, 9000)) if i % 7 == 0 else 3_600_000
+        if max_tasks_cap is not None:  # a pool that saturates: requests park, FreeTask wakes them
+            p["max_tasks"] = min(p["max_tasks"], max_tasks_cap)
+        pers.append(p)
+    td.oplog_enable(True)
+    for p in pers:
+        td.keep_servant_alive(**p)
+    stop = threading.Event()
+    shared_lock = threading.Lock()
+    handed_over = []       # grants left for the freer thread
+    errors = []
+    per_thread = {}        # thread key -> [(kind, payload, t_invoke, t_return), ...] in program order
+
+    def guard(fn):
+        def run(*a):
+            try:
+                fn(*a)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(repr(e))
+                stop.set()
+        return run
+
+    @guard
+    def caller(k):
+        rng = np.random.default_rng(1000 * seed + k)
+        ip = "172.20.%d.7" % k if k % 3 else pers[int(rng.integers(n_servants))]["location"].split(":")[0]
+        mine, hist = [], per_thread.setdefault(("caller", k), [])
+        hist.append(("ip", ip, 0, 0))
+        for _ in range(calls):
+            if stop.is_set():
+                return
+            ev = rng.random()
+            if ev < 0.62:
+                dg = "unknown" if rng.random() < 0.02 else digests[int(rng.integers(4))]
+                mv = int(rng.choice([0, 20]))
+                lease = int(rng.choice([40, 200, 60000]))
+                timeout = int(rng.choice([0, 0, 0, 3]))
+                t0 = time.perf_counter()
+                st, tid, loc = td.wait_for_starting_new_task(ip, dg, min_version=mv, expires_in_ms=lease,
+                                                             timeout_in_ms=timeout)
+                hist.append(("wait", (st, tid, loc), t0, time.perf_counter()))
+                if st == D.GRANTED:
+                    mine.append(tid)
+            elif ev < 0.70:
+                n = int(rng.integers(2, 9))
+                dg = digests[int(rng.integers(4))]
+                t0 = time.perf_counter()
+                st, ids, locs = td.wait_for_starting_new_tasks([ip] * n, [dg] * n, [0] * n, expires_in_ms=60000)
+                t1 = time.perf_counter()
+                for j in range(n):
+                    ok = int(st[j]) == D.GRANTED
+                    hist.append(("wait", (int(st[j]), int(ids[j]) if ok else None, locs[j] if ok else None), t0, t1))
+                    if ok:
+                        mine.append(int(ids[j]))
+            elif ev < 0.90 and mine:
+                tid = mine.pop(int(rng.integers(len(mine))))
+                if rng.random() < 0.25:
+                    with shared_lock:
+                        handed_over.append(tid)
+                else:
+                    t0 = time.perf_counter()
+                    td.free_task(tid)
+                    hist.append(("free", tid, t0, time.perf_counter()))
+            elif mine:
+                tid = mine[int(rng.integers(len(mine)))]
+                td.keep_task_alive(tid, int(rng.choice([50, 5000])))
+        with shared_lock:
+            handed_over.extend(mine)
+
+    @guard
+    def freer():
+        hist = per_thread.setdefault(("freer", 0), [])
+        while not stop.is_set() or handed_over:
+            with shared_lock:
+                tid = handed_over.pop() if handed_over else None
+            if tid is None:
+                time.sleep(0.0005)
+                continue
+            t0 = time.perf_counter()
+            td.free_task(tid)
+            hist.append(("free", tid, t0, time.perf_counter()))
+
+    @guard
+    def registry():
+        rng = np.random.default_rng(77 + seed)
+        while not stop.is_set():
+            i = int(rng.integers(n_servants))
+            p = dict(pers[i])
+            if rng.random() < 0.8:  # the daemon's next report: a new load figure
+                p["current_load"] = int(rng.integers(0, int(p["num_processors"] * 1.25)))
+            else:                   # ... or a changed machine (capacity, environments)
+                q = _random_personality(rng, i, digests)
+                p.update(envs=q["envs"], max_tasks=q["max_tasks"], num_processors=q["num_processors"],
+                         version=q["version"], memory_available=q["memory_available"])
+                if max_tasks_cap is not None:
+                    p["max_tasks"] = min(p["max_tasks"], max_tasks_cap)
+            pers[i] = p
+            td.keep_servant_alive(**p)
+            if rng.random() < 0.3:
+                td.notify_servant_running_tasks(p["location"], [int(x) for x in rng.integers(0, 4000, size=5)])
+            time.sleep(0.0002)
+
+    @guard
+    def clock():
+        tick = 0
+        while not stop.is_set():
+            td.clock_advance_ms(1)
+            tick += 1
+            if tick % 25 == 0:
+                td.on_expiration_timer()
+            time.sleep(0.0005)
+
+    callers = [threading.Thread(target=caller, args=(k,)) for k in range(n_threads)]
+    others = [threading.Thread(target=f) for f in (freer, registry, clock)]
+    [t.start() for t in others + callers]
+    [t.join() for t in callers]
+    stop.set()
+    [t.join() for t in others]
+    assert not errors, errors[:3]
+    log = td.oplog_take()
+    td.oplog_enable(False)
+    dump = td.dump_internals()
+    hs = td.host_stats()
+
+    threads = []
+    for key, hist in per_thread.items():
+        if key[0] == "caller":
+            threads.append({"ip": hist[0][1], "ops": [(k, pl, t0, t1) for k, pl, t0, t1 in hist[1:]]})
+        else:
+            threads.append({"ip": None, "ops": list(hist)})
+    n = verify_linearizable(log, dump, threads, check_real_time)
+    td.close()
+    kinds = {}
+    for e in log:
+        k = e["op"] + (":%d" % e["st"] if e["op"] == "wait" else "")
+        kinds[k] = kinds.get(k, 0) + 1
+    parked = sum(1 for e in log if e["op"] == "wait" and e["try"] > 1)
+    return {"records": n, "kinds": kinds, "retried_attempts": parked, "threads": n_threads,
+            "requests_per_device_turn": hs["requests"] / max(hs["batches"], 1)}
+
+
+def event_stream_at_scale(make, seed, n_pool=2000, prefill=50_000, steps=20_000, n_digests=4, batch_sizes=(
+        1, 1, 2, 3, 4, 8, 16, 32, 64, 128, 256)):
+    """The differential of event_stream_matches_reference at the scale the scheduler runs at:
+    2000 servants, >= 5*10^4 live leases throughout, >= 2*10^4 events whose grant batches have
+    1 .. 256 requests — so that within ONE stream the resident tick kernel, the launched tick and
+    the batch pipeline all serve calls, between structural heartbeats (new / changed / expired
+    servants: class changes, ydc_remove_servants), bulk frees (COMMIT / release) and timer ticks
+    that turn leases into zombies — every answer compared with the reference class's."""
+    digests = ["c0ffee%04d" % i + "0" * 54 for i in range(n_digests)]
+    rng = np.random.default_rng(seed)
+    ref = R.RefDispatcher()
+    td = make()
+    hosts = ["10.%d.%d.%d" % (1 + i // 62500, (i // 250) % 250, (i if i % 5 else max(i - 1, 0)) % 250) for i in range(n_pool)]
+    live_ids, live_pos = [], {}
+    by_servant = {}
+    pick = lambda: digests[int(rng.integers(n_digests))]
+
+    def add_live(tid, loc):
+        live_pos[tid] = len(live_ids)
+        live_ids.append(tid)
+        by_servant.setdefault(loc, []).append(tid)
+
+    def drop_live(tid):
+        at = live_pos.pop(tid, None)
+        if at is None:
+            return
+        last = live_ids.pop()
+        if last != tid:
+            live_ids[at] = last
+            live_pos[last] = at
+
+    def heartbeat(i, long_lived=False):
+        p = _random_personality(rng, i, digests)
+        p["location"] = "%s:%d" % (hosts[i], 9000 + i % 50)
+        p["num_processors"] *= 4
+        p["max_tasks"] *= 4
+        p["current_load"] *= 4
+        if long_lived or rng.random() < 0.8:
+            p["expires_in_ms"] = 3_600_000
+        for d in (ref, td):
+            d.keep_servant_alive(**p)
+
+    def grant_batch(n, lease):
+        ips = [hosts[int(rng.integers(n_pool))] if rng.random() < 0.2 else "172.16.%d.%d" % (rng.integers(250), rng.integers(250))
+               for _ in range(n)]
+        dg = [("unknown" if rng.random() < 0.01 else pick()) for _ in range(n)]
+        mv = [int(rng.choice([0, 20])) for _ in range(n)]
+        st, ids, locs = td.wait_for_starting_new_tasks(ips, dg, mv, expires_in_ms=lease)
+        for k in range(n):
+            rst, rid, rloc = ref.wait_for_starting_new_task(ips[k], dg[k], min_version=mv[k], expires_in_ms=lease)
+            assert (int(st[k]), locs[k] or None) == (rst, rloc), (seed, "batch of", n, k)
+            if rst == R.OK:
+                assert int(ids[k]) == rid
+                add_live(rid, rloc)
+
+    for i in range(n_pool):
+        if i % 10:
+            heartbeat(i, long_lived=True)
+    while len(live_ids) < prefill:
+        before = len(live_ids)
+        grant_batch(5000, 3_600_000)
+        assert len(live_ids) > before, "the pool cannot hold the prefill"
+    paths = td.dump_internals().get("gpu", {})
+    low_water = len(live_ids)
+    for step in range(steps):
+        ev = rng.random()
+        if ev < 0.22:
+            heartbeat(int(rng.integers(n_pool)))
+        elif ev < 0.52:
+            grant_batch(int(rng.choice(batch_sizes)), 3_600_000 if rng.random() < 0.8 else int(rng.integers(500, 6000)))
+        elif ev < 0.72 and live_ids:
+            k = int(rng.integers(1, 200))
+            ids = [live_ids[int(j)] for j in rng.integers(0, len(live_ids), size=k)]
+            ids = list(dict.fromkeys(ids)) + ([10 ** 9] if rng.random() < 0.05 else [])
+            if rng.random() < 0.5:
+                for d in (ref, td):
+                    d.free_tasks(ids)
+            else:
+                for t in ids[:8]:
+                    for d in (ref, td):
+                        d.free_task(t)
+                ids = ids[:8]
+            # (free_tasks = one FreeTask per id on both sides: an unknown id ends only its own call)
+            for t in ids:
+                drop_live(t)
+        elif ev < 0.78 and live_ids:
+            tid = live_ids[int(rng.integers(len(live_ids)))] if rng.random() < 0.9 else 10 ** 9
+            ms = int(rng.integers(500, 6000))
+            assert ref.keep_task_alive(tid, ms) == td.keep_task_alive(tid, ms)
+        elif ev < 0.90 and by_servant:
+            locs = list(by_servant)
+            loc = locs[int(rng.integers(len(locs)))]
+            ids = [t for t in by_servant[loc][-40:] if rng.random() < 0.7] + ([10 ** 9 + step] if rng.random() < 0.3 else [])
+            a = ref.notify_servant_running_tasks(loc, ids)
+            b = td.notify_servant_running_tasks(loc, ids)
+            assert a == b, (seed, step)
+            for t in by_servant[loc][-40:]:
+                if t not in ids:
+                    pass  # (swept only if it was a zombie: the final dump comparison sees it)
+        else:
+            ms = int(rng.integers(200, 2500))
+            R.clock_advance_ms(ms)
+            td.clock_advance_ms(ms)
+            R.fire_timers()
+            td.on_expiration_timer()
+        if step % 500 == 0:
+            # leases that both sides dropped (zombies swept, orphans): resynchronise the model from the dump
+            known = set(td.dump_internals()["tasks"])
+            for t in [t for t in live_ids if str(t) not in known]:
+                drop_live(t)
+            if len(live_ids) < prefill:
+                grant_batch(min(5000, prefill - len(live_ids) + 500), 3_600_000)
+            low_water = min(low_water, len(live_ids))
+    dump = td.dump_internals()
+    assert_same_dump(dump, ref.dump_internals())
+    stats = td.host_stats()
+    ref.close()
+    td.close()
+    return {"live_low_water": low_water, "live_at_end": len(dump["tasks"]), "servants_at_end": dump["servants_up"],
+            "requests": stats["requests"], "batches": stats["batches"], "gpu": dump.get("gpu", paths)}

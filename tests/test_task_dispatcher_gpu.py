@@ -97,3 +97,51 @@ def test_native_scheduler_harness():
     subprocess.check_call(["make", "-s", "tests/native/harness_test"], cwd=root)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "HARNESS-OK" in out.stdout, (out.stdout, out.stderr)
+
+
+@needs_ref
+@pytest.mark.parametrize("shape", ["roomy", "saturated"])
+def test_concurrent_callers_linearize(shape):
+    """12 caller threads + freer + heartbeats + clock / timer on the real library: the order in
+    which the calls took effect (ydc_td_oplog_*), replayed one call at a time through the
+    reference class, gives the same (status, task id, location) for every call and the same final
+    DumpInternals; every thread's own calls appear in program order and no call overtakes one
+    that had returned before it was made (tests/td_scenarios.py:verify_linearizable)."""
+    kw = dict(n_servants=2000, calls=500) if shape == "roomy" else dict(n_servants=40, calls=1500, max_tasks_cap=1)
+    r = S.concurrent_callers_linearize(make, seed=7, **kw)
+    assert r["records"] > 5000 and r["kinds"].get("wait:0", 0) > 500
+    if shape == "saturated":
+        assert r["retried_attempts"] > 500
+
+
+@needs_ref
+@pytest.mark.parametrize("shape", ["roomy", "saturated"])
+def test_native_callers_linearize(shape, tmp_path):
+    """... with the threads in C++ (tests/native/td_linearize.cc linked against libydc.so): 16
+    callers at full speed on 2000 servants (roomy: queued FreeTasks meet the same thread's next
+    request inside one device turn) and on a saturated pool (parked waiters retried at wake-ups)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "tests/native/td_linearize_gpu"], cwd=root)
+    args = dict(n_servants=2000, n_threads=16, calls=2500) if shape == "roomy" else dict(
+        n_servants=40, n_threads=16, calls=3000, cap=1)
+    r = S.native_linearize(os.path.join(root, "tests", "native", "td_linearize_gpu"), str(tmp_path / "lin.json"),
+                           seed=5, **args)
+    assert r["records"] > 40000 and r["kinds"]["wait:0"] > 5000
+    if shape == "roomy":
+        assert r["requests_per_device_turn"] > 1.2  # callers were combined
+    else:
+        assert r["retried_attempts"] > 5000
+
+
+@needs_ref
+def test_event_stream_at_scale():
+    """2000 servants, >= 5*10^4 live leases throughout, 2*10^4 events with grant batches of 1..256:
+    the resident tick kernel, the launched tick and the batch pipeline all serve calls of ONE
+    stream, between structural heartbeats, bulk frees and timer ticks — every answer and the final
+    DumpInternals equal to the reference class's (~1 min, most of it the reference)."""
+    r = S.event_stream_at_scale(make, seed=21)
+    assert r["live_low_water"] >= 45_000 and r["servants_at_end"] > 1500
+    g = r["gpu"]
+    assert g["tick_resident_calls"] > 500 and g["tick_launched_calls"] > 50 and g["pipeline_batches"] > 500, g

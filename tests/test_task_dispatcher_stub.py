@@ -120,3 +120,47 @@ def test_flat_string_map_against_unordered_map():
                          timeout=600)
     assert out.returncode == 0 and "FLAT-MAP-OK" in out.stdout, (out.stdout[-2000:],
                                                                  out.stderr[-4000:])
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [1, 2])
+def test_concurrent_callers_linearize(seed):
+    """12 caller threads + a freer, a heartbeat thread and the clock / timer thread on 2000
+    servants; the order in which their calls took effect, replayed one call at a time through the
+    reference, gives the same answers and the same final state."""
+    r = S.concurrent_callers_linearize(make, seed=seed)
+    assert r["records"] > 5000 and r["kinds"].get("wait:0", 0) > 1000 and r["kinds"].get("timer", 0) > 3
+
+
+@needs_ref
+@pytest.mark.parametrize("shape", ["roomy", "saturated"])
+def test_native_callers_linearize(shape, tmp_path):
+    """The same proof with the threads in C++ (tests/native/td_linearize.cc, through the C-ABI): 12
+    callers at full speed, so that FreeTask queued behind somebody's device turn and the same
+    thread's next request do meet in one turn (a build that applies queued frees after placing
+    fails here on program order). roomy: nobody parks, frees are queued; saturated: most requests
+    park and are retried at FreeTask's wake-ups."""
+    subprocess.check_call(["make", "-s", "-C", NATIVE, "linearize"])
+    args = dict(n_servants=300, calls=1500) if shape == "roomy" else dict(n_servants=40, calls=3000, cap=1)
+    r = S.native_linearize(os.path.join(NATIVE, "td_linearize_stub"), str(tmp_path / "lin.json"), seed=3, **args)
+    assert r["records"] > 20000 and r["kinds"]["wait:0"] > 3000
+    if shape == "saturated":
+        assert r["retried_attempts"] > 5000 and r["kinds"]["wait:2"] > 10000
+
+
+@needs_ref
+def test_native_callers_linearize_tsan(tmp_path):
+    """... and under ThreadSanitizer: no report, and the logged order still equals the reference's."""
+    subprocess.check_call(["make", "-s", "-C", NATIVE, "linearize"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    r = S.native_linearize(os.path.join(NATIVE, "td_linearize_tsan"), str(tmp_path / "lin.json"), n_servants=60,
+                           n_threads=8, calls=600, seed=4, env=env)
+    assert r["records"] > 3000
+
+
+@needs_ref
+def test_event_stream_at_scale_small():
+    """The scaled differential's event mix (bulk frees, batches of 1..256, structural heartbeats,
+    expiries under thousands of live leases) on the stand-in, reduced: the host class's side of it."""
+    r = S.event_stream_at_scale(make, seed=3, n_pool=300, prefill=5000, steps=2500)
+    assert r["live_low_water"] >= 4500

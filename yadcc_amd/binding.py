@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (YDC_LIB: a measurement build of the same library, e.g. libydc_probe.so — tools/phase_probe.py)
 LIB_PATH = os.environ.get("YDC_LIB") or os.path.join(_HERE, "libydc.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 IPC_HANDLE_BYTES = 256
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_LOCAL, TRANSPORT_IPC_DEVICE, TRANSPORT_IPC_HOST = range(5)
 TRANSPORT_NAMES = ("none", "rccl", "local", "ipc", "ipc-host")
@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
     "ydc_td_free_tasks", "ydc_td_host_stats", "ydc_td_running_tasks_acquire", "ydc_td_running_tasks_release",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
-    "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
+    "ydc_td_on_expiration_timer", "ydc_td_dump_internals", "ydc_td_oplog_enable", "ydc_td_oplog_take",
 )
 
 
@@ -72,7 +72,8 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in (
         "n_tasks", "n_servants", "n_classes", "n_slots", "key_bits", "radix_passes", "n_chunks",
         "rounds", "chunk_sims", "granted", "timeouts", "env_not_found", "shard_sort_batches",
-        "shard_sort_misses", "small_batch", "zone_rows")] + [
+        "shard_sort_misses", "small_batch", "zone_rows", "tick_resident_calls", "tick_launched_calls",
+        "pipeline_batches")] + [
             ("stage_ms", C.c_float * 16)]
 
     def as_dict(self):

@@ -56,6 +56,11 @@ std::vector<std::string> RequestorPrefixes(const std::string& location) {
   return out;
 }
 
+inline std::uint64_t NowNs() {
+  return (std::uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 std::uint32_t Clamp32(std::size_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (std::uint32_t)v; }
 
 void JsonEscape(const std::string& s, std::string* out) {
@@ -354,7 +359,61 @@ GpuTaskDispatcher::HostStats GpuTaskDispatcher::host_stats() const {
   HostStats s = host_stats_;
   s.bookkeeper_rebuilds = running_task_bookkeeper_.rebuilds();
   s.lease_pages = tasks_.pages();
+  s.lease_wheel_entries = lease_wheel_.entries();
   return s;
+}
+
+// ---------------------------------------------------------------------------
+// Operation log (test switch, gpu_task_dispatcher.h)
+// ---------------------------------------------------------------------------
+namespace {
+void LogKey(std::string* out, const char* key) {
+  if (out->back() != '{') *out += ", ";
+  out->push_back('"');
+  *out += key;
+  *out += "\": ";
+}
+void LogNum(std::string* out, const char* key, long long v) {
+  LogKey(out, key);
+  *out += std::to_string(v);
+}
+void LogStr(std::string* out, const char* key, std::string_view v) {
+  LogKey(out, key);
+  JsonEscape(std::string(v), out);
+}
+void LogOpen(std::string* out, const char* op) {
+  *out += out->empty() ? "{" : ",\n{";
+  LogStr(out, "op", op);
+}
+}  // namespace
+
+void GpuTaskDispatcher::EnableOpLog(bool on) {
+  Section sec(this);
+  oplog_on_ = on;
+}
+
+std::string GpuTaskDispatcher::TakeOpLog() {
+  Section sec(this);
+  std::string out = "[" + oplog_ + "]";
+  oplog_.clear();
+  return out;
+}
+
+void GpuTaskDispatcher::LogWait(const RequestView& r, std::chrono::nanoseconds lease, Clock::time_point now,
+                                int status, std::uint64_t id, const Servant* pick, std::uint32_t attempt) {
+  LogOpen(&oplog_, "wait");
+  LogNum(&oplog_, "try", attempt);
+  LogNum(&oplog_, "now", now.time_since_epoch().count());
+  LogStr(&oplog_, "ip", r.requestor_ip);
+  LogStr(&oplog_, "digest", r.compiler_digest);
+  LogNum(&oplog_, "minv", r.min_version);
+  LogNum(&oplog_, "lease", lease.count());
+  LogNum(&oplog_, "st", status);
+  if (pick) {
+    LogNum(&oplog_, "id", (long long)id);
+    LogStr(&oplog_, "loc", pick->personality.observed_location);
+  }
+  oplog_ += "}";
 }
 
 std::size_t GpuTaskDispatcher::CapacityAvailable(const Servant& s) const {
@@ -461,6 +520,29 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono
   Section sec(this);
   auto now = Now();
   ++host_stats_.heartbeats;
+  if (oplog_on_) {
+    LogOpen(&oplog_, "servant");
+    LogNum(&oplog_, "now", now.time_since_epoch().count());
+    LogNum(&oplog_, "lease", expires_in.count());
+    LogStr(&oplog_, "location", servant.observed_location);
+    LogStr(&oplog_, "reported", servant.reported_location);
+    LogKey(&oplog_, "envs");
+    oplog_ += "[";
+    for (std::size_t k = 0; k != servant.n_environments; ++k) {
+      if (k) oplog_ += ", ";
+      JsonEscape(std::string(servant.environments[k]), &oplog_);
+    }
+    oplog_ += "]";
+    LogNum(&oplog_, "version", servant.version);
+    LogNum(&oplog_, "num_processors", (long long)servant.num_processors);
+    LogNum(&oplog_, "current_load", (long long)servant.current_load);
+    LogNum(&oplog_, "total_memory", (long long)servant.total_memory_in_bytes);
+    LogNum(&oplog_, "memory_available", (long long)servant.memory_available_in_bytes);
+    LogNum(&oplog_, "max_tasks", (long long)servant.max_tasks);
+    LogNum(&oplog_, "priority", servant.priority);
+    LogNum(&oplog_, "reason", servant.not_accepting_task_reason);
+    oplog_ += "}";
+  }
   auto assign_scalars = [&](ServantPersonality& p) {
     p.version = servant.version;
     p.num_processors = servant.num_processors;
@@ -482,6 +564,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono
     Servant* e = servants_[idx].get();
     ServantPersonality& p = e->personality;
     e->expires_at = now + expires_in;
+    servant_expires_at_[idx] = e->expires_at;
     bool same_envs = p.environments.size() == servant.n_environments;
     for (std::size_t k = 0; same_envs && k != servant.n_environments; ++k)
       same_envs = std::string_view(p.environments[k]) == servant.environments[k];
@@ -534,6 +617,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono
       added->shorter_prefixes.push_back(std::move(prefixes[k]));
     }
     index_of_location_.emplace(p.observed_location, idx);
+    servant_expires_at_.push_back(added->expires_at);
     servants_.push_back(std::move(added));
     row_is_dirty_.push_back(0);
   }
@@ -561,9 +645,26 @@ std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(std::str
   std::vector<std::uint64_t> unknown_tasks;
   Section sec(this);
   const std::uint32_t* known = index_of_location_.find(servant_location);
+  auto log_report = [&] {
+    if (!oplog_on_) return;
+    LogOpen(&oplog_, "report");
+    LogStr(&oplog_, "loc", servant_location);
+    for (int which = 0; which != 2; ++which) {
+      LogKey(&oplog_, which ? "unknown" : "ids");
+      oplog_ += "[";
+      const std::size_t m = which ? unknown_tasks.size() : n;
+      for (std::size_t i = 0; i != m; ++i) {
+        if (i) oplog_ += ", ";
+        oplog_ += std::to_string(which ? unknown_tasks[i] : tasks[i].task_grant_id);
+      }
+      oplog_ += "]";
+    }
+    oplog_ += "}";
+  };
   if (!known) {  // :241-243: the servant itself has expired — every reported id comes back
     unknown_tasks.reserve(n);
     for (std::size_t i = 0; i != n; ++i) unknown_tasks.push_back(tasks[i].task_grant_id);
+    log_report();
     return unknown_tasks;
   }
   Servant* servant = servants_[*known].get();
@@ -584,6 +685,7 @@ std::vector<std::uint64_t> GpuTaskDispatcher::NotifyServantRunningTasks(std::str
     }
   }
   running_task_bookkeeper_.SetServantRunningTasks(servant_location, tasks, kept.data(), kept.size());
+  log_report();
   return unknown_tasks;
 }
 
@@ -596,21 +698,32 @@ std::vector<RunningTask> GpuTaskDispatcher::GetRunningTasks() const {
 // ---------------------------------------------------------------------------
 bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanoseconds new_expires_in) {
   Section sec(this);
+  const auto now = Now();
   Task* t = tasks_.find(task_id);
-  if (!t) return false;        // :146-153
-  if (t->zombie) return false;  // :154-162
-  t->expires_at = Now() + new_expires_in;
+  const bool ok = t && !t->zombie;  // :146-153, :154-162
+  if (oplog_on_) {
+    LogOpen(&oplog_, "renew");
+    LogNum(&oplog_, "now", now.time_since_epoch().count());
+    LogNum(&oplog_, "id", (long long)task_id);
+    LogNum(&oplog_, "lease", new_expires_in.count());
+    LogNum(&oplog_, "ok", ok);
+    oplog_ += "}";
+  }
+  if (!ok) return false;
+  const std::int64_t filed_under = LeaseWheel::SecondOf(t->expires_at);
+  t->expires_at = now + new_expires_in;
+  if (LeaseWheel::SecondOf(t->expires_at) != filed_under) FileLease(task_id, t->expires_at);
   return true;
 }
 
-void GpuTaskDispatcher::LockBriefly(std::unique_lock<std::mutex>& lk) {
-  for (int spins = 0; spins < 4000; ++spins) {
-    if (lk.try_lock()) return;
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-  }
-  lk.lock();
+void GpuTaskDispatcher::FileLease(std::uint64_t id, Clock::time_point expires_at) {
+  lease_wheel_.File(id, expires_at);
+  // Renewals and early frees leave entries behind; swept when they dominate.
+  if (lease_wheel_.entries() > 4 * tasks_.size() + (1u << 20))
+    lease_wheel_.Sweep([this](std::uint64_t i, std::int64_t second) {
+      const Task* t = tasks_.find(i);
+      return t && !t->zombie && LeaseWheel::SecondOf(t->expires_at) == second;
+    });
 }
 
 bool GpuTaskDispatcher::UnsafeApplyQueuedFrees() {
@@ -621,8 +734,19 @@ bool GpuTaskDispatcher::UnsafeApplyQueuedFrees() {
     ids.swap(free_queue_);
     free_queued_.store(0, std::memory_order_seq_cst);
   }
+  return UnsafeApplyFrees(ids);
+}
+
+bool GpuTaskDispatcher::UnsafeApplyFrees(const std::vector<std::uint64_t>& ids) {
   // (n calls, not one call with n ids: an unknown id ends a call, not the others — :176-180)
-  for (std::uint64_t id : ids) UnsafeFreeTasks(&id, 1);
+  for (std::uint64_t id : ids) {
+    if (oplog_on_) {
+      LogOpen(&oplog_, "free");
+      LogNum(&oplog_, "id", (long long)id);
+      oplog_ += "}";
+    }
+    UnsafeFreeTasks(&id, 1);
+  }
   return !ids.empty();
 }
 
@@ -635,6 +759,7 @@ void GpuTaskDispatcher::FreeTasks(const std::uint64_t* task_ids, std::size_t n) 
     free_queue_.insert(free_queue_.end(), task_ids, task_ids + n);
     free_queued_.fetch_add((std::uint32_t)n, std::memory_order_seq_cst);
   }
+  std::atomic_thread_fence(std::memory_order_seq_cst);  // (pairs with the one in ~Section)
   std::unique_lock lk(allocation_lock_, std::try_to_lock);
   if (!lk.owns_lock()) {
     // Somebody is in the middle of a device turn: it applies the ids when it is done (Section).
@@ -688,12 +813,18 @@ void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant, const RunningTask
 void GpuTaskDispatcher::OnExpirationTimer() {
   auto now = Now();
   Section sec(this);
+  const std::uint64_t t_in = NowNs();
+  if (oplog_on_) {
+    LogOpen(&oplog_, "timer");
+    LogNum(&oplog_, "now", now.time_since_epoch().count());
+    oplog_ += "}";
+  }
 
   // Expired servants leave the registry; the order of the others is kept
   // because it decides ties (:503-516).
   std::vector<std::uint32_t> expired;
-  for (std::uint32_t i = 0; i != servants_.size(); ++i)
-    if (servants_[i]->expires_at < now) expired.push_back(i);
+  for (std::uint32_t i = 0; i != servant_expires_at_.size(); ++i)
+    if (servant_expires_at_[i] < now) expired.push_back(i);
   std::vector<std::uint64_t> orphans;
   std::vector<std::unique_ptr<Servant>> removed;  // alive until their orphans are freed
   if (!expired.empty()) {
@@ -721,11 +852,15 @@ void GpuTaskDispatcher::OnExpirationTimer() {
         s->removed = true;
         removed.push_back(std::move(servants_[i]));
       } else {
-        if (w != i) servants_[w] = std::move(servants_[i]);
+        if (w != i) {
+          servants_[w] = std::move(servants_[i]);
+          servant_expires_at_[w] = servant_expires_at_[i];
+        }
         ++w;
       }
     }
     servants_.resize(w);
+    servant_expires_at_.resize(w);
     for (std::uint32_t i = 0; i != servants_.size(); ++i) {
       servants_[i]->index = i;
       *index_of_location_.find(servants_[i]->personality.observed_location) = i;
@@ -748,12 +883,26 @@ void GpuTaskDispatcher::OnExpirationTimer() {
 
   // Expired leases become zombies; they keep their slot until the servant's
   // next heartbeat no longer lists them (:523-535, task_dispatcher.h:207-214).
-  tasks_.for_each([&](std::uint64_t, Task& t) {
-    if (!t.zombie && t.expires_at < now) {
-      t.zombie = true;
-      ++t.servant->n_zombies;
-    }
-  });
+  // Only the leases filed under the seconds up to `now` are looked at (LeaseWheel), not every lease.
+  std::uint64_t seen = 0;
+  lease_wheel_.Due(
+      now,
+      [&](std::uint64_t id, std::int64_t second) {
+        ++seen;
+        const Task* t = tasks_.find(id);
+        return t && !t->zombie && LeaseWheel::SecondOf(t->expires_at) == second;
+      },
+      [&](std::uint64_t id) {
+        Task* t = tasks_.find(id);
+        if (!(t->expires_at < now)) return false;
+        t->zombie = true;
+        ++t->servant->n_zombies;
+        return true;
+      });
+  ++host_stats_.timer_ticks;
+  host_stats_.timer_lease_entries_seen = seen;
+  host_stats_.timer_last_ns = NowNs() - t_in;
+  host_stats_.timer_max_ns = std::max(host_stats_.timer_max_ns, host_stats_.timer_last_ns);
 }
 
 // ---------------------------------------------------------------------------
@@ -874,12 +1023,6 @@ GpuTaskDispatcher::HostColumn::~HostColumn() {
   }
 }
 
-namespace {
-inline std::uint64_t NowNs() {
-  return (std::uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-             std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-}  // namespace
 
 int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
   const std::uint32_t n = (std::uint32_t)batch.n;
@@ -993,6 +1136,7 @@ std::uint64_t GpuTaskDispatcher::UnsafeGrant(const RequestView& r, std::uint32_t
   if (pick->grants_head != kNoTask) tasks_.slot(pick->grants_head)->prev = task_id;
   pick->grants_head = task_id;
   ++pick->n_grants;
+  FileLease(task_id, t->expires_at);
   return task_id;
 }
 
@@ -1024,29 +1168,43 @@ void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
   auto now = Now();
   for (std::size_t i = 0; i != batch.size(); ++i) {
     Pending* r = batch[i];
+    ++r->tries;
     if (out[i] == YDC_IDX_ENV_NOT_FOUND) {
       r->done = true;  // :105-108
       r->result.ok = false;
       r->result.status = WaitStatus::EnvironmentNotFound;
+      if (oplog_on_) LogWait(r->request, r->expires_in, now, 1, 0, nullptr, r->tries);
     } else if (out[i] == YDC_IDX_TIMEOUT) {
       r->tried_epoch = wake_epoch_;  // stays pending until its deadline (:116-118)
+      if (oplog_on_) LogWait(r->request, r->expires_in, now, 2, 0, nullptr, r->tries);
     } else {
       r->done = true;
       r->result.ok = true;
       r->result.allocation.task_id = UnsafeGrant(r->request, col_digest_name_[i], out[i], r->expires_in, now);
       r->result.allocation.servant_location = servants_[out[i]]->personality.observed_location;
+      if (oplog_on_) LogWait(r->request, r->expires_in, now, 0, r->result.allocation.task_id, servants_[out[i]].get(), r->tries);
     }
   }
   host_stats_.host_ns += (NowNs() - t0) - (host_stats_.device_ns - dev0);
 }
 
 void GpuTaskDispatcher::UnsafeDrainQueue() {
+  // The queued frees and the queued requests are taken in ONE acquisition of queue_lock_, and the
+  // frees applied first: a thread that called FreeTask and then WaitForStartingNewTask pushed them
+  // in that order, so a turn that places its request has applied its free (the reference's
+  // FreeTask is synchronous, task_dispatcher.cc:165-188 — program order must survive the queue).
+  std::vector<std::uint64_t> frees;
   {
     std::scoped_lock _(queue_lock_);
+    if (!free_queue_.empty()) {
+      frees.swap(free_queue_);
+      free_queued_.store(0, std::memory_order_seq_cst);
+    }
     waiting_.insert(waiting_.end(), queue_.begin(), queue_.end());
     queue_.clear();
     queued_.store(0, std::memory_order_relaxed);
   }
+  UnsafeApplyFrees(frees);
   // One device batch, arrival order. A parked request is only retried after FreeTask has
   // woken the waiters (wake_epoch_): in the reference a waiter sleeps until notify_all or
   // its deadline, and a heartbeat wakes nobody (task_dispatcher.cc:116-118,187,190-220).
@@ -1170,11 +1328,18 @@ int GpuTaskDispatcher::UnsafePlaceAndGrant(std::size_t n, const RequestView* req
   for (std::size_t i = 0; i != n; ++i) {
     if (out[i] >= YDC_IDX_ENV_NOT_FOUND) {
       // EnvironmentNotFound (:105-108) / Timeout — timeout == now (:116-118)
+      if (oplog_on_) LogWait(requests[i], expires_in, now, out[i] == YDC_IDX_ENV_NOT_FOUND ? 1 : 2, 0, nullptr);
       sink(i, out[i] == YDC_IDX_ENV_NOT_FOUND ? 1 : 2, ~0ull, nullptr);
       continue;
     }
     const std::uint64_t id = UnsafeGrant(requests[i], col_digest_name_[i], out[i], expires_in, now);
+    if (oplog_on_) LogWait(requests[i], expires_in, now, 0, id, servants_[out[i]].get());
     if (!sink(i, 0, id, servants_[out[i]].get())) {
+      if (oplog_on_) {
+        LogOpen(&oplog_, "free");
+        LogNum(&oplog_, "id", (long long)id);
+        oplog_ += "}";
+      }
       UnsafeFreeTasks(&id, 1);
       worst = YDC_ERR_CAPACITY;
     }
@@ -1334,7 +1499,13 @@ std::string GpuTaskDispatcher::DumpInternals() {
   j += ",\"gpu\":{\"device\":" + std::to_string(options_.device) +
        ",\"device_status\":" + std::to_string(device_status_) +
        ",\"environments_interned\":" + std::to_string(env_ids_.size()) +
-       ",\"environment_mask_words\":" + std::to_string(EnvWords()) + "}";
+       ",\"environment_mask_words\":" + std::to_string(EnvWords());
+  ydc_stats ds;
+  if (ctx_ && ydc_get_stats(ctx_, &ds) == YDC_OK)  // which device path served the calls so far
+    j += ",\"tick_resident_calls\":" + std::to_string(ds.tick_resident_calls) +
+         ",\"tick_launched_calls\":" + std::to_string(ds.tick_launched_calls) +
+         ",\"pipeline_batches\":" + std::to_string(ds.pipeline_batches);
+  j += "}";
   j += "}";
   return j;
 }

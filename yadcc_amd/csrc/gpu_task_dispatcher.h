@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -237,8 +238,23 @@ class GpuTaskDispatcher {
     std::uint64_t requests = 0, batches = 0, device_ns = 0, host_ns = 0;
     std::uint64_t heartbeats = 0, heartbeats_unchanged = 0, bookkeeper_rebuilds = 0;
     std::uint64_t lease_pages = 0;
+    // What the last OnExpirationTimer looked at (lease entries of the due buckets, not all leases),
+    // how long it held the lock, and the longest any of them did.
+    std::uint64_t timer_ticks = 0, timer_lease_entries_seen = 0, timer_last_ns = 0, timer_max_ns = 0;
+    std::uint64_t lease_wheel_entries = 0;
   };
   HostStats host_stats() const;
+
+  // ---- test switch: the order in which calls took effect ----
+  // With the log on, every call that reads or changes the dispatcher's state appends one record
+  // at the moment it takes effect, under allocation_lock_: each placement attempt of a request
+  // (requestor, digest, min_version, lease, clock reading, answer), each FreeTask id, lease renewal,
+  // heartbeat (the whole personality), servant report and timer tick. Concurrent callers are
+  // linearizable iff replaying that sequence through the reference, single-threaded, gives the
+  // same answers and the same final state — tests/td_scenarios.py does exactly that. Off by
+  // default; costs one branch per call when off.
+  void EnableOpLog(bool on);
+  std::string TakeOpLog();  // a JSON array; the log is emptied
 
   // task_dispatcher.cc:498-536. Public so that a host without the timer thread
   // (tests, a fiber runtime's own timer) can drive it.
@@ -328,6 +344,73 @@ class GpuTaskDispatcher {
     FlatStringMap<std::uint32_t> ids_;
     std::deque<std::string> names_;
   };
+  // Leases filed under the second in which they run out. The reference's timer walks every
+  // lease once a second under the lock (task_dispatcher.cc:523-535); here OnExpirationTimer opens
+  // only the buckets that are due. A renewal (KeepTaskAlive) files the lease again under its
+  // new second and leaves the old entry behind: an entry counts only while the lease still
+  // exists, is no zombie, and runs out in the second of the bucket it is found in. Stale
+  // entries go with their bucket — or, when they outnumber the live leases four to one, in a sweep.
+  class LeaseWheel {
+   public:
+    static std::int64_t SecondOf(Clock::time_point t) {
+      const std::int64_t ns = t.time_since_epoch().count();
+      return ns >= 0 ? ns / 1000000000 : -((-ns + 999999999) / 1000000000);  // floor
+    }
+    void File(std::uint64_t id, Clock::time_point expires_at) {
+      const std::int64_t second = SecondOf(expires_at);
+      if (!last_ || last_second_ != second) {
+        last_ = &buckets_[second];  // (std::map: the address of a mapped vector is stable)
+        last_second_ = second;
+      }
+      last_->push_back(id);
+      ++entries_;
+    }
+    // still(id, second) -> the entry counts; expire(id) -> true: done with it (marked), false: its
+    // lease runs out later in the second `now` lies in — the entry stays.
+    template <class Still, class Expire>
+    void Due(Clock::time_point now, Still&& still, Expire&& expire) {
+      const std::int64_t this_second = SecondOf(now);
+      while (!buckets_.empty() && buckets_.begin()->first <= this_second) {
+        auto it = buckets_.begin();
+        std::vector<std::uint64_t>& ids = it->second;
+        std::size_t kept = 0;
+        for (std::uint64_t id : ids)
+          if (still(id, it->first) && !expire(id)) ids[kept++] = id;
+        entries_ -= ids.size() - kept;
+        if (kept != 0 && it->first == this_second) {
+          ids.resize(kept);
+          break;  // (the bucket of the running second: looked at again next time)
+        }
+        if (last_ == &ids) last_ = nullptr;
+        buckets_.erase(it);
+      }
+    }
+    template <class Still>
+    void Sweep(Still&& still) {
+      for (auto it = buckets_.begin(); it != buckets_.end();) {
+        std::vector<std::uint64_t>& ids = it->second;
+        std::size_t kept = 0;
+        for (std::uint64_t id : ids)
+          if (still(id, it->first)) ids[kept++] = id;
+        entries_ -= ids.size() - kept;
+        ids.resize(kept);
+        if (kept == 0) {
+          if (last_ == &ids) last_ = nullptr;
+          it = buckets_.erase(it);
+        } else {
+          ++it;
+        }
+      }
+    }
+    std::size_t entries() const { return entries_; }
+    std::size_t buckets() const { return buckets_.size(); }
+
+   private:
+    std::map<std::int64_t, std::vector<std::uint64_t>> buckets_;
+    std::vector<std::uint64_t>* last_ = nullptr;  // the bucket of the last File (a batch's grants share it)
+    std::int64_t last_second_ = 0;
+    std::size_t entries_ = 0;
+  };
   struct EnvEntry {
     std::uint32_t bit = 0, refs = 0, name = 0;  // mask bit, servants' references, NamePool id
   };
@@ -337,15 +420,12 @@ class GpuTaskDispatcher {
     Clock::time_point deadline;
     bool done = false;                   // (the thread that holds allocation_lock_)
     std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
+    std::uint32_t tries = 0;            // placement attempts so far (1 unless it was parked)
     WaitResult result;
     // Set by the thread that placed this request for its owner, as its LAST access to the record:
     // the owner — spinning for it instead of sleeping on the lock — may return at once.
     std::atomic<bool> published{false};
   };
-  // allocation_lock_ for a short critical section: a holder is a few microseconds from releasing
-  // it (one device turn), a sleep on the futex and the wake-up cost ten times that.
-  void LockBriefly(std::unique_lock<std::mutex>& lk);
-
   // FreeTask never waits for a device turn of somebody else's: when allocation_lock_ is taken its
   // ids are queued, and whoever holds the lock applies them — on entering its critical section
   // and again after leaving it (Section) — in arrival order, each id a FreeTask call of its own.
@@ -358,11 +438,11 @@ class GpuTaskDispatcher {
   // word — shared, in their caches — and go for the lock's own cache line only when it says free).
   std::atomic<bool> busy_{false};
   bool UnsafeApplyQueuedFrees();  // true: something was applied (waiters were woken)
+  bool UnsafeApplyFrees(const std::vector<std::uint64_t>& ids);
   // allocation_lock_ held for a scope.
   class Section {
    public:
-    explicit Section(GpuTaskDispatcher* d, bool brief = false) : d_(d), lk_(d->allocation_lock_, std::defer_lock) {
-      if (brief) d->LockBriefly(lk_); else lk_.lock();
+    explicit Section(GpuTaskDispatcher* d) : d_(d), lk_(d->allocation_lock_) {
       d->busy_.store(true, std::memory_order_relaxed);
       d->UnsafeApplyQueuedFrees();
     }
@@ -375,6 +455,11 @@ class GpuTaskDispatcher {
       for (;;) {
         d_->busy_.store(false, std::memory_order_relaxed);
         lk_.unlock();
+        // Store-buffering with FreeTasks ("queue the ids; fence; try_lock" there, "unlock; fence;
+        // look at the queue" here): with a full fence on both sides either that try_lock sees the
+        // lock free, or this load sees the queued ids. A failed try_lock orders nothing by itself
+        // in the C++ model — the fences do not lean on the mutex implementation's own barriers.
+        std::atomic_thread_fence(std::memory_order_seq_cst);
         if (d_->free_queued_.load(std::memory_order_seq_cst) == 0) return;
         if (!lk_.try_lock()) return;  // (the new holder applies them, on its way in or out)
         d_->busy_.store(true, std::memory_order_relaxed);
@@ -435,7 +520,12 @@ class GpuTaskDispatcher {
   std::vector<std::unique_ptr<Servant>> servants_;  // registration order == tie-break order
   FlatStringMap<std::uint32_t> index_of_location_;
   std::uint64_t next_servant_uid_ = 1;
+  // expires_at of servants_[i], side by side: what the timer scans every second (16k servants:
+  // 128 KB in a row instead of 16k records behind pointers).
+  std::vector<Clock::time_point> servant_expires_at_;
   TaskTable tasks_;
+  LeaseWheel lease_wheel_;
+  void FileLease(std::uint64_t id, Clock::time_point expires_at);
   NamePool names_;
   std::uint64_t next_task_id_ = 0;  // task_dispatcher.h:218
   std::uint64_t wake_epoch_ = 0;  // bumped where the reference notifies its waiters (:187)
@@ -505,6 +595,10 @@ class GpuTaskDispatcher {
 
   RunningTaskBookkeeper running_task_bookkeeper_;
   HostStats host_stats_;  // guarded by allocation_lock_
+  bool oplog_on_ = false;  // guarded by allocation_lock_, like the log itself
+  std::string oplog_;
+  void LogWait(const RequestView& r, std::chrono::nanoseconds lease, Clock::time_point now, int status,
+               std::uint64_t id, const Servant* pick, std::uint32_t attempt = 1);
 
   std::thread timer_;
   std::mutex timer_lock_;

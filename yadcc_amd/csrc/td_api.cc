@@ -16,7 +16,7 @@ using namespace std::literals;
 struct ydc_td {
   std::atomic<std::int64_t> fake_now_ns{0};
   std::unique_ptr<ydc::GpuTaskDispatcher> impl;
-  std::string dump;
+  std::string dump, oplog;
 };
 
 namespace {
@@ -253,6 +253,11 @@ int ydc_td_host_stats(ydc_td* td, ydc_td_stats* out) {
   out->heartbeats_unchanged = s.heartbeats_unchanged;
   out->bookkeeper_rebuilds = s.bookkeeper_rebuilds;
   out->lease_pages = s.lease_pages;
+  out->timer_ticks = s.timer_ticks;
+  out->timer_lease_entries_seen = s.timer_lease_entries_seen;
+  out->timer_last_ns = s.timer_last_ns;
+  out->timer_max_ns = s.timer_max_ns;
+  out->lease_wheel_entries = s.lease_wheel_entries;
   return YDC_OK;
 }
 
@@ -266,6 +271,18 @@ const char* ydc_td_dump_internals(ydc_td* td) {
   if (!td) return "{}";
   td->dump = td->impl->DumpInternals();
   return td->dump.c_str();
+}
+
+int ydc_td_oplog_enable(ydc_td* td, int on) {
+  if (!td) return YDC_ERR_INVALID_ARGUMENT;
+  td->impl->EnableOpLog(on != 0);
+  return YDC_OK;
+}
+
+const char* ydc_td_oplog_take(ydc_td* td) {
+  if (!td) return "[]";
+  td->oplog = td->impl->TakeOpLog();
+  return td->oplog.c_str();
 }
 
 }  // extern "C"

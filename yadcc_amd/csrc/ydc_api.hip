@@ -327,7 +327,7 @@ struct ydc_context {
   hipStream_t res_stream = nullptr;
   hipEvent_t res_ev = nullptr;
   bool res_live = false;  // a resident kernel was launched and has not been seen to leave
-  uint64_t tick_resident = 0, tick_launches = 0;
+  uint64_t tick_resident = 0, tick_launches = 0, pipeline_batches = 0;
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
   uint32_t opt_target_chunks = 2048;
@@ -737,7 +737,7 @@ int ydc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int ydc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? YDC_OK : YDC_ERR_HIP;
 }
-uint32_t ydc_abi_version(void) { return 5; }
+uint32_t ydc_abi_version(void) { return 6; }
 
 int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t max_slots,
                void* stream, ydc_context** out) {
@@ -1806,6 +1806,7 @@ int read_outcome(ydc_context* c, const BatchPlan& p, uint32_t first, uint32_t la
 void fill_stats(ydc_context* c, const BatchPlan& p, uint32_t rounds) {
   ydc_stats& s = c->stats;
   std::memset(&s, 0, sizeof(s));
+  ++c->pipeline_batches;
   s.n_tasks = p.N;
   s.n_servants = p.S;
   s.n_classes = p.C;
@@ -4233,6 +4234,9 @@ int ydc_debug_phase_probe(unsigned long long* out, size_t n_words, int clear) {
 int ydc_get_stats(const ydc_context* c, ydc_stats* out) {
   if (!c || !out) return YDC_ERR_INVALID_ARGUMENT;
   *out = c->stats;
+  out->tick_resident_calls = (uint32_t)c->tick_resident;
+  out->tick_launched_calls = (uint32_t)c->tick_launches;
+  out->pipeline_batches = (uint32_t)c->pipeline_batches;
   return YDC_OK;
 }
 

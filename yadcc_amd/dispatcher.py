@@ -20,7 +20,7 @@ TD_SYMBOLS = (
     "ydc_td_wait_for_starting_new_tasks", "ydc_td_keep_task_alive", "ydc_td_free_task",
     "ydc_td_free_tasks", "ydc_td_host_stats", "ydc_td_running_tasks_acquire", "ydc_td_running_tasks_release",
     "ydc_td_notify_servant_running_tasks", "ydc_td_get_running_tasks",
-    "ydc_td_on_expiration_timer", "ydc_td_dump_internals",
+    "ydc_td_on_expiration_timer", "ydc_td_dump_internals", "ydc_td_oplog_enable", "ydc_td_oplog_take",
 )
 
 
@@ -47,7 +47,9 @@ class _RunningView(C.Structure):
 
 class _TdStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("requests", "batches", "device_ns", "host_ns", "heartbeats",
-                                          "heartbeats_unchanged", "bookkeeper_rebuilds", "lease_pages")]
+                                          "heartbeats_unchanged", "bookkeeper_rebuilds", "lease_pages",
+                                          "timer_ticks", "timer_lease_entries_seen", "timer_last_ns",
+                                          "timer_max_ns", "lease_wheel_entries")]
 
 
 def type_td_functions(L):
@@ -82,6 +84,9 @@ def type_td_functions(L):
         L.ydc_td_on_expiration_timer.argtypes = [C.c_void_p]
         L.ydc_td_dump_internals.argtypes = [C.c_void_p]
         L.ydc_td_dump_internals.restype = C.c_char_p
+        L.ydc_td_oplog_enable.argtypes = [C.c_void_p, C.c_int]
+        L.ydc_td_oplog_take.argtypes = [C.c_void_p]
+        L.ydc_td_oplog_take.restype = C.c_char_p
         L._ydc_td_typed = True
     return L
 
@@ -247,3 +252,14 @@ class GpuTaskDispatcher:
 
     def dump_internals(self):
         return json.loads(self._L.ydc_td_dump_internals(self._h).decode())
+
+    def oplog_enable(self, on=True):
+        """Test switch: record the order in which calls take effect (ydc_td_oplog_enable)."""
+        assert self._L.ydc_td_oplog_enable(self._h, int(on)) == 0
+
+    def oplog_take(self):
+        return json.loads(self._L.ydc_td_oplog_take(self._h).decode())
+
+    def set_clock_ns(self, ns):
+        self._now_ns = int(ns)
+        self._L.ydc_td_set_clock_ns(self._h, self._now_ns)
