@@ -38,13 +38,13 @@ tests/tools/overlap_probe: tests/tools/overlap_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tests/tools/overlap_probe.hip
 tests/tools/atomic_probe: tests/tools/atomic_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tests/tools/atomic_probe.hip
-tools/td_native_bench: tools/td_native_bench.cc yadcc_amd/libydc.so $(HDRS)
-	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tools/td_native_bench.cc \
+tools/td_native_bench: tools/td_native_bench.cc tools/parked_workload.h yadcc_amd/libydc.so $(HDRS)
+	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -Itools -o $@ tools/td_native_bench.cc \
 	    -Lyadcc_amd -lydc -Wl,-rpath,'$$ORIGIN/../yadcc_amd' -lpthread
 # The same tool over the CPU stand-in of the device API (host-side profiling without a GPU).
-tools/td_native_bench_stub: tools/td_native_bench.cc $(HDRS)
+tools/td_native_bench_stub: tools/td_native_bench.cc tools/parked_workload.h $(HDRS)
 	$(MAKE) -s -C tests/native all
-	g++ -O2 -g -std=c++17 -Wall -I$(CSRC) -Iinclude -o $@ tools/td_native_bench.cc \
+	g++ -O2 -g -std=c++17 -Wall -I$(CSRC) -Iinclude -Itools -o $@ tools/td_native_bench.cc \
 	    -Ltests/native -ltd_stub -Wl,-rpath,'$$ORIGIN/../tests/native' -lpthread
 tests/native/harness_test: tests/native/harness_test.cc tests/native/scheduler_harness.cc tests/native/scheduler_harness.h yadcc_amd/libydc.so $(HDRS)
 	g++ -O2 -std=c++17 -Wall -I$(CSRC) -Iinclude -Itests/native -o $@ tests/native/harness_test.cc tests/native/scheduler_harness.cc \

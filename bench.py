@@ -323,6 +323,29 @@ def td_surface(with_reference=True):
             "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
     except Exception as e:  # noqa: BLE001
         out["concurrent_callers_2k_servants"] = {"error": str(e)}
+    # The 1 s expiration timer running, as the reference always has it (task_dispatcher.cc:81-82,
+    # 498-536): single-request latency with 10^5 / 10^6 live leases in the table, timer off and on.
+    for name, argv in (("timer_2k_servants_100k_leases", ["timer", "2000", "100000", "3"]),
+                       ("timer_16k_servants_1M_leases", ["timer", "16000", "1000000", "4"])):
+        try:
+            r = subprocess.run([tool] + argv, capture_output=True, text=True, timeout=300, cwd=ROOT)
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {
+                "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
+    # The reference's admitted scaling problem (task_dispatcher.h:281-288): K waiters parked on a
+    # saturated pool, one FreeTask at a time. Same workload on both sides (tools/parked_workload.h).
+    try:
+        r = subprocess.run([tool, "parked", "200", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        out["parked_waiters"] = json.loads(r.stdout.strip().splitlines()[-1])["waiters"] if r.returncode == 0 else {
+            "error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+    except Exception as e:  # noqa: BLE001
+        out["parked_waiters"] = {"error": str(e)}
+    if with_reference:
+        try:
+            out["parked_waiters_reference"] = reference_parked()
+        except Exception as e:  # noqa: BLE001
+            out["parked_waiters_reference"] = {"error": str(e)}
     if with_reference:
         try:
             out["reference"] = reference_td_surface()
@@ -366,6 +389,22 @@ def reference_latency(n_servants, calls=None):
     return rec
 
 
+def reference_parked():
+    """cpu_baseline leg of the parked-waiters measurement: the reference class itself, multi-threaded
+    build (oracle/_ref/ref_parked_bench: real clock, real condition variable), same workload. A
+    bounded sample: at 10 000 waiters one FreeTask costs the reference ~0.3 s."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_parked_bench")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/ref_parked_bench is not built"}
+    out = {"kind": "reference", "cores": os.cpu_count()}
+    for argv in (["60", "1", "100", "1000"], ["12", "1", "10000"]):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+        out.update(json.loads(r.stdout.strip().splitlines()[-1])["waiters"])
+    return out
+
+
 def reference_td_surface(n_servants=2000, n_leases=100_000, heartbeats=150):
     """The verbatim reference class (oracle/_ref) on the host: 2k servants, 10^5 live leases;
     KeepServantAlive + NotifyServantRunningTasks of `heartbeats` servants, each reporting the
@@ -401,12 +440,18 @@ def reference_td_surface(n_servants=2000, n_leases=100_000, heartbeats=150):
     for _ in range(polls):
         listed = len(d.get_running_tasks(cap=n_leases))
     poll_secs = time.perf_counter() - t0
+    # OnExpirationTimer with that many leases in the table (it walks all of them, :523-535)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        R.fire_timers()
+    timer_ms = 1e3 * (time.perf_counter() - t0) / 5
     d.close()
     return {"kind": "reference", "cores": 1, "servants": n_servants, "leases": int(ok.sum()),
             "wait_for_starting_new_task_per_s": float(ok.sum()) / wait_secs,
             "heartbeats_per_s": heartbeats / hb_secs, "us_per_heartbeat": 1e6 * hb_secs / heartbeats,
             "reported_tasks_per_heartbeat": reported / heartbeats,
             "get_running_tasks_per_s": polls / poll_secs, "running_tasks_listed": listed,
+            "expiration_timer_tick_ms": timer_ms,
             "sample": "%d heartbeats (KeepServantAlive + NotifyServantRunningTasks), %d GetRunningTasks "
                       "calls, %.1f s" % (heartbeats, polls, hb_secs + poll_secs)}
 
@@ -1095,9 +1140,19 @@ def driver_line(full):
                 s["call_us_%dk_servants" % (S // 1000)] = {
                     "p50": one.get("p50"), "p99": one.get("p99"), "p999": one.get("p999"),
                     "reference_p50": ref and ref.get("p50"), "reference_p99": ref and ref.get("p99")}
-        for k in ("timer_on", "parked_waiters"):
-            if k in td:
-                s[k] = td[k]
+        for name, short in (("timer_2k_servants_100k_leases", "timer_on_100k_leases_us"),
+                            ("timer_16k_servants_1M_leases", "timer_on_1M_leases_us")):
+            t = td.get(name, {}).get("timer_on")
+            if isinstance(t, dict):
+                s[short] = {k: t.get(k) for k in ("p50", "p99", "p999", "max", "timer_max_us")}
+        pw, pr = td.get("parked_waiters", {}), td.get("parked_waiters_reference", {})
+        if isinstance(pw, dict) and "error" not in pw:
+            s["parked_waiters"] = {
+                k: {"wake_to_grant_us_p50": v["wake_to_grant_us"]["p50"], "wake_to_grant_us_p99": v["wake_to_grant_us"]["p99"],
+                    "frees_per_s": v["frees_per_s"],
+                    "reference_wake_us_p50": pr.get(k, {}).get("wake_to_grant_us", {}).get("p50"),
+                    "reference_frees_per_s": pr.get(k, {}).get("frees_per_s")}
+                for k, v in pw.items() if isinstance(v, dict)}
         cc = td.get("concurrent_callers_2k_servants")
         if isinstance(cc, dict) and "error" not in cc:
             s["concurrent_calls_per_s"] = {k: v.get("calls_per_s") for k, v in cc.items() if isinstance(v, dict)}

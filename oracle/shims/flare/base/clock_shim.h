@@ -14,8 +14,13 @@ inline std::int64_t& FakeNowNs() {
 }  // namespace flare::shim
 namespace flare {
 inline std::chrono::steady_clock::time_point ReadCoarseSteadyClock() {
+#ifdef ORACLE_SHIM_REAL_THREADS
+  // The multi-threaded build (oracle/ref_parked_bench.cc): waiters really sleep until a deadline.
+  return std::chrono::steady_clock::now();
+#else
   return std::chrono::steady_clock::time_point(
       std::chrono::nanoseconds(shim::FakeNowNs()));
+#endif
 }
 inline std::chrono::steady_clock::time_point ReadSteadyClock() {
   return ReadCoarseSteadyClock();

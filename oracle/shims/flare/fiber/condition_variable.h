@@ -8,6 +8,13 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#ifdef ORACLE_SHIM_REAL_THREADS
+// The multi-threaded build (oracle/ref_parked_bench.cc, the parked-waiters baseline): fibers are
+// OS threads there, fiber::Mutex is std::mutex, and this is the real thing.
+namespace flare::fiber {
+using ConditionVariable = std::condition_variable;
+}
+#else
 namespace flare::fiber {
 class ConditionVariable {
  public:
@@ -19,4 +26,5 @@ class ConditionVariable {
   void notify_one() {}
 };
 }  // namespace flare::fiber
+#endif
 #endif

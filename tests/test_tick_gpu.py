@@ -329,3 +329,32 @@ def test_resident_kernel_and_everything_else_interleaved():
             c.set_running(sv["running_tasks"])
     assert np.array_equal(c.get_running(), sv["running_tasks"])
     c.close()
+
+
+def test_resident_kernel_alternating_utilisation():
+    """One context, COMMITting ticks that alternately want and do not want the chosen servants'
+    utilisation (round-5 advisor finding: a resident kernel fixes its utilisation output at launch;
+    a call of the other kind must not be answered from a kernel that never stores it). Small and
+    7+ request batches, every answer and every utilisation against the oracle."""
+    c = binding.Context(device=0)
+    sv, _ = cases.random_case(seed=77, n_tasks=10, n_servants=600, n_envs=2)
+    sv = {k: np.array(v, copy=True) for k, v in sv.items()}
+    c.upload_servants(pack.to_abi_columns(sv))
+    rng = np.random.default_rng(17)
+    resident_before = c.stats()["tick_resident_calls"]
+    for turn in range(60):
+        n = int(rng.choice([1, 3, 7, 8, 20]))
+        tk = synth.make_tasks(n, sv, n_envs=2, seed=int(rng.integers(1 << 30)), self_frac=0.2)
+        want, wutil, wrun = O.dispatch(sv, tk, "scan")
+        want_util = bool((turn // 2) % 2) if turn < 40 else bool(turn % 2)
+        got, gutil = c.dispatch_tick(tk, commit=True, want_util=want_util)
+        assert np.array_equal(got, want), (turn, n, want_util)
+        if want_util:
+            assert np.array_equal(gutil, wutil), (turn, n)
+        assert took_the_tick_kernel(c.stats())
+        sv["running_tasks"] = wrun
+    assert np.array_equal(c.get_running(), sv["running_tasks"])
+    # (pairs of equal calls in the first 40 turns: the second of a pair is answered by the kernel the
+    # first one left resident)
+    assert c.stats()["tick_resident_calls"] - resident_before >= 15
+    c.close()

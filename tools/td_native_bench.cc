@@ -25,6 +25,16 @@
 //       WaitForStartingNewTask + FreeTask from its own requestor address: calls/s of all threads
 //       together and p50 / p99 per call. Callers that arrive while a batch is being placed are
 //       placed together by whoever gets the lock next (gpu_task_dispatcher.cc: the queue).
+//   td_native_bench timer <servants> <leases> <seconds>
+//       single-request latency (as in `latency`) with `leases` live leases in the table, twice: the
+//       dispatcher's own 1 s expiration timer off, and ON (task_dispatcher.cc:81-82,498-536 — the
+//       reference always runs it): p50 / p99 / p99.9 / max per call over `seconds` seconds, and what
+//       the ticks cost (lease entries looked at, lock hold time).
+//   td_native_bench parked <samples> <seconds>
+//       the reference's admitted scaling problem (task_dispatcher.h:281-288): a saturated pool, K =
+//       100 / 1000 / 10000 waiters parked in WaitForStartingNewTask, a releaser freeing one slot at
+//       a time — wake-to-grant latency and frees per second (tools/parked_workload.h; the reference
+//       runs the same workload in oracle/ref_parked_bench.cc).
 // Links libydc.so (GPU) or tests/native/libtd_stub.so (CPU model of the device API: host-side
 // profiling without a GPU). Prints one JSON object.
 #include <algorithm>
@@ -38,6 +48,7 @@
 #include <thread>
 #include <vector>
 
+#include "parked_workload.h"
 #include "yadcc_dispatch.h"
 
 using Clk = std::chrono::steady_clock;
@@ -80,9 +91,9 @@ static void Register(ydc_td* td, int n, std::mt19937_64& rng, int scale, std::ve
   }
 }
 
-static ydc_td* Create() {
+static ydc_td* Create(int start_timer = 0) {
   ydc_td* td = nullptr;
-  if (ydc_td_create(0, nullptr, /*start_timer=*/0, /*fake_clock=*/0, &td) != YDC_OK || !td) {
+  if (ydc_td_create(0, nullptr, start_timer, /*fake_clock=*/0, &td) != YDC_OK || !td) {
     std::fprintf(stderr, "ydc_td_create failed\n");
     std::exit(2);
   }
@@ -441,6 +452,149 @@ static int ConcurrentMode(int n_servants, int calls) {
   return 0;
 }
 
+// `leases` live grants (one-hour leases) spread over the pool, in batches of 100k.
+static bool Prefill(ydc_td* td, std::size_t leases) {
+  const std::size_t batch = std::min<std::size_t>(leases, 100000);
+  if (!batch) return true;
+  std::vector<std::string> ips(batch);
+  std::vector<const char*> ip_ptrs(batch), digest_ptrs(batch);
+  std::vector<std::uint32_t> minv(batch, 20);
+  for (std::size_t i = 0; i < batch; ++i) {
+    ips[i] = "172.17." + std::to_string((i >> 8) & 255) + "." + std::to_string(i & 255);
+    ip_ptrs[i] = ips[i].c_str();
+    digest_ptrs[i] = g_env_ptrs[i % 4];
+  }
+  std::vector<std::int32_t> status(batch);
+  std::vector<std::uint64_t> ids(batch);
+  for (std::size_t live = 0; live < leases;) {
+    const std::size_t n = std::min(batch, leases - live);
+    if (ydc_td_wait_for_starting_new_tasks(td, n, ip_ptrs.data(), minv.data(), digest_ptrs.data(), 3600ll * 1000000000ll,
+                                           nullptr, status.data(), ids.data(), nullptr, 0) < 0)
+      return false;
+    std::size_t got = 0;
+    for (std::size_t i = 0; i < n; ++i) got += status[i] == YDC_TD_GRANTED;
+    if (!got) return false;
+    live += got;
+  }
+  return true;
+}
+
+static int TimerMode(int n_servants, std::size_t leases, double seconds) {
+  std::printf("{\"mode\": \"timer\", \"servants\": %d, \"live_leases\": %zu, \"seconds_per_leg\": %.1f", n_servants, leases, seconds);
+  for (int timer_on = 0; timer_on < 2; ++timer_on) {
+    ydc_td* td = Create(timer_on);
+    std::mt19937_64 rng(5);
+    std::vector<ydc_td_servant> sv;
+    std::vector<std::string> locations;
+    std::vector<std::vector<const char*>> envs;
+    const int scale = std::max<int>(1, (int)(leases * 2 / ((std::size_t)n_servants * 70) + 1));
+    Register(td, n_servants, rng, scale, &sv, &locations, &envs);
+    if (!Prefill(td, leases)) {
+      std::fprintf(stderr, "prefill failed\n");
+      return 1;
+    }
+    std::vector<double> us;
+    us.reserve(1 << 20);
+    char loc[32];
+    std::uint64_t id = 0;
+    const auto t_end = Clk::now() + std::chrono::duration<double>(seconds);
+    for (long r = -200; Clk::now() < t_end; ++r) {
+      const std::string ip = "172.16." + std::to_string((r >> 8) & 255) + "." + std::to_string(r & 255);
+      if ((r & 3) == 3) {
+        const int s = (int)(rng() % n_servants);
+        sv[s].current_load = (sv[s].current_load + 1) % (sv[s].num_processors / 2);
+        ydc_td_keep_servant_alive(td, &sv[s], 3600ll * 1000000000ll);
+      }
+      auto t0 = Clk::now();
+      const int rc = ydc_td_wait_for_starting_new_task(td, ip.c_str(), 20, g_env_ptrs[(unsigned)r % 4], 15ll * 1000000000ll, 0,
+                                                       0, &id, loc, sizeof loc);
+      auto t1 = Clk::now();
+      if (rc < 0) return 1;
+      if (rc == YDC_TD_GRANTED) ydc_td_free_task(td, id);
+      if (r >= 0) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+    }
+    ydc_td_stats hs{};
+    ydc_td_host_stats(td, &hs);
+    std::sort(us.begin(), us.end());
+    double sum = 0;
+    for (double v : us) sum += v;
+    auto q = [&](double f) { return us[std::min(us.size() - 1, (std::size_t)(f * us.size()))]; };
+    std::size_t above50 = us.end() - std::upper_bound(us.begin(), us.end(), 50.0);
+    std::printf(", \"timer_%s\": {\"calls\": %zu, \"p50\": %.2f, \"p99\": %.2f, \"p999\": %.2f, \"max\": %.2f, \"mean\": %.2f, "
+                "\"calls_above_50us\": %zu, \"timer_ticks\": %llu, \"timer_max_us\": %.1f, \"timer_last_us\": %.1f, "
+                "\"lease_entries_seen_last_tick\": %llu, \"lease_index_entries\": %llu}",
+                timer_on ? "on" : "off", us.size(), q(0.5), q(0.99), q(0.999), us.back(), sum / us.size(), above50,
+                (unsigned long long)hs.timer_ticks, hs.timer_max_ns / 1e3, hs.timer_last_ns / 1e3,
+                (unsigned long long)hs.timer_lease_entries_seen, (unsigned long long)hs.lease_wheel_entries);
+    ydc_td_destroy(td);
+  }
+  std::printf("}\n");
+  return 0;
+}
+
+struct TdParkedAdapter {
+  ydc_td* td;
+  std::vector<std::string> ips;
+  bool Wait(int waiter, long long timeout_ms, unsigned long long* id) {
+    std::uint64_t got = 0;
+    char loc[32];
+    const int rc = ydc_td_wait_for_starting_new_task(td, ips[waiter].c_str(), 20, g_env_ptrs[0], 3600ll * 1000000000ll,
+                                                     timeout_ms * 1000000ll, 0, &got, loc, sizeof loc);
+    if (rc < 0) {
+      std::fprintf(stderr, "device error %d\n", rc);
+      std::exit(1);
+    }
+    *id = got;
+    return rc == YDC_TD_GRANTED;
+  }
+  void Free(unsigned long long id) { ydc_td_free_task(td, id); }
+};
+
+static int ParkedMode(int samples, double seconds) {
+  std::printf("{\"mode\": \"parked\", \"pool\": \"64 servants x 4 slots, all taken\", \"waiters\": {");
+  const int ks[] = {100, 1000, 10000};
+  for (int ki = 0; ki < 3; ++ki) {
+    ydc_td* td = Create(/*start_timer=*/1);
+    std::vector<std::string> locations(64);
+    const char* env[1] = {g_env_ptrs[0]};
+    for (int i = 0; i < 64; ++i) {
+      ydc_td_servant s;
+      std::memset(&s, 0, sizeof s);
+      locations[i] = Location(i);
+      s.version = 20;
+      s.observed_location = s.reported_location = locations[i].c_str();
+      s.num_processors = 64;
+      s.priority = 2;
+      s.max_tasks = 4;
+      s.total_memory_in_bytes = 256ull << 30;
+      s.memory_available_in_bytes = 64ull << 30;
+      s.env_digests = env;
+      s.n_envs = 1;
+      if (ydc_td_keep_servant_alive(td, &s, 3600ll * 1000000000ll) != YDC_OK) return 3;
+    }
+    TdParkedAdapter a{td, {}};
+    for (int k = 0; k < ks[ki]; ++k) a.ips.push_back("172.21." + std::to_string(k >> 8) + "." + std::to_string(k & 255));
+    a.ips.push_back("172.22.0.1");
+    std::vector<unsigned long long> initial;
+    for (;;) {
+      unsigned long long id;
+      if (!a.Wait(ks[ki], 0, &id)) break;
+      initial.push_back(id);
+    }
+    if (initial.size() != 256) {
+      std::fprintf(stderr, "pool holds %zu grants, expected 256\n", initial.size());
+      return 1;
+    }
+    parked::Run<TdParkedAdapter> run;
+    run.a = &a;
+    const parked::Result r = run.Go(ks[ki], initial, samples, seconds);
+    parked::Print("ydc_td", r, ki == 2);
+    ydc_td_destroy(td);
+  }
+  std::printf("}}\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   for (int i = 0; i < 4; ++i) {
     char b[80];
@@ -459,6 +613,10 @@ int main(int argc, char** argv) {
     return LatencyMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 1000);
   if (mode == "concurrent")
     return ConcurrentMode(argc > 2 ? std::atoi(argv[2]) : 2000, argc > 3 ? std::atoi(argv[3]) : 2000);
-  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat|latency|concurrent ...\n");
+  if (mode == "timer")
+    return TimerMode(argc > 2 ? std::atoi(argv[2]) : 16000, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 1000000,
+                     argc > 4 ? std::atof(argv[4]) : 4.0);
+  if (mode == "parked") return ParkedMode(argc > 2 ? std::atoi(argv[2]) : 200, argc > 3 ? std::atof(argv[3]) : 2.0);
+  std::fprintf(stderr, "usage: td_native_bench wait|heartbeat|latency|concurrent|timer|parked ...\n");
   return 2;
 }

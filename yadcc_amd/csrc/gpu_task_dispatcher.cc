@@ -787,7 +787,16 @@ void GpuTaskDispatcher::UnsafeFreeTasks(const std::uint64_t* task_ids, std::size
     tasks_.erase(id);
   }
   ++wake_epoch_;
-  allocation_cv_.notify_all();  // :187
+  wake_pending_ = true;  // :187 notify_all — served by this thread before it lets go of the lock
+}
+
+// What the reference's woken waiters do one by one (re-run their loops, :101-119), done for all of
+// them at once by the thread that woke them: the parked requests go through one device batch in
+// arrival order; the owners of those that were served are woken, the others sleep on.
+void GpuTaskDispatcher::UnsafeServeWoken() {
+  if (!wake_pending_) return;
+  wake_pending_ = false;
+  if (!waiting_.empty() || queued_.load(std::memory_order_relaxed) != 0) UnsafeDrainQueue();
 }
 
 void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant, const RunningTaskView* reported,
@@ -1205,6 +1214,7 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
     queued_.store(0, std::memory_order_relaxed);
   }
   UnsafeApplyFrees(frees);
+  wake_pending_ = false;  // (this turn is the retry)
   // One device batch, arrival order. A parked request is only retried after FreeTask has
   // woken the waiters (wake_epoch_): in the reference a waiter sleeps until notify_all or
   // its deadline, and a heartbeat wakes nobody (task_dispatcher.cc:116-118,187,190-220).
@@ -1212,17 +1222,21 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
   for (auto* r : waiting_)
     if (!r->done && r->tried_epoch != wake_epoch_) batch.push_back(r);
   UnsafeDispatch(batch);
-  const std::size_t before = waiting_.size();
+
   // (`batch` is reused for the served ones: after its `published` flag is up a record may be gone)
   batch.clear();
   for (auto* r : waiting_)
     if (r->done) batch.push_back(r);
   waiting_.erase(std::remove_if(waiting_.begin(), waiting_.end(), [](Pending* r) { return r->done; }),
                  waiting_.end());
-  for (auto* r : batch) r->published.store(true, std::memory_order_release);
-  // Requests of other threads may just have been completed by this one: wake their owners
-  // (those that have given up spinning sleep on the condition variable until their deadline).
-  if (waiting_.size() != before) allocation_cv_.notify_all();
+  // Requests of other threads may just have been completed by this one: wake exactly their owners
+  // (those that have given up spinning sleep until their deadline). A sleeping owner cannot return
+  // before this thread lets go of the lock; a spinning one may as soon as `published` is up.
+
+  for (auto* r : batch) {
+    if (r->sleeping) r->cv.notify_one();
+    r->published.store(true, std::memory_order_release);
+  }
 }
 
 WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& personality,
@@ -1272,25 +1286,27 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
     }
     bool timed_out;
     busy_.store(false, std::memory_order_relaxed);  // (the waits below release the lock)
+    req.sleeping = true;
     if (options_.clock) {
       // Injected (test) clock: poll it, do not sleep on the real one.
       timed_out = Now() >= req.deadline;
 #if defined(__SANITIZE_THREAD__)
-      if (!timed_out) allocation_cv_.wait_until(lk, std::chrono::system_clock::now() + 1ms);
+      if (!timed_out) req.cv.wait_until(lk, std::chrono::system_clock::now() + 1ms);
 #else
-      if (!timed_out) allocation_cv_.wait_for(lk, 1ms);
+      if (!timed_out) req.cv.wait_for(lk, 1ms);
 #endif
     } else {
 #if defined(__SANITIZE_THREAD__)
       // GCC 11's libtsan does not intercept pthread_cond_clockwait (what a steady_clock
       // wait compiles to) and then reports the lock as held across the wait; the sanitizer
       // build waits on the system clock (pthread_cond_timedwait) instead.
-      timed_out = allocation_cv_.wait_until(lk, std::chrono::system_clock::now() +
-                                                    (req.deadline - Clock::now())) == std::cv_status::timeout;
+      timed_out = req.cv.wait_until(lk, std::chrono::system_clock::now() +
+                                            (req.deadline - Clock::now())) == std::cv_status::timeout;
 #else
-      timed_out = allocation_cv_.wait_until(lk, req.deadline) == std::cv_status::timeout;
+      timed_out = req.cv.wait_until(lk, req.deadline) == std::cv_status::timeout;
 #endif
     }
+    req.sleeping = false;
     busy_.store(true, std::memory_order_relaxed);
     sleepers_.fetch_sub(1, std::memory_order_seq_cst);
     UnsafeApplyQueuedFrees();

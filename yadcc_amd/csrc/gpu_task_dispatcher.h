@@ -422,6 +422,13 @@ class GpuTaskDispatcher {
     std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     std::uint32_t tries = 0;            // placement attempts so far (1 unless it was parked)
     WaitResult result;
+    // A parked owner sleeps on its OWN condition variable (with allocation_lock_): whoever frees a
+    // slot re-places the parked requests itself, as one device batch, and wakes only the owners of
+    // those it served. The reference wakes every waiter for every FreeTask and lets each of them
+    // scan the registry under the one lock (task_dispatcher.h:281-288 says it does not scale,
+    // .cc:116-118,185-187).
+    std::condition_variable cv;
+    bool sleeping = false;  // inside cv.wait (guarded by allocation_lock_)
     // Set by the thread that placed this request for its owner, as its LAST access to the record:
     // the owner — spinning for it instead of sleeping on the lock — may return at once.
     std::atomic<bool> published{false};
@@ -429,14 +436,18 @@ class GpuTaskDispatcher {
   // FreeTask never waits for a device turn of somebody else's: when allocation_lock_ is taken its
   // ids are queued, and whoever holds the lock applies them — on entering its critical section
   // and again after leaving it (Section) — in arrival order, each id a FreeTask call of its own.
-  // sleepers_: threads asleep (or about to be) on allocation_cv_ hold no lock and apply nothing;
-  // a FreeTask that finds one takes the lock itself, so that its notify_all is not lost.
+  // sleepers_: threads asleep (or about to be) on their condition variable hold no lock and apply
+  // nothing; a FreeTask that finds one takes the lock itself, so that its wake-up is not lost.
+  // wake_pending_: where the reference calls notify_all (:187) this is set; the thread that set it
+  // re-places the parked requests before it lets go of the lock (UnsafeServeWoken).
   std::vector<std::uint64_t> free_queue_;  // guarded by queue_lock_
   std::atomic<std::uint32_t> free_queued_{0};
   std::atomic<std::uint32_t> sleepers_{0};
   // allocation_lock_ is held (a hint for the spinners of WaitForStartingNewTask: they read this
   // word — shared, in their caches — and go for the lock's own cache line only when it says free).
   std::atomic<bool> busy_{false};
+  bool wake_pending_ = false;  // guarded by allocation_lock_
+  void UnsafeServeWoken();
   bool UnsafeApplyQueuedFrees();  // true: something was applied (waiters were woken)
   bool UnsafeApplyFrees(const std::vector<std::uint64_t>& ids);
   // allocation_lock_ held for a scope.
@@ -453,6 +464,7 @@ class GpuTaskDispatcher {
     ~Section() {
       // A FreeTask that found the lock taken has left its ids behind: nobody else may come by soon.
       for (;;) {
+        d_->UnsafeServeWoken();
         d_->busy_.store(false, std::memory_order_relaxed);
         lk_.unlock();
         // Store-buffering with FreeTasks ("queue the ids; fence; try_lock" there, "unlock; fence;
@@ -516,7 +528,7 @@ class GpuTaskDispatcher {
   std::size_t min_memory_for_new_task_ = 0;
 
   mutable std::mutex allocation_lock_;           // task_dispatcher.h:289
-  std::condition_variable allocation_cv_;        // task_dispatcher.h:290
+  // (task_dispatcher.h:290's one condition variable is one per parked request here: Pending::cv)
   std::vector<std::unique_ptr<Servant>> servants_;  // registration order == tie-break order
   FlatStringMap<std::uint32_t> index_of_location_;
   std::uint64_t next_servant_uid_ = 1;

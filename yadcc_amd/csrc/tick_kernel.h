@@ -1032,7 +1032,10 @@ __global__ __launch_bounds__(THREADS) void k_tick(const TickArgs a) {
         if (lane == 12) s_urow[0].flags = word;
         if (lane >= 13 && lane < 16) s_rel[lane - 9] = word;
         const uint32_t nt = (w0 >> 8) & 0xFF, nu = (w0 >> 16) & 0xFF, nr = w0 >> 24;
-        // (what does not fit the head was stored before it; this read follows the head's)
+        // What does not fit the head was stored before it (release stores on the host). The reads of
+        // it below are ordered behind the head's by an acquire fence — only when there is
+        // something to read: a single request, or copies of one, travel in the head alone.
+        if ((nt > 1 && !(w0 & kTickCmdSame)) || nr > 7 || nu > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (nt > 1 && (w0 & kTickCmdSame)) {  // copies of the first request: nothing more to fetch
           const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 1),
                          m0 = (uint32_t)__builtin_amdgcn_readlane((int)word, 2),

@@ -327,6 +327,7 @@ struct ydc_context {
   hipStream_t res_stream = nullptr;
   hipEvent_t res_ev = nullptr;
   bool res_live = false;  // a resident kernel was launched and has not been seen to leave
+  bool res_util = false;  // ... and it stores utilisations (fixed at its launch: TickArgs::out_util)
   uint64_t tick_resident = 0, tick_launches = 0, pipeline_batches = 0;
 
   uint32_t opt_chunk_size = 0;     // 0: automatic
@@ -2257,7 +2258,17 @@ bool box_wait(ydc_context* c, int g, uint32_t seq, uint32_t* word) {
         }
         return false;
       }
-      if (spins > (1u << 30)) return false;
+      // A live kernel that is slow (a preempted GPU, a debugger) is waited for: giving it up and
+      // sending the command again could apply its releases and commit its picks twice. Only a
+      // stream that has ended — finished or faulted — ends the wait.
+      if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(c->res_stream) != hipErrorNotReady) {
+        const unsigned long long w = box_load(p);
+        if ((uint32_t)(w >> 32) == seq) {
+          *word = (uint32_t)w;
+          return true;
+        }
+        return false;
+      }
     }
   }
 }
@@ -2371,6 +2382,9 @@ int tick_run(ydc_context* c, const TickCall& io) {
                         N <= kTickInlineTasks && io.n_upd <= kTickInlineUpd && io.n_rel <= kTickInlineRel &&
                         !c->profiling;
   if (c->res_live && !resident) resident_stop(c);
+  // A resident kernel answers with or without utilisations for its whole life (its out_util is a
+  // launch argument): a call that wants the other kind ends it and launches its own.
+  if (c->res_live && (io.out_util != nullptr) != c->res_util) resident_stop(c);
   if (c->res_live) {
     TickBox* b = c->h_box;
     if (__atomic_load_n(&b->alive, __ATOMIC_ACQUIRE) != 0) {
@@ -2570,6 +2584,7 @@ int tick_run(ydc_context* c, const TickCall& io) {
   ++c->tick_launches;
   if (resident) {
     c->res_live = true;
+    c->res_util = io.out_util != nullptr;
     {
       std::lock_guard<std::mutex> lk(g_resident_mu);
       g_resident.push_back(c);
