@@ -115,7 +115,7 @@ def test_concurrent_callers_linearize(shape):
 
 
 @needs_ref
-@pytest.mark.parametrize("shape", ["roomy", "saturated"])
+@pytest.mark.parametrize("shape", ["roomy", "saturated", "crowd"])
 def test_native_callers_linearize(shape, tmp_path):
     """... with the threads in C++ (tests/native/td_linearize.cc linked against libydc.so): 16
     callers at full speed on 2000 servants (roomy: queued FreeTasks meet the same thread's next
@@ -124,11 +124,14 @@ def test_native_callers_linearize(shape, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "tests/native/td_linearize_gpu"], cwd=root)
-    args = dict(n_servants=2000, n_threads=16, calls=2500) if shape == "roomy" else dict(
-        n_servants=40, n_threads=16, calls=3000, cap=1)
+    args = {"roomy": dict(n_servants=2000, n_threads=16, calls=2500),
+            "saturated": dict(n_servants=40, n_threads=16, calls=3000, cap=1),
+            # more parked requests than a device turn takes: placed again in segments (gpu_task_dispatcher.cc:
+            # UnsafeDispatchSegmented), the known Timeouts not sent at all
+            "crowd": dict(n_servants=40, n_threads=200, calls=300, cap=1)}[shape]
     r = S.native_linearize(os.path.join(root, "tests", "native", "td_linearize_gpu"), str(tmp_path / "lin.json"),
                            seed=5, **args)
-    assert r["records"] > 40000 and r["kinds"]["wait:0"] > 5000
+    assert r["records"] > 40000 and r["kinds"]["wait:0"] > (800 if shape == "crowd" else 5000)
     if shape == "roomy":
         assert r["requests_per_device_turn"] > 1.2  # callers were combined
     else:

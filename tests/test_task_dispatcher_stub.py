@@ -133,7 +133,7 @@ def test_concurrent_callers_linearize(seed):
 
 
 @needs_ref
-@pytest.mark.parametrize("shape", ["roomy", "saturated"])
+@pytest.mark.parametrize("shape", ["roomy", "saturated", "crowd"])
 def test_native_callers_linearize(shape, tmp_path):
     """The same proof with the threads in C++ (tests/native/td_linearize.cc, through the C-ABI): 12
     callers at full speed, so that FreeTask queued behind somebody's device turn and the same
@@ -141,10 +141,13 @@ def test_native_callers_linearize(shape, tmp_path):
     fails here on program order). roomy: nobody parks, frees are queued; saturated: most requests
     park and are retried at FreeTask's wake-ups."""
     subprocess.check_call(["make", "-s", "-C", NATIVE, "linearize"])
-    args = dict(n_servants=300, calls=1500) if shape == "roomy" else dict(n_servants=40, calls=3000, cap=1)
+    args = {"roomy": dict(n_servants=300, calls=1500), "saturated": dict(n_servants=40, calls=3000, cap=1),
+            # crowd: more parked requests than one device turn takes — placed again in segments, those
+            # whose (digest, version, host) already came back Timeout in the turn not sent at all
+            "crowd": dict(n_servants=40, n_threads=160, calls=200, cap=1)}[shape]
     r = S.native_linearize(os.path.join(NATIVE, "td_linearize_stub"), str(tmp_path / "lin.json"), seed=3, **args)
-    assert r["records"] > 20000 and r["kinds"]["wait:0"] > 3000
-    if shape == "saturated":
+    assert r["records"] > 20000 and r["kinds"]["wait:0"] > (500 if shape == "crowd" else 3000)
+    if shape != "roomy":
         assert r["retried_attempts"] > 5000 and r["kinds"]["wait:2"] > 10000
 
 

@@ -313,6 +313,7 @@ class Context:
                                                     lib().ydc_last_error(None).decode()))
         self._h = h
         self.n_servants = 0
+        self._stream_caps = (0, 0, 0)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -526,6 +527,7 @@ class Context:
     def stream_begin(self, max_updates, max_releases, max_tasks):
         self._check(lib().ydc_stream_begin(self._h, max_updates, max_releases, max_tasks),
                     "ydc_stream_begin")
+        self._stream_caps = (int(max_updates), int(max_releases), int(max_tasks))
 
     def stream_tick(self, upd_idx, upd_rows, release_idx, tasks, env_masks=None):
         """upd_rows: numpy structured array of ROW_DTYPE (one heartbeat per entry of upd_idx);
@@ -555,9 +557,15 @@ class Context:
                                                    out.ctypes.data), "ydc_stream_tick_wide")
         return out
 
-    def stream_buffers(self, max_updates, max_releases, max_tasks):
+    def stream_buffers(self, max_updates=None, max_releases=None, max_tasks=None):
         """numpy views of the page-locked arrays a tick is staged in (ydc_stream_buffers_get): fill
-        them in place and call stream_tick_inplace — nothing is copied on either side."""
+        them in place and call stream_tick_inplace — nothing is copied on either side. The views
+        have the capacities stream_begin was given (arguments, if any, may only ask for less)."""
+        caps = self._stream_caps
+        want = (max_updates, max_releases, max_tasks)
+        if any(w is not None and w > c for w, c in zip(want, caps)):
+            raise YdcError("stream_buffers%r: beyond the capacities of stream_begin%r" % (want, caps))
+        max_updates, max_releases, max_tasks = [c if w is None else w for w, c in zip(want, caps)]
         class _B(C.Structure):
             _fields_ = [(k, C.c_void_p) for k in ("upd_idx", "upd_rows", "release_servant_idx", "env_id",
                                                    "min_version", "requestor_ip", "out_servant_idx")]

@@ -444,6 +444,7 @@ std::uint32_t GpuTaskDispatcher::RequestorId(std::string_view ip) {
       const std::uint32_t id = InternIp(ip, true);
       alias_ids_.emplace(ip, id);
       aliases_dirty_ = true;
+      ++registry_epoch_;
       return id;
     }
   }
@@ -576,6 +577,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono
                           p.current_load == servant.current_load && p.max_tasks == servant.max_tasks &&
                           p.priority == servant.priority && low_mem_was == low_mem_is;
     if (!same_envs) {
+      ++registry_epoch_;
       auto bits = AcquireEnvBits(servant.environments, servant.n_environments);
       ReleaseEnvBits(p.environments);
       p.environments.assign(servant.environments, servant.environments + servant.n_environments);
@@ -590,6 +592,7 @@ void GpuTaskDispatcher::KeepServantAlive(const ServantView& servant, std::chrono
     }
   } else {
     idx = (std::uint32_t)servants_.size();
+    ++registry_epoch_;
     auto added = std::make_unique<Servant>();
     added->uid = next_servant_uid_++;
     added->index = idx;
@@ -837,6 +840,7 @@ void GpuTaskDispatcher::OnExpirationTimer() {
   std::vector<std::uint64_t> orphans;
   std::vector<std::unique_ptr<Servant>> removed;  // alive until their orphans are freed
   if (!expired.empty()) {
+    ++registry_epoch_;
     // Device first, while the host rows still have their old positions: the deltas recorded
     // against those positions, then an order-preserving compaction of the resident columns on
     // the device (running_tasks of the survivors stays where it is; no table upload).
@@ -1044,7 +1048,9 @@ int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
   std::uint32_t last_ip_id = 0, last_env = 0xFFFFFFFFu, last_name = 0;
   col_digest_name_.resize(n);
   bool have_ip = false, have_digest = false;
-  for (std::uint32_t i = 0; i != n; ++i) {
+  // (a parked request that is being placed again brings what was looked up for it last time)
+  const bool cached = batch.pending && batch.cached;
+  for (std::uint32_t i = 0; i != n && !cached; ++i) {
     const RequestView& r = batch[i];
     if (!have_ip || r.requestor_ip.data() != last_ip.data() || r.requestor_ip.size() != last_ip.size()) {
       last_ip = r.requestor_ip;
@@ -1070,7 +1076,14 @@ int GpuTaskDispatcher::UnsafePlace(const RequestSpan& batch) {
       std::uint32_t env = 0, name = 0;
     } seen[4];
     unsigned next_seen = 0;  // entries of seen[] in use: min(next_seen, 4) — an unused entry matches nothing
-    for (std::uint32_t i = 0; i != n; ++i) {
+    for (std::uint32_t i = 0; i != n && cached; ++i) {
+      const Pending& q = *batch.pending[i];
+      rip[i] = q.col_rip;
+      env[i] = q.col_env;
+      col_digest_name_[i] = q.col_name;
+      minv[i] = q.request.min_version;
+    }
+    for (std::uint32_t i = 0; i != n && !cached; ++i) {
       const RequestView& r = batch[i];
       const char* dp = r.compiler_digest.data();
       const std::size_t dn = r.compiler_digest.size();
@@ -1156,12 +1169,66 @@ std::string GpuTaskDispatcher::TaskRequestorIp(const Task& t) const {
   return names_.name(name);
 }
 
+void GpuTaskDispatcher::UnsafeCacheColumns(Pending* r) {
+  if (r->cols_epoch == registry_epoch_) return;
+  r->col_rip = RequestorId(r->request.requestor_ip);  // (may create an alias: bumps registry_epoch_)
+  const EnvEntry* e = LookupEnv(r->request.compiler_digest);
+  r->col_env = e ? e->bit : 0xFFFFFFFFu;  // unknown: nobody has it
+  r->col_name = e ? e->name : 0;
+  if (sig_epoch_ != registry_epoch_) {
+    sig_ids_.clear();
+    sig_epoch_ = registry_epoch_;
+  }
+  r->sig = sig_ids_.try_emplace(SigKey{r->col_env, r->request.min_version, r->col_rip},
+                                (std::uint32_t)sig_ids_.size()).first->second;
+  r->cols_epoch = registry_epoch_;
+}
+
+void GpuTaskDispatcher::UnsafeDispatchSegmented(const std::vector<Pending*>& batch) {
+  for (Pending* r : batch) UnsafeCacheColumns(r);
+  for (Pending* r : batch) UnsafeCacheColumns(r);  // (an alias created on the way invalidated earlier ones)
+  sig_dead_.assign(sig_ids_.size(), 0);
+  // Segments of what one resident tick takes; while whole segments are granted the pool evidently
+  // has room, and the segments grow towards one batch of everything that is left.
+  std::size_t cap = 64;
+  std::vector<Pending*> seg;
+  auto flush = [&] {
+    if (seg.empty()) return;
+    UnsafeDispatch(seg);
+    bool any_dead = false;
+    for (Pending* r : seg)
+      if (!r->done && r->result.device_error == 0) {  // Timeout: so will every later request like it
+        sig_dead_[r->sig] = 1;
+        any_dead = true;
+      }
+    if (!any_dead) cap *= 4;
+    seg.clear();
+  };
+  const auto now = Now();
+  for (Pending* r : batch) {
+    if (sig_dead_[r->sig]) {
+      // Not sent: the answer is known. For the reference this was one more turn of the waiter's
+      // loop that found no free servant (task_dispatcher.cc:109-118).
+      ++r->tries;
+      r->tried_epoch = wake_epoch_;
+      if (oplog_on_) LogWait(r->request, r->expires_in, now, 2, 0, nullptr, r->tries);
+      continue;
+    }
+    seg.push_back(r);
+    if (seg.size() >= cap) flush();
+  }
+  flush();
+}
+
 void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
   if (batch.empty()) return;
   const std::uint64_t t0 = NowNs(), dev0 = host_stats_.device_ns;
+  for (Pending* r : batch) UnsafeCacheColumns(r);
+  for (Pending* r : batch) UnsafeCacheColumns(r);  // (an alias created on the way invalidated earlier ones)
   RequestSpan span;
   span.pending = batch.data();
   span.n = batch.size();
+  span.cached = true;
   const int rc = UnsafePlace(span);
   if (rc != YDC_OK) {
     // Fail loudly: every request of the batch gets the device error.
@@ -1221,7 +1288,7 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
   std::vector<Pending*> batch;
   for (auto* r : waiting_)
     if (!r->done && r->tried_epoch != wake_epoch_) batch.push_back(r);
-  UnsafeDispatch(batch);
+  if (batch.size() <= 64) UnsafeDispatch(batch); else UnsafeDispatchSegmented(batch);
 
   // (`batch` is reused for the served ones: after its `published` flag is up a record may be gone)
   batch.clear();

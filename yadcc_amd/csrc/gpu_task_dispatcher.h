@@ -421,6 +421,12 @@ class GpuTaskDispatcher {
     bool done = false;                   // (the thread that holds allocation_lock_)
     std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     std::uint32_t tries = 0;            // placement attempts so far (1 unless it was parked)
+    // The request as the device sees it (interned digest, host id of the requestor), looked up once
+    // and kept while the interning tables stay as they are (registry_epoch_): a parked request is
+    // placed again at every wake-up. sig: the number of its (digest, min_version, host) triple
+    // among the parked requests' (UnsafeDispatchSegmented).
+    std::uint64_t cols_epoch = ~0ull;
+    std::uint32_t col_env = 0, col_rip = 0, col_name = 0, sig = 0;
     WaitResult result;
     // A parked owner sleeps on its OWN condition variable (with allocation_lock_): whoever frees a
     // slot re-places the parked requests itself, as one device batch, and wakes only the owners of
@@ -505,6 +511,7 @@ class GpuTaskDispatcher {
     const RequestView* views = nullptr;
     Pending* const* pending = nullptr;
     std::size_t n = 0;
+    bool cached = false;  // pending[i]'s columns are valid (UnsafeCacheColumns)
     const RequestView& operator[](std::size_t i) const { return views ? views[i] : pending[i]->request; }
   };
   // Places the span as one device batch (COMMIT); the answers (registry index or YDC_IDX_*) are
@@ -517,6 +524,11 @@ class GpuTaskDispatcher {
   int UnsafePlaceAndGrant(std::size_t n, const RequestView* requests, std::chrono::nanoseconds expires_in,
                           Sink&& sink);
   void UnsafeDispatch(const std::vector<Pending*>& batch);
+  // Many parked requests (a saturated pool): placed in arrival order in segments; a (digest,
+  // min_version, requestor host) triple that has come back Timeout in this turn does so for every
+  // later request of the turn — grants only take capacity away — so those are not sent at all.
+  void UnsafeDispatchSegmented(const std::vector<Pending*>& batch);
+  void UnsafeCacheColumns(Pending* r);
   void UnsafeDrainQueue();
   void TimerLoop();
   std::string TaskRequestorIp(const Task& t) const;
@@ -541,6 +553,21 @@ class GpuTaskDispatcher {
   NamePool names_;
   std::uint64_t next_task_id_ = 0;  // task_dispatcher.h:218
   std::uint64_t wake_epoch_ = 0;  // bumped where the reference notifies its waiters (:187)
+  // Bumped whenever a digest / requestor-host lookup may answer differently than before (a servant
+  // registered, changed its environments or expired; an alias was created).
+  std::uint64_t registry_epoch_ = 0;
+  struct SigKey {
+    std::uint32_t env, minv, rip;
+    bool operator==(const SigKey& o) const { return env == o.env && minv == o.minv && rip == o.rip; }
+  };
+  struct SigHash {
+    std::size_t operator()(const SigKey& k) const {
+      return (std::size_t)((k.env * 0x9E3779B97F4A7C15ull) ^ ((std::uint64_t)k.rip << 20) ^ k.minv);
+    }
+  };
+  std::unordered_map<SigKey, std::uint32_t, SigHash> sig_ids_;  // valid for sig_epoch_
+  std::uint64_t sig_epoch_ = ~0ull;
+  std::vector<std::uint8_t> sig_dead_;
 
   // interning
   FlatStringMap<std::uint32_t> ip_ids_;

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -223,7 +224,13 @@ int64_t ydc_td_get_running_tasks(ydc_td* td, uint64_t* out_servant_task_ids,
 
 int ydc_td_running_tasks_acquire(ydc_td* td, void** out_handle, ydc_td_running_view* out_view) {
   if (!td || !out_handle || !out_view) return YDC_ERR_INVALID_ARGUMENT;
-  auto* held = new ydc::RunningTaskBookkeeper::ColumnsSnapshot(td->impl->GetRunningTasksColumns());
+  ydc::RunningTaskBookkeeper::ColumnsSnapshot* held = nullptr;
+  try {  // (the snapshot may have to be built: no exception crosses the C boundary)
+    held = new ydc::RunningTaskBookkeeper::ColumnsSnapshot(td->impl->GetRunningTasksColumns());
+  } catch (const std::exception&) {
+    delete held;
+    return YDC_ERR_CAPACITY;
+  }
   const ydc::RunningTaskColumns& c = **held;
   out_view->n = c.task_grant_ids.size();
   out_view->servant_task_ids = c.servant_task_ids.data();
