@@ -147,6 +147,13 @@ struct MatchBuffers {
   const uint32_t* tile_tab;
   uint32_t tile_tab_tiles, tile_tab_elems;
   uint32_t warm_len;  // the warm-up's length in requests (kWarmUp unless tuned; <= 64)
+  // Checkpoints are taken before every cp_every-th block of 64 requests of a chunk (a power of
+  // two; the chunk's first block always: it says what the chunk was replayed from). Every block
+  // was round 5's choice: 16 B x C per 64 requests, 7.5 MB of a 1M-request batch with 30 classes,
+  // written by every batch and read by the few chunks that are replayed a second time — whose
+  // early stop mostly comes 16 requests in (`early`). Rows of blocks that are not checkpointed are
+  // never read.
+  uint32_t cp_every;
   uint32_t hand_tries;  // polls for the predecessor's granules before giving up (kHandTries; tests: 0)
   // Non-NULL (zone_guess.h): k_zone_guess walks the stretch where the dedicated tier runs out
   // as workgroup 0 of the launch of pass 0 (the chunks are the workgroups behind it) and publishes, as granules {word, batch number}, which chunks
@@ -1204,6 +1211,8 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
     const uint32_t t1 = min(n_tasks, t0 + chunk_size);
     bool stopped_early = false;
 
+    // Is block tb of the chunk that starts at c0 one with a checkpoint in front?
+    auto is_cp = [&](uint32_t tb, uint32_t c0) { return (((tb - c0) >> 6) & (B.cp_every - 1)) == 0; };
     // Requests of a block are staged one block ahead: lane l holds request tb + l.
     uint64_t nx_m[W];
     uint32_t nx_slo, nx_shi;
@@ -1221,7 +1230,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
       for (int j = 0; j < W; ++j) {
         nx_m[j] = (tl < t1 && (uint32_t)j < T.words) ? T.mask[(size_t)tl * T.words + j] : 0;
         const uint32_t c = lane + 64 * j;
-        if (pass != 0 && tb < t1 && c < C) nx_cp[j] = B.checkpoint[(size_t)(tb >> 6) * C + c];
+        if (pass != 0 && tb < t1 && c < C && is_cp(tb, t0)) nx_cp[j] = B.checkpoint[(size_t)(tb >> 6) * C + c];
       }
       if (tl < t1) {
         nx_slo = T.self_lo[tl];
@@ -1247,7 +1256,7 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
     for (uint32_t tb = warm ? t0 - B.warm_len : t0; tb < t1; tb = tb < t0 ? t0 : tb + 64) {
       const bool warm_blk = tb < t0;  // the warm-up requests: picks are made and thrown away
       // ---- checkpoint: stop if the previous replay was in the same state here ----
-      if (!warm_blk) {
+      if (!warm_blk && is_cp(tb, t0)) {
         ClassState* cp = B.checkpoint + (size_t)(tb >> 6) * C;
         bool differs = false;
 #pragma unroll
@@ -1630,12 +1639,14 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
         const uint32_t c = lane + 64 * j;
         if (c < C) {
           const ClassState s = w.state(j);
-          unsigned long long* g = B.hand + ((size_t)kc * C + c) * 4;
+          // (word-major inside the chunk's block: the C lanes of one store write C consecutive
+          // granules — class-major, every lane's 8 bytes went to a 32-byte sector of their own)
+          unsigned long long* g = B.hand + (size_t)kc * C * 4 + c;
           const unsigned long long tag = (unsigned long long)hstamp << 32;
-          __hip_atomic_store(g + 0, tag | s.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(g + 1, tag | s.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(g + 2, tag | s.hown_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(g + 3, tag | s.hown_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 0 * (size_t)C, tag | s.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 1 * (size_t)C, tag | s.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 2 * (size_t)C, tag | s.hown_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 3 * (size_t)C, tag | s.hown_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       YDC_PROBE(probe_kc, 6);  // hand-off published
@@ -1651,11 +1662,11 @@ __global__ __launch_bounds__(64, OCC) void k_match_pass(ClassLists L, TaskTable 
           const uint32_t c = lane + 64 * j;
           pred[j] = ClassState{};
           if (c < C) {
-            unsigned long long* g = B.hand + ((size_t)(kc - 1) * C + c) * 4;
-            const unsigned long long v0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* g = B.hand + (size_t)(kc - 1) * C * 4 + c;
+            const unsigned long long v0 = __hip_atomic_load(g + 0 * (size_t)C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(g + 1 * (size_t)C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v2 = __hip_atomic_load(g + 2 * (size_t)C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v3 = __hip_atomic_load(g + 3 * (size_t)C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             missing |= (uint32_t)(v0 >> 32) != hstamp || (uint32_t)(v1 >> 32) != hstamp ||
                        (uint32_t)(v2 >> 32) != hstamp || (uint32_t)(v3 >> 32) != hstamp;
             pred[j].cursor = (uint32_t)v0;

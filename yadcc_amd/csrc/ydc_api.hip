@@ -375,6 +375,7 @@ struct ydc_context {
   // (binsort_blocked) until the registry changes structure.
   bool opt_fuse_passes = true;  // one GPU: the launch of pass 0 does pass 1 as well (match_kernel.h)
   uint32_t opt_warm_up = 0;  // requests a chunk of pass 0 starts early (1 .. 64; 0: by chunk size)
+  uint32_t opt_cp_every = 4;  // checkpoints before every 4th block of a chunk (MatchBuffers::cp_every)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
   bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
@@ -806,6 +807,11 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("fuse_passes")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = tune_value("warm_up")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = tune_value("hand_tries")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
+  if (const char* s = tune_value("cp_every")) {
+    uint32_t v = (uint32_t)std::max(1, atoi(s)), p2 = 1;
+    while (p2 * 2 <= v && p2 < 1024) p2 *= 2;
+    c->opt_cp_every = p2;
+  }
   if (const char* s = tune_value("level_tab")) c->opt_level_tab = atoi(s) != 0;
   if (const char* s = tune_value("wide")) c->opt_wide = atoi(s) != 0;
   if (const char* s = tune_value("walk_prefetch")) c->opt_walk_prefetch = atoi(s) != 0;
@@ -1373,6 +1379,7 @@ int plan_batch(ydc_context* c, uint32_t N, BatchPlan* out, bool for_window = fal
     p.mb.part_rank_base = c->d_part_base.p;
     p.mb.n_parts = c->n_parts;
     p.mb.early = c->d_early.p;
+    p.mb.cp_every = c->opt_cp_every;
     p.mb.claim = c->d_claim.p;
     p.mb.slot_of = c->d_slot_of.p;
     p.mb.boundary_in = nullptr;
