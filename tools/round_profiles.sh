@@ -23,27 +23,41 @@ cp gpurun_out/prof_cfg5/kernel_stats.txt profiles/${R}_cfg5_kernel_stats.txt
 python tools/rocprof_summary.py hbmtable "cfg2 (100k requests x 2k servants)=profiles/${R}_cfg2_pmc_hbm.json" \
   "cfg3 (1M requests x 8k servants, 4 digests)=profiles/${R}_cfg3_pmc_hbm.json" \
   "cfg4 (4M requests x 16k servants, 4 digests)=profiles/${R}_cfg4_pmc_hbm.json" > profiles/${R}_hbm_utilisation.txt
-# bench lines
-timeout 900 python bench.py --steps 20 --warmup 5 > $F/bench_driver_line.json 2> $F/bench_driver_line.err
-timeout 600 python bench.py --no-extra-configs --steps 2000 --warmup 100 > $F/bench_cfg2.json 2> $F/bench_cfg2.err
-timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --no-pipeline --steps 2000 --warmup 100 > $F/bench_cfg2_sync.json 2> $F/bench_cfg2_sync.err
-timeout 300 python bench.py --config cfg3 --no-cpu-baseline --no-extra-configs --steps 200 --warmup 10 > $F/bench_cfg3.json 2> $F/bench_cfg3.err
-timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-extra-configs --steps 100 --warmup 5 > $F/bench_cfg4.json 2> $F/bench_cfg4.err
-timeout 300 python bench.py --config cfg5 --steps 1000 --warmup 50 > $F/bench_cfg5.json 2> $F/bench_cfg5.err
-timeout 300 python bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > $F/bench_gpus2_one_device.json 2> $F/bench_gpus2_one_device.err
-for c in driver_line cfg2 cfg2_sync cfg3 cfg4 cfg5 gpus2_one_device; do
-  if [ -s $F/bench_$c.json ] && tail -1 $F/bench_$c.json | python -c 'import json,sys; json.loads(sys.stdin.read())' 2>/dev/null; then
-    tail -1 $F/bench_$c.json > profiles/${R}_bench_$c.json
+# bench lines: what the driver parses (the short line) as ..._line.json, everything that was measured
+# in that run (bench_detail.json) as ....json. cfg3 / cfg4 with the reference beside them (the
+# first 100k requests of the batch: 13 s / 27 s of the host's CPU).
+run_bench() {  # <name> <timeout> <bench args...>
+  local name=$1 t=$2; shift 2
+  rm -f bench_detail.json
+  timeout $t python bench.py "$@" > $F/bench_$name.line 2> $F/bench_$name.err
+  if [ -s $F/bench_$name.line ] && tail -1 $F/bench_$name.line | python -c 'import json,sys; json.loads(sys.stdin.read())' 2>/dev/null \
+     && [ -s bench_detail.json ]; then
+    tail -1 $F/bench_$name.line > profiles/${R}_bench_${name}_line.json
+    python -c 'import json,sys; json.dump(json.load(open("bench_detail.json")), open(sys.argv[1], "w"))' profiles/${R}_bench_$name.json
   else
-    echo "no bench line for $c" >&2; tail -3 $F/bench_$c.err >&2
+    echo "no bench line for $name" >&2; tail -3 $F/bench_$name.err >&2
   fi
-done
+}
+run_bench driver_line 1200 --steps 20 --warmup 5
+run_bench cfg2 600 --no-extra-configs --steps 2000 --warmup 100
+run_bench cfg2_sync 300 --no-cpu-baseline --no-extra-configs --no-pipeline --steps 2000 --warmup 100
+run_bench cfg3 400 --config cfg3 --no-extra-configs --steps 200 --warmup 10
+run_bench cfg4 400 --config cfg4 --no-extra-configs --steps 100 --warmup 5
+run_bench cfg5 300 --config cfg5 --steps 1000 --warmup 50
+run_bench gpus2_one_device 300 --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline
 [ -s profiles/${R}_bench_driver_line.json ] && python tools/latency_table.py profiles/${R}_bench_driver_line.json > profiles/${R}_td_latency_table.txt
 # the TaskDispatcher surface, natively
 { for a in "wait 2000 10000 50" "wait 2000 100000 20" "heartbeat 16000 1000000 3" "heartbeat 2000 100000 5" \
            "latency 2000 1000" "latency 8000 1000" "latency 16000 1000"; do
     echo "== td_native_bench $a"; timeout 300 ./tools/td_native_bench $a; done
   for a in "concurrent 2000 3000" "concurrent 16000 3000"; do echo "== td_native_bench $a"; timeout 300 ./tools/td_native_bench $a; done
+  # round 6: the 1 s expiration timer running (10^5 and 10^6 live leases), and K parked waiters on a
+  # saturated pool with the reference's multi-threaded build under the same workload beside it
+  for a in "timer 2000 100000 4" "timer 16000 1000000 5" "parked 300 2"; do echo "== td_native_bench $a"; timeout 600 ./tools/td_native_bench $a; done
+  echo "== oracle/_ref/ref_parked_bench 100 2 100 1000 (the reference, same workload)"
+  timeout 300 ./oracle/_ref/ref_parked_bench 100 2 100 1000
+  echo "== oracle/_ref/ref_parked_bench 20 1 10000"
+  timeout 300 ./oracle/_ref/ref_parked_bench 20 1 10000
   echo "== td_native_bench latency 2000 1000 (YDC_TUNE=resident=0: one launch per call)"
   YDC_TUNE=resident=0 timeout 300 ./tools/td_native_bench latency 2000 500
   echo "== td_native_bench latency 2000 1000 (YDC_TUNE=packed_tick=0: the reference's double as the key)"
@@ -53,11 +67,9 @@ done
     YDC_TUNE=resident=0 timeout 120 python tools/tick_probe.py $a 200; echo; done; } > profiles/${R}_tick_phases.txt 2>&1
 timeout 120 ./tests/tools/launch_probe 2000 > profiles/${R}_launch_probe.txt 2>&1
 timeout 300 python tools/commit_loop.py 300 > profiles/${R}_commit_loop.txt 2>&1
-# the walk of the dedicated tier's end on variants of cfg3's pool; the corner of DESIGN 9.7; two queues
-timeout 600 python tools/zone_probe.py > profiles/${R}_zone_probe.txt 2>&1
-{ timeout 200 python tools/cliff_probe.py; timeout 200 python tools/cliff_probe.py probe; } > profiles/${R}_cliff_probe.txt 2>&1
-{ for m in 0 1 3; do timeout 60 ./tests/tools/overlap_probe 200 150 1954 $m; echo; done; } > profiles/${R}_overlap_probe.txt 2>&1
-{ timeout 100 ./tests/tools/atomic_probe; timeout 100 ./tests/tools/atomic_probe 1250000; } > profiles/${R}_atomic_probe.txt 2>&1
+# the matching kernel's writes by buffer (WRITE_SIZE under YDC_TUNE variants)
+{ bash tools/pmc_match_writes.sh ${R}w cfg3 "cp_every=1" "cp_every=4" "cp_every=1024" "cp_every=4,fuse_passes=0"
+  bash tools/pmc_match_writes.sh ${R}w cfg4 "cp_every=1" "cp_every=4" "cp_every=1024"; } > profiles/${R}_match_writes.txt 2>&1
 # the matching kernel's phases (measurement build)
 for c in cfg2 cfg3 cfg4; do timeout 300 python tools/phase_probe.py $c 10 > profiles/${R}_${c}_match_phases.txt 2>&1; done
 [ -s gpurun_out/rccl_1rank_debug.log ] && cp gpurun_out/rccl_1rank_debug.log profiles/${R}_rccl_1rank_debug.log

@@ -9,6 +9,12 @@
 #include <cstring>
 #include <ctime>
 
+#if defined(__linux__)
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
+
 #include "../../include/yadcc_dispatch.h"
 
 using namespace std::literals;
@@ -54,6 +60,24 @@ std::vector<std::string> RequestorPrefixes(const std::string& location) {
     if (p == 0) break;
   }
   return out;
+}
+
+// Sleeps while *word == expected, at most `ns` nanoseconds (spurious returns are fine).
+inline void FutexWait(std::atomic<std::uint32_t>* word, std::uint32_t expected, long ns) {
+#if defined(__linux__)
+  timespec ts{0, ns};
+  syscall(SYS_futex, reinterpret_cast<std::uint32_t*>(word), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+#else
+  (void)word; (void)expected;
+  std::this_thread::sleep_for(std::chrono::nanoseconds(ns));
+#endif
+}
+inline void FutexWakeAll(std::atomic<std::uint32_t>* word) {
+#if defined(__linux__)
+  syscall(SYS_futex, reinterpret_cast<std::uint32_t*>(word), FUTEX_WAKE_PRIVATE, 0x7FFFFFFF, nullptr, nullptr, 0);
+#else
+  (void)word;
+#endif
 }
 
 inline std::uint64_t NowNs() {
@@ -1302,8 +1326,17 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
 
   for (auto* r : batch) {
     if (r->sleeping) r->cv.notify_one();
-    r->published.store(true, std::memory_order_release);
+    r->published.store(true, std::memory_order_seq_cst);
   }
+  WakeTurnSleepers();
+}
+
+// The end of a device turn (or of this thread's service): callers asleep for their answer look
+// again. The counter moves first; a caller that is on its way to sleep either sees it moved (the
+// futex compares) or is counted in turn_sleepers_ by the time it is read here.
+void GpuTaskDispatcher::WakeTurnSleepers() {
+  turn_seq_.fetch_add(1, std::memory_order_seq_cst);
+  if (turn_sleepers_.load(std::memory_order_seq_cst) != 0) FutexWakeAll(&turn_seq_);
 }
 
 WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& personality,
@@ -1323,25 +1356,31 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
   // Whoever holds allocation_lock_ next places everything that is queued, this request included:
   // its owner spins for the answer (one device turn away) instead of sleeping on the lock, and
   // takes the lock itself — placing everybody else's — when it is free.
+  // A short spin (the answer is one device turn away); then sleep until a turn ends — the holder
+  // serves the queue on its way out (Section), so a queued request is never stranded: either that
+  // exit sees it, or the lock is free when this thread looks.
   std::unique_lock held(allocation_lock_, std::defer_lock);
-  for (int spins = 0; busy_.load(std::memory_order_relaxed) || !held.try_lock(); ++spins) {
+  for (int spins = 0;;) {
     if (req.published.load(std::memory_order_acquire)) return req.result;
-    if (spins >= 20000) {  // (a long batch of somebody else's, or a parked request: sleep like the reference)
-      held.lock();
-      break;
-    }
+    if (!busy_.load(std::memory_order_relaxed) && held.try_lock()) break;
+    if (++spins < options_.caller_spins) {
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+      __builtin_ia32_pause();
 #endif
+      continue;
+    }
+    turn_sleepers_.fetch_add(1, std::memory_order_seq_cst);
+    const std::uint32_t seen = turn_seq_.load(std::memory_order_seq_cst);
+    if (!req.published.load(std::memory_order_seq_cst) && busy_.load(std::memory_order_seq_cst))
+      FutexWait(&turn_seq_, seen, 200000);  // (bounded: a turn that never ends — a hung device — must not hide the lock)
+    turn_sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+    spins = options_.caller_spins - options_.caller_spins / 4;
   }
   Section sec(this, std::move(held));
   std::unique_lock<std::mutex>& lk = sec.lock();
   for (;;) {
     if (!req.done) {
-      UnsafeDrainQueue();
-      // Requests that came in during that turn are placed before the lock changes hands (a new
-      // holder would do the same a hand-over later) — a few turns, then this caller goes home.
-      for (int extra = 0; extra < 3 && queued_.load(std::memory_order_relaxed) != 0; ++extra) UnsafeDrainQueue();
+      UnsafeDrainQueue();  // (what comes in during the turn is served on the way out: Section)
     }
     if (req.done) return req.result;
     // About to sleep: say so first, then look for queued FreeTasks once more — a FreeTask that

@@ -174,6 +174,9 @@ class GpuTaskDispatcher {
     // Own 1 s expiration thread (task_dispatcher.cc:81-82). Tests drive
     // OnExpirationTimer() themselves.
     bool start_expiration_timer = true;
+    // How long a caller whose request is queued spins for its answer (pause instructions; a
+    // device turn takes 7 - 40 us) before it sleeps until the end of the next turn.
+    int caller_spins = 3000;
     // Coarse steady clock (flare::ReadCoarseSteadyClock); tests inject a fake one.
     std::function<Clock::time_point()> clock;
   };
@@ -452,6 +455,12 @@ class GpuTaskDispatcher {
   // allocation_lock_ is held (a hint for the spinners of WaitForStartingNewTask: they read this
   // word — shared, in their caches — and go for the lock's own cache line only when it says free).
   std::atomic<bool> busy_{false};
+  // Callers whose request is queued spin briefly for their answer and then sleep until the end of
+  // the next device turn: turn_seq_ counts the turns, and a sleeper waits (futex) for it to move.
+  // Nothing of a request's own record is touched after its answer is published.
+  std::atomic<std::uint32_t> turn_seq_{0};
+  std::atomic<std::uint32_t> turn_sleepers_{0};
+  void WakeTurnSleepers();
   bool wake_pending_ = false;  // guarded by allocation_lock_
   void UnsafeServeWoken();
   bool UnsafeApplyQueuedFrees();  // true: something was applied (waiters were woken)
@@ -468,9 +477,16 @@ class GpuTaskDispatcher {
       d->UnsafeApplyQueuedFrees();
     }
     ~Section() {
-      // A FreeTask that found the lock taken has left its ids behind: nobody else may come by soon.
-      for (;;) {
+      // Whoever holds the lock serves what has queued up behind it before it goes: requests of
+      // callers that are spinning or asleep for their answer (a bounded number of turns — then
+      // the lock is let go and one of them takes over), and the ids a FreeTask left behind when
+      // it found the lock taken: nobody else may come by soon.
+      for (int turns = 0;; ++turns) {
         d_->UnsafeServeWoken();
+        if (turns < kExitTurns && d_->queued_.load(std::memory_order_relaxed) != 0) {
+          d_->UnsafeDrainQueue();
+          continue;
+        }
         d_->busy_.store(false, std::memory_order_relaxed);
         lk_.unlock();
         // Store-buffering with FreeTasks ("queue the ids; fence; try_lock" there, "unlock; fence;
@@ -478,12 +494,17 @@ class GpuTaskDispatcher {
         // lock free, or this load sees the queued ids. A failed try_lock orders nothing by itself
         // in the C++ model — the fences do not lean on the mutex implementation's own barriers.
         std::atomic_thread_fence(std::memory_order_seq_cst);
-        if (d_->free_queued_.load(std::memory_order_seq_cst) == 0) return;
-        if (!lk_.try_lock()) return;  // (the new holder applies them, on its way in or out)
+        const bool requests = d_->queued_.load(std::memory_order_seq_cst) != 0;
+        if (d_->free_queued_.load(std::memory_order_seq_cst) == 0 && !(requests && turns < kExitTurns)) {
+          if (requests) d_->WakeTurnSleepers();  // (this thread has done its share: one of them takes the lock)
+          return;
+        }
+        if (!lk_.try_lock()) return;  // (the new holder serves them, on its way in or out)
         d_->busy_.store(true, std::memory_order_relaxed);
         d_->UnsafeApplyQueuedFrees();
       }
     }
+    static constexpr int kExitTurns = 2;
     std::unique_lock<std::mutex>& lock() { return lk_; }
    private:
     GpuTaskDispatcher* d_;

@@ -3,7 +3,9 @@
 // TaskDispatcher (yadcc/scheduler/task_dispatcher.h:139-181).
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <string>
 #include <string_view>
@@ -54,6 +56,7 @@ int ydc_td_create(int device, const char* min_memory, int start_timer, int fake_
       return ydc::GpuTaskDispatcher::Clock::time_point(std::chrono::nanoseconds(td->fake_now_ns.load()));
     };
   }
+  if (const char* e = std::getenv("YDC_TD_SPINS")) opt.caller_spins = std::max(1, std::atoi(e));  // (measurements)
   td->impl = std::make_unique<ydc::GpuTaskDispatcher>(opt);
   *out = td;
   return YDC_OK;
