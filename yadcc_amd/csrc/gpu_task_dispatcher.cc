@@ -4,6 +4,7 @@
 #include "gpu_task_dispatcher.h"
 
 #include <algorithm>
+#include <queue>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -823,7 +824,7 @@ void GpuTaskDispatcher::UnsafeFreeTasks(const std::uint64_t* task_ids, std::size
 void GpuTaskDispatcher::UnsafeServeWoken() {
   if (!wake_pending_) return;
   wake_pending_ = false;
-  if (!waiting_.empty() || queued_.load(std::memory_order_relaxed) != 0) UnsafeDrainQueue();
+  if (parked_count_ != 0 || queued_.load(std::memory_order_relaxed) != 0) UnsafeDrainQueue();
 }
 
 void GpuTaskDispatcher::UnsafeSweepZombiesOf(Servant* servant, const RunningTaskView* reported,
@@ -1208,40 +1209,45 @@ void GpuTaskDispatcher::UnsafeCacheColumns(Pending* r) {
   r->cols_epoch = registry_epoch_;
 }
 
-void GpuTaskDispatcher::UnsafeDispatchSegmented(const std::vector<Pending*>& batch) {
-  for (Pending* r : batch) UnsafeCacheColumns(r);
-  for (Pending* r : batch) UnsafeCacheColumns(r);  // (an alias created on the way invalidated earlier ones)
-  sig_dead_.assign(sig_ids_.size(), 0);
-  // Segments of what one resident tick takes; while whole segments are granted the pool evidently
-  // has room, and the segments grow towards one batch of everything that is left.
-  std::size_t cap = 64;
-  std::vector<Pending*> seg;
-  auto flush = [&] {
-    if (seg.empty()) return;
-    UnsafeDispatch(seg);
-    bool any_dead = false;
-    for (Pending* r : seg)
-      if (!r->done && r->result.device_error == 0) {  // Timeout: so will every later request like it
-        sig_dead_[r->sig] = 1;
-        any_dead = true;
-      }
-    if (!any_dead) cap *= 4;
-    seg.clear();
-  };
-  const auto now = Now();
-  for (Pending* r : batch) {
-    if (sig_dead_[r->sig]) {
-      // Not sent: the answer is known. For the reference this was one more turn of the waiter's
-      // loop that found no free servant (task_dispatcher.cc:109-118).
-      ++r->tries;
-      r->tried_epoch = wake_epoch_;
-      if (oplog_on_) LogWait(r->request, r->expires_in, now, 2, 0, nullptr, r->tries);
-      continue;
-    }
-    seg.push_back(r);
-    if (seg.size() >= cap) flush();
+void GpuTaskDispatcher::UnsafePark(Pending* r) {
+  if (r->sig >= parked_.size()) parked_.resize((std::size_t)r->sig + 1);
+  ParkedList& l = parked_[r->sig];
+  r->park_prev = l.tail;
+  r->park_next = nullptr;
+  if (l.tail) l.tail->park_next = r; else l.head = r;
+  l.tail = r;
+  r->parked = true;
+  ++parked_count_;
+}
+
+void GpuTaskDispatcher::UnsafeUnpark(Pending* r) {
+  if (!r->parked) return;
+  ParkedList& l = parked_[r->sig];
+  if (r->park_prev) r->park_prev->park_next = r->park_next; else l.head = r->park_next;
+  if (r->park_next) r->park_next->park_prev = r->park_prev; else l.tail = r->park_prev;
+  r->park_prev = r->park_next = nullptr;
+  r->parked = false;
+  --parked_count_;
+}
+
+// The interning tables changed (a servant registered, changed its environments or expired): the
+// parked requests' triples are numbered anew. Rare, O(parked).
+void GpuTaskDispatcher::UnsafeReindexParked() {
+  std::vector<Pending*> all;
+  all.reserve(parked_count_);
+  for (ParkedList& l : parked_)
+    for (Pending* r = l.head; r; r = r->park_next) all.push_back(r);
+  for (Pending* r : all) {
+    r->park_prev = r->park_next = nullptr;
+    r->parked = false;
   }
-  flush();
+  parked_.clear();
+  parked_count_ = 0;
+  std::sort(all.begin(), all.end(), [](const Pending* a, const Pending* b) { return a->arrival < b->arrival; });
+  for (Pending* r : all) UnsafeCacheColumns(r);
+  for (Pending* r : all) UnsafeCacheColumns(r);  // (an alias created on the way invalidated earlier ones)
+  for (Pending* r : all) UnsafePark(r);
+  parked_epoch_ = registry_epoch_;
 }
 
 void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
@@ -1275,7 +1281,7 @@ void GpuTaskDispatcher::UnsafeDispatch(const std::vector<Pending*>& batch) {
       r->result.status = WaitStatus::EnvironmentNotFound;
       if (oplog_on_) LogWait(r->request, r->expires_in, now, 1, 0, nullptr, r->tries);
     } else if (out[i] == YDC_IDX_TIMEOUT) {
-      r->tried_epoch = wake_epoch_;  // stays pending until its deadline (:116-118)
+      // (stays pending until its deadline, :116-118)
       if (oplog_on_) LogWait(r->request, r->expires_in, now, 2, 0, nullptr, r->tries);
     } else {
       r->done = true;
@@ -1294,37 +1300,99 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
   // in that order, so a turn that places its request has applied its free (the reference's
   // FreeTask is synchronous, task_dispatcher.cc:165-188 — program order must survive the queue).
   std::vector<std::uint64_t> frees;
+  std::vector<Pending*> arrivals;
   {
     std::scoped_lock _(queue_lock_);
     if (!free_queue_.empty()) {
       frees.swap(free_queue_);
       free_queued_.store(0, std::memory_order_seq_cst);
     }
-    waiting_.insert(waiting_.end(), queue_.begin(), queue_.end());
+    arrivals.assign(queue_.begin(), queue_.end());
     queue_.clear();
     queued_.store(0, std::memory_order_relaxed);
   }
   UnsafeApplyFrees(frees);
   wake_pending_ = false;  // (this turn is the retry)
-  // One device batch, arrival order. A parked request is only retried after FreeTask has
-  // woken the waiters (wake_epoch_): in the reference a waiter sleeps until notify_all or
-  // its deadline, and a heartbeat wakes nobody (task_dispatcher.cc:116-118,187,190-220).
-  std::vector<Pending*> batch;
-  for (auto* r : waiting_)
-    if (!r->done && r->tried_epoch != wake_epoch_) batch.push_back(r);
-  if (batch.size() <= 64) UnsafeDispatch(batch); else UnsafeDispatchSegmented(batch);
-
-  // (`batch` is reused for the served ones: after its `published` flag is up a record may be gone)
-  batch.clear();
-  for (auto* r : waiting_)
-    if (r->done) batch.push_back(r);
-  waiting_.erase(std::remove_if(waiting_.begin(), waiting_.end(), [](Pending* r) { return r->done; }),
-                 waiting_.end());
+  // Arrival order: the parked requests (where the waiters were woken since they were last placed:
+  // in the reference a waiter sleeps until notify_all or its deadline, and a heartbeat wakes
+  // nobody, task_dispatcher.cc:116-118,187,190-220), then what has just come in.
+  for (Pending* r : arrivals) UnsafeCacheColumns(r);
+  for (Pending* r : arrivals) UnsafeCacheColumns(r);  // (an alias created on the way invalidated earlier ones)
+  if (parked_count_ != 0 && parked_epoch_ != registry_epoch_) UnsafeReindexParked();
+  if (parked_count_ == 0) parked_epoch_ = registry_epoch_;
+  for (Pending* r : arrivals) r->arrival = next_arrival_++;
+  const bool retry = parked_count_ != 0 && retried_epoch_ != wake_epoch_;
+  retried_epoch_ = wake_epoch_;
+  if (!retry && arrivals.empty()) return;
+  sig_dead_.assign(sig_ids_.size() + 1, 0);
+  std::vector<Pending*> served, seg;
+  // Segments: a handful of requests first (one freed slot serves one waiter: 8 requests cost the
+  // resident tick 13 us, 64 cost 40), four times as many while whole segments are granted.
+  std::size_t cap = 8;
+  const auto now = Now();
+  auto flush = [&] {
+    if (seg.empty()) return;
+    UnsafeDispatch(seg);
+    bool any_dead = false;
+    for (Pending* r : seg) {
+      if (r->done) {
+        UnsafeUnpark(r);
+        served.push_back(r);
+      } else {  // Timeout: so will every later request of its triple in this turn
+        sig_dead_[r->sig] = 1;
+        any_dead = true;
+        if (!r->parked) UnsafePark(r);
+      }
+    }
+    if (!any_dead) cap *= 4;
+    seg.clear();
+  };
+  // Not sent, the answer is known: for the reference this was one more turn of the waiter's loop
+  // that found no free servant (task_dispatcher.cc:109-118).
+  auto known_timeout = [&](Pending* r) {
+    ++r->tries;
+    if (oplog_on_) LogWait(r->request, r->expires_in, now, 2, 0, nullptr, r->tries);
+  };
+  if (retry) {
+    // The heads of the triples' lists, merged by arrival number.
+    using Head = std::pair<std::uint64_t, Pending*>;
+    std::priority_queue<Head, std::vector<Head>, std::greater<Head>> heads;
+    for (ParkedList& l : parked_)
+      if (l.head) heads.push({l.head->arrival, l.head});
+    while (!heads.empty()) {
+      Pending* r = heads.top().second;
+      heads.pop();
+      if (sig_dead_[r->sig]) {
+        // (the rest of this triple's list stays where it is; walked only for the test log)
+        if (oplog_on_)
+          for (Pending* q = r; q; q = q->park_next) known_timeout(q);
+        continue;
+      }
+      Pending* next = r->park_next;
+      seg.push_back(r);
+      if (seg.size() >= cap) {
+        flush();
+        // (the flush may have unparked `next`'s predecessors, never `next` itself: it was not in the segment)
+      }
+      if (next) heads.push({next->arrival, next});
+    }
+    // (a segment still open may hold requests whose successors are already in the heap: the heap is
+    // empty here, so nothing is pending behind it)
+  }
+  for (Pending* r : arrivals) {
+    if (sig_dead_[r->sig]) {
+      known_timeout(r);
+      UnsafePark(r);
+      continue;
+    }
+    seg.push_back(r);
+    if (seg.size() >= cap) flush();
+  }
+  flush();
   // Requests of other threads may just have been completed by this one: wake exactly their owners
   // (those that have given up spinning sleep until their deadline). A sleeping owner cannot return
   // before this thread lets go of the lock; a spinning one may as soon as `published` is up.
-
-  for (auto* r : batch) {
+  for (auto* r : served) {
     if (r->sleeping) r->cv.notify_one();
     r->published.store(true, std::memory_order_seq_cst);
   }
@@ -1418,7 +1486,7 @@ WaitResult GpuTaskDispatcher::WaitForStartingNewTask(const TaskPersonality& pers
     UnsafeApplyQueuedFrees();
     if (req.done) return req.result;  // a concurrent drain served us meanwhile
     if (timed_out) {
-      waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), &req), waiting_.end());
+      UnsafeUnpark(&req);
       WaitResult r;
       r.status = WaitStatus::Timeout;  // :116-118
       return r;

@@ -422,7 +422,6 @@ class GpuTaskDispatcher {
     std::chrono::nanoseconds expires_in;
     Clock::time_point deadline;
     bool done = false;                   // (the thread that holds allocation_lock_)
-    std::uint64_t tried_epoch = ~0ull;  // wake epoch of the last failed attempt
     std::uint32_t tries = 0;            // placement attempts so far (1 unless it was parked)
     // The request as the device sees it (interned digest, host id of the requestor), looked up once
     // and kept while the interning tables stay as they are (registry_epoch_): a parked request is
@@ -430,6 +429,10 @@ class GpuTaskDispatcher {
     // among the parked requests' (UnsafeDispatchSegmented).
     std::uint64_t cols_epoch = ~0ull;
     std::uint32_t col_env = 0, col_rip = 0, col_name = 0, sig = 0;
+    // Parked (found no free servant): a member of its triple's list, in arrival order.
+    std::uint64_t arrival = 0;
+    Pending *park_prev = nullptr, *park_next = nullptr;
+    bool parked = false;
     WaitResult result;
     // A parked owner sleeps on its OWN condition variable (with allocation_lock_): whoever frees a
     // slot re-places the parked requests itself, as one device batch, and wakes only the owners of
@@ -545,10 +548,23 @@ class GpuTaskDispatcher {
   int UnsafePlaceAndGrant(std::size_t n, const RequestView* requests, std::chrono::nanoseconds expires_in,
                           Sink&& sink);
   void UnsafeDispatch(const std::vector<Pending*>& batch);
-  // Many parked requests (a saturated pool): placed in arrival order in segments; a (digest,
-  // min_version, requestor host) triple that has come back Timeout in this turn does so for every
-  // later request of the turn — grants only take capacity away — so those are not sent at all.
-  void UnsafeDispatchSegmented(const std::vector<Pending*>& batch);
+  // Parked requests are kept per (digest, min_version, requestor host) triple, each list in
+  // arrival order. When the waiters are woken (wake_epoch_ moved) they are placed again in global
+  // arrival order — a merge of the lists' heads — in segments of what a device turn takes; a triple
+  // that has come back Timeout in this turn does so for every later request of the turn (grants
+  // only take capacity away), so the rest of its list is not even looked at: a FreeTask on a pool
+  // with ten thousand parked waiters of a handful of triples costs one small device turn.
+  struct ParkedList {
+    Pending *head = nullptr, *tail = nullptr;
+  };
+  std::vector<ParkedList> parked_;        // by Pending::sig, valid for parked_epoch_
+  std::uint64_t parked_epoch_ = ~0ull;    // the registry_epoch_ the triples were numbered in
+  std::size_t parked_count_ = 0;
+  std::uint64_t next_arrival_ = 0;
+  std::uint64_t retried_epoch_ = 0;       // wake epoch at which the parked requests were last placed again
+  void UnsafePark(Pending* r);
+  void UnsafeUnpark(Pending* r);
+  void UnsafeReindexParked();
   void UnsafeCacheColumns(Pending* r);
   void UnsafeDrainQueue();
   void TimerLoop();
@@ -651,7 +667,6 @@ class GpuTaskDispatcher {
   SpinLock queue_lock_;
   std::deque<Pending*> queue_;
   std::atomic<std::uint32_t> queued_{0};  // entries of queue_ (read without the lock)
-  std::vector<Pending*> waiting_;  // found no free servant; arrival order
 
   RunningTaskBookkeeper running_task_bookkeeper_;
   HostStats host_stats_;  // guarded by allocation_lock_
