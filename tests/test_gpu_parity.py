@@ -465,6 +465,10 @@ def test_group_walk_random_sparse_pools(seed, monkeypatch):
         kw["initial_running"] = True
     if seed % 4 == 1:
         monkeypatch.setenv("YDC_WALK_PACKED", "0")  # (head ranks and class ids in two arrays)
+    if seed % 3 == 2:
+        # the fetch of the entry after next in plain variables instead of parked in a254 / a255
+        # (wide_kernel.h: plain_park) — the variant that rests on nothing the compiler does not know
+        monkeypatch.setenv("YDC_WALK_PARK", "0")
     sv, tk = cases.random_case(**kw)
     c = binding.Context(device=0)
     try:
@@ -541,6 +545,29 @@ def test_hand_off_that_never_arrives(monkeypatch):
             assert st["rounds"] >= 2
         sv, tk = synth.make_config("cfg2")
         check(c, sv, tk)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("cp_every", ["1", "2", "4", "1024"])
+@pytest.mark.parametrize("patient", [True, False])
+def test_checkpoint_spacing(cp_every, patient, monkeypatch):
+    """Checkpoints before every block of 64 requests of a chunk (round 5), every second, every
+    fourth (the default) or only the chunk's first (match_kernel.h: MatchBuffers::cp_every) — with
+    chunks of 512 requests, and with waves that do not wait for their predecessor's hand-off
+    (YDC_HAND_TRIES=0), so that most chunks are replayed by later launches, which is where the
+    early stops at checkpoints decide how much of a chunk is replayed: same placement every time."""
+    monkeypatch.setenv("YDC_CP_EVERY", cp_every)
+    monkeypatch.setenv("YDC_CHUNK_SIZE", "512")
+    if not patient:
+        monkeypatch.setenv("YDC_HAND_TRIES", "0")
+    c = binding.Context(device=0)
+    try:
+        for seed, envs, n in ((171, 1, 30_000), (172, 4, 80_000), (173, 6, 60_000)):
+            sv, tk = cases.random_case(seed=seed, n_tasks=n, n_servants=900, n_envs=envs, self_frac=0.3,
+                                       unknown_env_frac=0.001, oversubscribed=seed == 173)
+            st = check(c, sv, tk)
+            assert patient or st["rounds"] >= 2
     finally:
         c.close()
 

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
                                                     uint32_t* __restrict__ slot_of, SharedIpTable shared,
                                                     uint32_t round, DeviceParams* prm, WideLists wl,
                                                     uint32_t n_rows, uint32_t n_list, uint32_t whole_batch,
-                                                    uint32_t cbits) {
+                                                    uint32_t cbits, uint32_t plain_park) {
   extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
   const uint32_t lane = threadIdx.x, C = L.n_classes, W = T.words;
   if (lane == 0) prm->n_changed[round & 63] = 0;
@@ -786,11 +786,19 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
   // go from there to the LDS (`flush`), both in inline assembly: a loaded VALUE the compiler knows
   // of is copied to the register of the variable it merges into right behind the load, i.e. waited
   // for on the spot — a round trip to the L2 per iteration, a quarter of the walk.
-  uint32_t pend_c = 0, pend_i = 0;
+  // plain_park (YDC_TUNE=walk_park=0): the same fetch in two ordinary variables — the compiler waits
+  // for them where they are loaded, so the walk is a quarter slower, but nothing rests on registers
+  // it does not know about. Kept selectable and run by the parity tests beside the default.
+  uint32_t pend_c = 0, pend_i = 0, plain_p = 0, plain_g = 0;
   bool pend_on = false;
   // young: this iteration's first pickers have issued their fetches already (two loads, younger than
   // any this flush is for — the counter is in order): wait for all but those.
   auto flush = [&](bool young) {
+    if (pend_on && plain_park) {
+      S.ng[pend_c] = plain_g;
+      S.np[pend_c] = L.list_p ? plain_p : pend_i;
+      pend_on = false;
+    }
     if (pend_on) {
       const uint32_t a_np = (uint32_t)(uintptr_t)(S.np + pend_c), a_ng = (uint32_t)(uintptr_t)(S.ng + pend_c);
       if (young) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -999,8 +1007,11 @@ __global__ __launch_bounds__(64) void k_walk_groups(ClassLists L, TaskTable T, u
         // wants it (issued at the commit it arrived a third of a microsecond late). A first picker
         // that ends up waiting has fetched for nothing.
         const bool fetching = cand && !loser && cur0 + 2 < end0;
-        const bool young = __ballot(fetching) != 0;
-        if (fetching) {
+        const bool young = __ballot(fetching) != 0 && !plain_park;
+        if (fetching && plain_park) {
+          plain_g = L.list_g[(size_t)(cur0 + 2) * L.stride];
+          plain_p = L.list_p ? L.list_p[(size_t)(cur0 + 2) * L.stride] : 0u;
+        } else if (fetching) {
           const uint32_t* ag = L.list_g + (size_t)(cur0 + 2) * L.stride;
           const uint32_t* ap = L.list_p ? L.list_p + (size_t)(cur0 + 2) * L.stride : ag;
           asm volatile("global_load_dword a254, %0, off\n\tglobal_load_dword a255, %1, off"

@@ -378,6 +378,7 @@ struct ydc_context {
   uint32_t opt_cp_every = 4;  // checkpoints before every 4th block of a chunk (MatchBuffers::cp_every)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  bool opt_walk_park = true;  // k_walk_groups parks its fetches in a254 / a255 (0: in plain variables)
   bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
   // The walk of the wide kernel with prefetch waves (YDC_WALK_PREFETCH=1). Off: measured slower
   // than the walker's own one-ahead fetch (57 against 35 ms of 100k picks; the scan was the cost).
@@ -804,6 +805,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("shard_sort")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = tune_value("packed_sort")) c->opt_packed_sort = atoi(s) != 0;
   if (const char* s = tune_value("binsort")) c->opt_binsort = atoi(s) != 0;
+  if (const char* s = tune_value("walk_park")) c->opt_walk_park = atoi(s) != 0;
   if (const char* s = tune_value("fuse_passes")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = tune_value("warm_up")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
   if (const char* s = tune_value("hand_tries")) c->opt_hand_tries = (uint32_t)std::max(0, atoi(s));
@@ -2100,12 +2102,14 @@ int run_planned_batch(ydc_context* c, const BatchPlan& p, const ydc_task_soa* tk
           YDC_LAUNCH(c, "k_walk_groups", k_walk_groups<true>, dim3(1), dim3(64),
                      group_walk_lds_bytes(p.C, n_rows, n_list, true), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
                      c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
-                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits);
+                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits,
+                     c->opt_walk_park ? 0u : 1u);
         else
           YDC_LAUNCH(c, "k_walk_groups", k_walk_groups<false>, dim3(1), dim3(64),
                      group_walk_lds_bytes(p.C, n_rows, n_list), st, p.L, p.T, N, p.cs, p.K, c->d_guess[0].p,
                      c->d_endst.p, c->d_dirty.p, c->d_slot_of.p, p.shared, rounds, prm,
-                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits);
+                     WideLists{c->d_row_of.p, c->d_elig_off.p, c->d_elig_cls.p}, n_rows, n_list, 1u, walk_cbits,
+                     c->opt_walk_park ? 0u : 1u);
         ++rounds;
         HIP_TRY(c, hipMemcpyAsync(c->h_prm, prm, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
