@@ -1330,6 +1330,18 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
   // resident tick 13 us, 64 cost 40), four times as many while whole segments are granted.
   std::size_t cap = 8;
   const auto now = Now();
+  // A request that has just come in, found no free servant and whose deadline has passed already
+  // (the RPC's "do not wait": timeout == now) is answered here and now — its owner would otherwise
+  // have to get hold of the lock only to find that out (task_dispatcher.cc:116-118: wait_until a
+  // time that has passed returns at once).
+  auto expire_now = [&](Pending* r) {
+    if (r->deadline > now) return false;
+    r->done = true;
+    r->result = WaitResult{};
+    r->result.status = WaitStatus::Timeout;
+    served.push_back(r);
+    return true;
+  };
   auto flush = [&] {
     if (seg.empty()) return;
     UnsafeDispatch(seg);
@@ -1341,7 +1353,7 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
       } else {  // Timeout: so will every later request of its triple in this turn
         sig_dead_[r->sig] = 1;
         any_dead = true;
-        if (!r->parked) UnsafePark(r);
+        if (!r->parked && !expire_now(r)) UnsafePark(r);
       }
     }
     if (!any_dead) cap *= 4;
@@ -1382,7 +1394,7 @@ void GpuTaskDispatcher::UnsafeDrainQueue() {
   for (Pending* r : arrivals) {
     if (sig_dead_[r->sig]) {
       known_timeout(r);
-      UnsafePark(r);
+      if (!expire_now(r)) UnsafePark(r);
       continue;
     }
     seg.push_back(r);

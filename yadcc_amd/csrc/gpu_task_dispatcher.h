@@ -360,10 +360,14 @@ class GpuTaskDispatcher {
       return ns >= 0 ? ns / 1000000000 : -((-ns + 999999999) / 1000000000);  // floor
     }
     void File(std::uint64_t id, Clock::time_point expires_at) {
-      const std::int64_t second = SecondOf(expires_at);
-      if (!last_ || last_second_ != second) {
-        last_ = &buckets_[second];  // (std::map: the address of a mapped vector is stable)
-        last_second_ = second;
+      // (the grants of one batch run out at the same instant: no division, no lookup for them)
+      if (!last_ || expires_at != last_time_) {
+        const std::int64_t second = SecondOf(expires_at);
+        if (!last_ || last_second_ != second) {
+          last_ = &buckets_[second];  // (std::map: the address of a mapped vector is stable)
+          last_second_ = second;
+        }
+        last_time_ = expires_at;
       }
       last_->push_back(id);
       ++entries_;
@@ -412,6 +416,7 @@ class GpuTaskDispatcher {
     std::map<std::int64_t, std::vector<std::uint64_t>> buckets_;
     std::vector<std::uint64_t>* last_ = nullptr;  // the bucket of the last File (a batch's grants share it)
     std::int64_t last_second_ = 0;
+    Clock::time_point last_time_{};
     std::size_t entries_ = 0;
   };
   struct EnvEntry {
