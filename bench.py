@@ -211,10 +211,42 @@ def stream_record(args, steps, warmup, ref_ticks, device=0):
         got = ctx.stream_tick_inplace(len(who), len(rel), len(tk["env_id"]))
         in_place.append(time.perf_counter() - s0)
         es.commit(got.copy())
+    # The same ticks with the step enqueued kernel by kernel instead of replayed from its hipGraph
+    # (YDC_TUNE=stream_graph=0; a context of its own, the stream from its start): the configuration
+    # names the captured step, so that is what `value` is; this is what the capture costs or saves.
+    eager = None
+    try:
+        os.environ["YDC_STREAM_GRAPH"] = "0"
+        ctx2 = binding.Context(device=device)
+    finally:
+        os.environ.pop("YDC_STREAM_GRAPH", None)
+    try:
+        es2 = streaming.EventStream(sv, 10_000, 10_000)
+        ctx2.upload_servants(pack.to_abi_columns(sv))
+        ctx2.stream_begin(es2.hb + 8, 10_000, 10_000)
+        el, e_ok, n2 = [], True, min(300, max(60, steps))
+        for t in range(20 + n2):
+            who, rows, rel, tk = es2.next_tick()
+            s0 = time.perf_counter()
+            got = ctx2.stream_tick(who, rows, rel, tk)
+            dt = time.perf_counter() - s0
+            if t < fx_ticks:
+                e_ok &= synth.placement_hash(got) == int(fx["digest"][t])
+            es2.commit(got)
+            if t >= 20:
+                el.append(dt)
+        eager = {"ms_per_step": 1e3 * sum(el) / len(el), "p99_ms": 1e3 * percentile(el, 0.99), "ticks": len(el),
+                 "parity_vs_reference_fixture": bool(e_ok) if fx_ticks else None,
+                 "what": "the same step enqueued kernel by kernel (YDC_TUNE=stream_graph=0) instead of replayed "
+                         "from the captured hipGraph"}
+        ctx2.stream_end()
+    finally:
+        ctx2.close()
     out = {
         "metric": METRIC,
         "value": granted / sum(lat), "unit": "assignments/s", "n_gpus": 1,
         "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * sum(lat) / len(lat),
+        "tick_enqueued_eagerly": eager,
         "tick_assembled_in_place": {"ms_per_step": 1e3 * sum(in_place) / len(in_place),
                                     "p99_ms": 1e3 * percentile(in_place, 0.99), "ticks": len(in_place),
                                     "what": "the tick written into the library's page-locked arena by the caller "
@@ -1055,6 +1087,9 @@ def compact(rec):
     c["granted"] = rec["stats"].get("granted")
     if "tick_assembled_in_place" in rec:
         c["tick_assembled_in_place"] = {k: rec["tick_assembled_in_place"][k] for k in ("ms_per_step", "p99_ms", "ticks")}
+    if rec.get("tick_enqueued_eagerly"):
+        c["tick_enqueued_eagerly"] = {k: rec["tick_enqueued_eagerly"][k] for k in ("ms_per_step", "p99_ms", "ticks",
+                                                                                  "parity_vs_reference_fixture")}
     if "end_to_end" in rec:
         c["end_to_end_ms"] = rec["end_to_end"]["ms_per_batch"]
         c["end_to_end_p99_ms"] = rec["end_to_end"]["p99_ms"]

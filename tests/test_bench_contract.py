@@ -176,6 +176,8 @@ def test_bench_cfg5_streaming_line():
     validate(j, steps=40, streaming=True)
     assert j["parity_ticks"] >= 20 and "hipGraph" in j["config"]["workload"]
     assert j["parity_vs_reference_fixture"] is True and j["fixture_ticks"] == 45
+    e = j["tick_enqueued_eagerly"]  # (the same step without the graph replay, beside it)
+    assert e["parity_vs_reference_fixture"] is True and e["ms_per_step"] > 0 and e["ticks"] >= 60
 
 
 @pytest.mark.gpu

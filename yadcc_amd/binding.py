@@ -180,7 +180,7 @@ _TUNE_KEYS = ("DEBUG_SIM", "CHUNK_SIZE", "TARGET_CHUNKS", "FUSED_CLASS", "OWN_GU
               "PACKED_CLASS", "SHARD_SORT", "PACKED_SORT", "BINSORT", "FUSE_PASSES", "WARM_UP",
               "HAND_TRIES", "CP_EVERY", "WALK_PARK", "LEVEL_TAB", "WIDE", "WALK_PREFETCH", "WIDE_LISTS", "GROUP_BINSORT",
               "ZERO_COPY", "HOST_IN", "BINSORT_VERIFY", "BINSORT_MAX_SLOTS", "SHARD_MARGIN",
-              "ROUNDS_PER_CHECK", "WALK_AFTER", "OUTCOME_STORE", "STREAM_ZERO_COPY", "COMMIT_SWAP", "RELEASE_COUNTED", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "PACKED_TICK", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
+              "ROUNDS_PER_CHECK", "WALK_AFTER", "OUTCOME_STORE", "STREAM_ZERO_COPY", "STREAM_GRAPH", "COMMIT_SWAP", "RELEASE_COUNTED", "SMALL_BATCH", "RESIDENT", "RESIDENT_IDLE_MS", "PACKED_TICK", "SORT_ITEMS", "IPC_SLOT_WORDS", "IPC_TIMEOUT_MS", "IPC_COARSE")
 _tune_injected = ""
 
 

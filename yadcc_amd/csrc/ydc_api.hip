@@ -378,6 +378,7 @@ struct ydc_context {
   uint32_t opt_cp_every = 4;  // checkpoints before every 4th block of a chunk (MatchBuffers::cp_every)
   uint32_t opt_hand_tries = kHandTries;  // (tests: 0 makes most waves give up and leave their chunk to pass 2)
   bool opt_binsort = true;
+  bool opt_stream_graph = true;  // the streaming step is replayed from its hipGraph (0: enqueued eagerly)
   bool opt_walk_park = true;  // k_walk_groups parks its fetches in a254 / a255 (0: in plain variables)
   bool opt_group_binsort = true;  // multi-GPU: bin sort of the whole registry before windowed radix (YDC_GROUP_BINSORT=0)
   // The walk of the wide kernel with prefetch waves (YDC_WALK_PREFETCH=1). Off: measured slower
@@ -805,6 +806,7 @@ int ydc_create(int device, uint32_t max_servants, uint32_t max_tasks, uint32_t m
   if (const char* s = tune_value("shard_sort")) c->opt_shard_sort = atoi(s) != 0;
   if (const char* s = tune_value("packed_sort")) c->opt_packed_sort = atoi(s) != 0;
   if (const char* s = tune_value("binsort")) c->opt_binsort = atoi(s) != 0;
+  if (const char* s = tune_value("stream_graph")) c->opt_stream_graph = atoi(s) != 0;
   if (const char* s = tune_value("walk_park")) c->opt_walk_park = atoi(s) != 0;
   if (const char* s = tune_value("fuse_passes")) c->opt_fuse_passes = atoi(s) != 0;
   if (const char* s = tune_value("warm_up")) c->opt_warm_up = (uint32_t)std::min(64, std::max(1, atoi(s)));
@@ -3849,16 +3851,14 @@ void stream_release(ydc_context* c) {
   sm.stale = true;
 }
 
-// One capture of the step with the columns as they are now (plan: made for them).
-int stream_capture_one(ydc_context* c, const BatchPlan& plan, bool by_swap, hipGraph_t* g_out,
-                       hipGraphExec_t* e_out) {
+// The step itself, enqueued on the context's stream (inside a capture, or — stream_graph=0 — as it is).
+int stream_enqueue_step(ydc_context* c, const BatchPlan& plan, bool by_swap) {
   auto& sm = c->stream_mode;
   hipStream_t st = c->stream;
-  HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
   int rc = YDC_OK;
   auto cap = [&](hipError_t e) {
     if (e != hipSuccess && rc == YDC_OK)
-      rc = fail(c, YDC_ERR_HIP, "capture: %s", hipGetErrorString(e));
+      rc = fail(c, YDC_ERR_HIP, "streaming step: %s", hipGetErrorString(e));
   };
   const size_t T = sm.max_tasks;
   // Round 5: no copy node. The tick's inputs are read where the host put them (k_apply_tick and
@@ -3889,6 +3889,15 @@ int stream_capture_one(ydc_context* c, const BatchPlan& plan, bool by_swap, hipG
   }
   if (!zc) cap(hipMemcpyAsync(sm.h_out, c->d_out_idx.p, T * 4, hipMemcpyDeviceToHost, st));
   if (!outcome_stored) cap(hipMemcpyAsync(c->h_prm, c->d_prm.p, sizeof(DeviceParams), hipMemcpyDeviceToHost, st));
+  return rc;
+}
+
+// One capture of the step with the columns as they are now (plan: made for them).
+int stream_capture_one(ydc_context* c, const BatchPlan& plan, bool by_swap, hipGraph_t* g_out,
+                       hipGraphExec_t* e_out) {
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  const int rc = stream_enqueue_step(c, plan, by_swap);
   hipGraph_t g = nullptr;
   hipError_t ee = hipStreamEndCapture(st, &g);
   if (ee != hipSuccess) return fail(c, YDC_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
@@ -4157,7 +4166,16 @@ int ydc_stream_tick_wide(ydc_context* c, const uint32_t* upd_idx, const ydc_serv
   const bool second = sm.swaps && c->d_running.p == sm.run_b;
   if (sm.swaps && !second && c->d_running.p != sm.run_a)
     return fail(c, YDC_ERR_NOT_CONVERGED, "streaming: the running_tasks column is neither of the captured ones");
-  HIP_TRY(c, hipGraphLaunch(second ? sm.exec_b : sm.exec, c->stream));
+  if (c->opt_stream_graph) {
+    HIP_TRY(c, hipGraphLaunch(second ? sm.exec_b : sm.exec, c->stream));
+  } else {
+    // (measurement, stream_graph=0: the same step enqueued kernel by kernel instead of replayed)
+    const bool was_profiling = c->profiling;
+    c->profiling = false;
+    const int erc = stream_enqueue_step(c, second ? sm.plan_b : sm.plan, sm.swaps);
+    c->profiling = was_profiling;
+    if (erc) return erc;
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   ++sm.ticks;
