@@ -255,7 +255,68 @@ static void NullDigestAndLeasePages() {
   CHECK(td.host_stats().lease_pages <= 2);
 }
 
+// Round 6: leases are filed under the second in which they run out, and the timer opens only the
+// buckets that are due (gpu_task_dispatcher.h: LeaseWheel). Against a plain model — a lease is a
+// zombie once a tick has seen expires_at < now, task_dispatcher.cc:523-535 —: random leases, renewals
+// that move them forwards and backwards across seconds, frees, ticks at random times, with the
+// sweep of stale entries forced to run all the time (lease_sweep_slack = 16).
+static void LeaseWheelAgainstModel() {
+  std::int64_t now_ns = 5'000'000'000;
+  GpuTaskDispatcher::Options opt;
+  opt.start_expiration_timer = false;
+  opt.lease_sweep_slack = 16;
+  opt.clock = [&now_ns] { return GpuTaskDispatcher::Clock::time_point(std::chrono::nanoseconds(now_ns)); };
+  GpuTaskDispatcher td(opt);
+  for (int i = 0; i < 24; ++i) td.KeepServantAlive(Servant("10.2.0." + std::to_string(i) + ":1", 64, "d"), 100000s);  // 24 x 64 slots
+  struct Lease {
+    std::uint64_t id;
+    std::int64_t expires_ns;
+    bool zombie;
+  };
+  std::vector<Lease> live;
+  unsigned seed = 99;
+  auto rnd = [&] { return seed = seed * 1664525u + 1013904223u, seed >> 8; };
+  TaskPersonality t{"9.9.9.9", 0, "d"};
+  for (int step = 0; step < 6000; ++step) {
+    const unsigned ev = rnd() % 100;
+    if (ev < 35 && live.size() < 1200) {
+      const std::int64_t lease = 200'000'000ll + (std::int64_t)(rnd() % 6000) * 1'000'000;
+      auto g = td.WaitForStartingNewTask(t, std::chrono::nanoseconds(lease), td.Now(), false);
+      CHECK(g.ok);
+      live.push_back({g->task_id, now_ns + lease, false});
+    } else if (ev < 65 && !live.empty()) {
+      Lease& l = live[rnd() % live.size()];
+      const std::int64_t lease = 100'000'000ll + (std::int64_t)(rnd() % 5000) * 1'000'000;
+      const bool ok = td.KeepTaskAlive(l.id, std::chrono::nanoseconds(lease));
+      CHECK(ok == !l.zombie);  // :154-162: a zombie is not renewable
+      if (ok) l.expires_ns = now_ns + lease;
+    } else if (ev < 80 && !live.empty()) {
+      const std::size_t at = rnd() % live.size();
+      td.FreeTask(live[at].id);
+      live[at] = live.back();
+      live.pop_back();
+    } else if (ev < 90) {
+      now_ns += (std::int64_t)(rnd() % 900) * 1'000'000;
+    } else {
+      td.OnExpirationTimer();
+      for (Lease& l : live)
+        if (!l.zombie && l.expires_ns < now_ns) l.zombie = true;
+      if (step % 7 == 0) {  // every zombie flag, through the dump
+        const std::string dump = td.DumpInternals();
+        std::size_t zombies = 0;
+        for (std::size_t p = dump.find("\"zombie\":true"); p != std::string::npos; p = dump.find("\"zombie\":true", p + 1)) ++zombies;
+        std::size_t want = 0;
+        for (const Lease& l : live) want += l.zombie;
+        CHECK(zombies == want);
+      }
+    }
+  }
+  // (the index holds the live leases and a bounded number of stale entries)
+  CHECK(td.host_stats().lease_wheel_entries <= 4 * live.size() + 16 + 1);
+}
+
 int main() {
+  LeaseWheelAgainstModel();
   NullDigestAndLeasePages();
   WakeOrder();
   CompletedByOthers();

@@ -747,7 +747,7 @@ bool GpuTaskDispatcher::KeepTaskAlive(std::uint64_t task_id, std::chrono::nanose
 void GpuTaskDispatcher::FileLease(std::uint64_t id, Clock::time_point expires_at) {
   lease_wheel_.File(id, expires_at);
   // Renewals and early frees leave entries behind; swept when they dominate.
-  if (lease_wheel_.entries() > 4 * tasks_.size() + (1u << 20))
+  if (lease_wheel_.entries() > 4 * tasks_.size() + options_.lease_sweep_slack)
     lease_wheel_.Sweep([this](std::uint64_t i, std::int64_t second) {
       const Task* t = tasks_.find(i);
       return t && !t->zombie && LeaseWheel::SecondOf(t->expires_at) == second;

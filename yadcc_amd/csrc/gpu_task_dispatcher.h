@@ -174,6 +174,9 @@ class GpuTaskDispatcher {
     // Own 1 s expiration thread (task_dispatcher.cc:81-82). Tests drive
     // OnExpirationTimer() themselves.
     bool start_expiration_timer = true;
+    // The expiry index keeps entries of renewed and freed leases until their second comes round;
+    // they are swept when they outnumber the live leases four to one by this much (tests: small).
+    std::size_t lease_sweep_slack = 1u << 20;
     // How long a caller whose request is queued spins for its answer (pause instructions; a
     // device turn takes 7 - 40 us) before it sleeps until the end of the next turn.
     int caller_spins = 3000;
